@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE itself (imported from
+/root/reference, CPU PyTorch) on seeded inputs.  Run in the build container
+only; the GPU box has no /root/reference and uses the committed fixtures.
+
+    python tools/make_golden.py            # writes tests/golden/{small_f32,small_f64}.npz, summary.json
+
+What is captured:
+  * small shape (S,H,L,B)=(64,96,8,16): full recon/mu/logvar/loss, all ten
+    gradients, parameters and Adam moments after 1 and 3 optimizer steps, and a
+    20-step loss trajectory -- in fp32 (the reference's dtype) and in fp64
+    (`model.double()`, the tight pin for the oracle's formulas).
+  * smoke shape (512,2048,8,32) and the benchmark shape C2 (1024,2048,64,4096):
+    loss, per-tensor L2 norms and 16 sampled elements of outputs and gradients
+    at step 0, and a 20-step loss trajectory.
+  * default-init statistics and a checksum of `VAE(64,96,8)` under
+    torch.manual_seed(0).
+
+The only intervention in the reference is that `torch.randn_like`
+(rawvae/model.py:25) is replaced, for the duration of each forward call, by a
+function returning the seeded eps array, so the same eps can be handed to the
+HIP path.  Inputs come from oracle/inputs.py (numpy PCG64).
+"""
+import json
+import os
+import sys
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import rawvae.model as ref  # noqa: E402  (the reference, namespace package)
+from oracle.inputs import PARAM_NAMES, make_eps, make_frames, make_params  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference/"), ref.__file__
+
+KL_BETA = 1e-4
+LR = 1e-4
+N_TRAJ = 20
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+@contextmanager
+def fixed_eps(eps_t):
+    orig = torch.randn_like
+
+    def _eps(t, *a, **k):
+        assert t.shape == eps_t.shape
+        return eps_t.to(t.dtype)
+    torch.randn_like = _eps
+    try:
+        yield
+    finally:
+        torch.randn_like = orig
+
+
+def build(S, H, L, dtype):
+    model = ref.VAE(S, H, L)
+    params = make_params(S, H, L, seed=0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    if dtype == torch.float64:
+        model = model.double()
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    return model, opt
+
+
+def step_inputs(i, B, S, L, dtype):
+    x = torch.from_numpy(make_frames(B, S, seed=1234 + i)).to(dtype)
+    eps = torch.from_numpy(make_eps(B, L, seed=4321 + i)).to(dtype)
+    return x, eps
+
+
+def run_step(model, opt, x, eps, S, do_step=True):
+    opt.zero_grad()
+    with fixed_eps(eps):
+        recon, mu, logvar = model(x)
+    loss = ref.loss_function(recon, x, mu, logvar, KL_BETA, S)
+    loss.backward()
+    grads = {k: p.grad.detach().clone().numpy() for k, p in model.named_parameters()}
+    if do_step:
+        opt.step()
+    return recon.detach().numpy(), mu.detach().numpy(), logvar.detach().numpy(), loss.item(), grads
+
+
+def adam_state(model, opt):
+    out = {}
+    for k, p in model.named_parameters():
+        st = opt.state[p]
+        out["exp_avg/" + k] = st["exp_avg"].numpy().copy()
+        out["exp_avg_sq/" + k] = st["exp_avg_sq"].numpy().copy()
+        out["param/" + k] = p.detach().numpy().copy()
+    return out
+
+
+def small_case(dtype, tag):
+    S, H, L, B = 64, 96, 8, 16
+    model, opt = build(S, H, L, dtype)
+    out = {"shape": np.array([S, H, L, B]), "kl_beta": KL_BETA, "lr": LR}
+    traj = []
+    for i in range(N_TRAJ):
+        x, eps = step_inputs(i, B, S, L, dtype)
+        recon, mu, logvar, loss, grads = run_step(model, opt, x, eps, S)
+        traj.append(loss)
+        if i == 0:
+            out.update(recon=recon, mu=mu, logvar=logvar, loss=np.array(loss))
+            for k in PARAM_NAMES:
+                out["grad/" + k] = grads[k]
+        if i in (0, 2):
+            for k, v in adam_state(model, opt).items():
+                out["after%d/%s" % (i + 1, k)] = v
+    out["traj"] = np.array(traj)
+    np.savez_compressed(os.path.join(OUT, "small_%s.npz" % tag), **out)
+    print("small", tag, "loss0", traj[0], "loss19", traj[-1])
+
+
+def summary_case(S, H, L, B, dtype):
+    model, opt = build(S, H, L, dtype)
+    rng = np.random.default_rng(99)
+    traj = []
+    info = {}
+    for i in range(N_TRAJ):
+        x, eps = step_inputs(i, B, S, L, dtype)
+        recon, mu, logvar, loss, grads = run_step(model, opt, x, eps, S)
+        traj.append(loss)
+        if i == 0:
+            tensors = {"recon": recon, "mu": mu, "logvar": logvar}
+            tensors.update({"grad/" + k: grads[k] for k in PARAM_NAMES})
+            for k, t in tensors.items():
+                flat = t.reshape(-1).astype(np.float64)
+                idx = np.sort(rng.choice(flat.size, size=min(16, flat.size), replace=False))
+                info[k] = {"l2": float(np.sqrt((flat ** 2).sum())),
+                           "sum": float(flat.sum()),
+                           "idx": [int(j) for j in idx],
+                           "val": [float(flat[j]) for j in idx]}
+    return {"shape": [S, H, L, B], "loss0": traj[0], "traj": traj, "tensors": info}
+
+
+def init_stats():
+    torch.manual_seed(0)
+    m = ref.VAE(64, 96, 8)
+    st = {}
+    for k, p in m.state_dict().items():
+        a = p.numpy().astype(np.float64)
+        fan_in = m.state_dict()[k.split(".")[0] + ".weight"].shape[1]
+        st[k] = {"min": float(a.min()), "max": float(a.max()), "sum": float(a.sum()),
+                 "bound": float(1.0 / np.sqrt(fan_in)), "first": [float(v) for v in a.reshape(-1)[:4]]}
+    return st
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    small_case(torch.float32, "f32")
+    small_case(torch.float64, "f64")
+    summ = {"kl_beta": KL_BETA, "lr": LR, "torch": torch.__version__,
+            "seeds": {"params": 0, "frames": "1234+step", "eps": "4321+step", "sample_idx": 99},
+            "init_seed0_64_96_8": init_stats(), "cases": {}}
+    for name, shp in (("smoke", (512, 2048, 8, 32)), ("c2", (1024, 2048, 64, 4096))):
+        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            summ["cases"]["%s_%s" % (name, tag)] = summary_case(*shp, dtype)
+            print(name, tag, "loss0", summ["cases"]["%s_%s" % (name, tag)]["loss0"])
+    # Dataset known answers measured on the reference classes during the survey
+    # (rawvae/dataset.py:99-121,141-160): 30 s @ 44.1 kHz.
+    summ["dataset"] = {"n_samples": 1323000, "segment_length": 1024, "hop": 128,
+                       "padded": 1323008, "len": 10329, "batch": 4096, "last_batch": 2137,
+                       "bad_segment_length": 1000}
+    with open(os.path.join(OUT, "summary.json"), "w") as f:
+        json.dump(summ, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
