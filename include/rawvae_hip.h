@@ -1,0 +1,221 @@
+/* rawvae_hip.h -- C ABI of librawvae_hip.so: the MI355X (gfx950) training path of
+ * the raw-audio VAE.
+ *
+ * The reference (kelseyicotton/rawaudiovae_kelsey) has no FFI of its own: its hot
+ * path sits behind a Python module surface (rawvae/model.py, train.py).  Each entry
+ * point below names the reference statement(s) whose arithmetic it replaces; the
+ * Python classes in rawaudiovae_kelsey_amd/ (re-exported as rawvae.model) keep the
+ * reference's signatures and call these through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *   - every pointer is a DEVICE pointer owned by the caller; the library allocates
+ *     nothing except the opaque rv_plan / rv_graph host objects.
+ *   - every function returns 0 on success or a negative RV_ERR_* code;
+ *     rv_last_error() gives the message.  Nothing throws, aborts or synchronises
+ *     unless its name ends in _sync; all launches are safe under stream capture.
+ *   - "bf16 padded" operands: row-major bfloat16 whose extents are multiples of the
+ *     GEMM tile (rows of the batch: 128; feature dims: 128; latent: 64) with zero
+ *     padding -- see rv_pad_dims().  fp32 tensors at the reference boundary
+ *     (frames, recon, mu, logvar, parameters, gradients) keep their exact shapes.
+ */
+#ifndef RAWVAE_HIP_H
+#define RAWVAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_OK 0
+#define RV_ERR_SHAPE (-1)
+#define RV_ERR_NULL (-2)
+#define RV_ERR_HIP (-3)
+#define RV_ERR_UNSUPPORTED (-4)
+#define RV_ERR_STATE (-5)
+
+#define RV_ACT_NONE 0
+#define RV_ACT_RELU 1
+
+int rv_version(void);
+const char* rv_last_error(void);
+
+/* Padded extents used by every bf16 operand: Bp, Sp, Hp multiples of 128, Lp of 64. */
+int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, long* Lp);
+
+/* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (ld = cols_p).
+ * Replaces the implicit fp32 operand read of F.linear (model.py:20) for frames and
+ * is how weight shadows are (re)built after load_state_dict.  If `step_counter` is
+ * non-NULL the kernel also increments *step_counter (device int64) once: it is the
+ * first kernel of a training step. */
+int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16,
+                     long rows_p, long cols_p, long long* step_counter, void* stream);
+
+/* y = act(x W^T + b) -> bf16.  nn.Linear + F.relu, model.py:20 (fc1) and :29 (fc3).
+ * x [Mp,Kp] bf16, w [Np,Kp] bf16 (nn.Linear [out,in] layout), bias [Np] fp32 or NULL. */
+int rv_linear_fwd(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias,
+                  long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
+
+/* Same contraction, fp32 output written as `splits` partial slabs of [Mp,Np]
+ * (slab s covers K range s*Kp/splits..); bias (may be NULL) is added by slab 0 only.
+ * Used for the fused mu|logvar head GEMM, model.py:21 (fc21, fc22). */
+int rv_linear_fwd_f32(const void* x_bf16, long ldx, const void* w_bf16, long ldw,
+                      const float* bias, long Mp, long Np, long Kp, int splits, float* y_f32,
+                      long ldy, void* stream);
+
+/* recon = tanh(h3 W4^T + b4), model.py:30, fused with the reconstruction half of
+ * loss_function (model.py:39) and its derivative:
+ *   recon   (optional) exact [B,S] fp32
+ *   if x != NULL: mse_partial[block] = sum (recon-x)^2 over the block's valid elements
+ *                 dP4 bf16 [Bp,Sp]   = (2/(B*S)) (recon-x)(1-recon^2)   (0 in padding)
+ *                 db4_partial [Bp/128][Sp] column sums of dP4 (optional)
+ * n_mse_partials = (Bp/128)*(Sp/128). */
+int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, long ldw,
+                           const float* b4, long Bp, long Sp, long Hp, long B, long S,
+                           const float* x, long ldx, float* recon, long ld_recon,
+                           void* dP4_bf16, long ld_dp4, float* mse_partial, float* db4_partial,
+                           void* stream);
+
+/* dX = dY W (autograd of F.linear, train.py:191).  dy [Mp,Kp] bf16, w [Kp,Np] bf16
+ * ([out,in] layout, consumed as-is through transposing LDS reads).
+ *   mask != NULL : dx_bf16 = (mask > 0) ? dX : 0   (ReLU', threshold_backward) and
+ *                  colsum_partial [Mp/128][Np] (optional) = column sums = bias grads
+ *   mask == NULL : dx_f32 written as `splits` fp32 partial slabs [Mp,Np]. */
+int rv_linear_dgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, long Mp,
+                    long Np, long Kp, const void* mask_bf16, long ldmask, void* dx_bf16,
+                    long lddx, float* colsum_partial, float* dx_f32, long lddx32, int splits,
+                    void* stream);
+
+/* dW = dY^T X as `splits` fp32 partial slabs [Mp(out), Np(in)] (split over the batch).
+ * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS
+ * reads.  Autograd of F.linear w.r.t. weight, train.py:191. */
+int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp,
+                    long Np, long Kp, int splits, float* dw_f32_slabs, long lddw, void* stream);
+
+/* Reparameterisation forward, model.py:23-26, fused with the KL half of
+ * loss_function (model.py:45):
+ *   mulv_slabs [splits][Bp][2Lp] fp32 partial head outputs (mu at col l, logvar at Lp+l)
+ *   -> mulv [Bp][2Lp] fp32 (summed, zero in padding), z bf16 [Bp][Lp],
+ *      kl_partial[block] = sum over valid (b,l) of 1 + logvar - mu^2 - exp(logvar).
+ * eps: explicit [B,L] fp32 when eps_in != NULL (parity runs), otherwise generated
+ * on-device (Philox4x32-10 + Box-Muller, keyed by seed and *step_counter) and
+ * written to eps_out [B,L].  n_kl_partials = ceil(Bp*Lp/256). */
+int rv_reparam_fwd(const float* mulv_slabs, int splits, long Bp, long Lp, long B, long L,
+                   const float* eps_in, float* eps_out, unsigned long long seed,
+                   const long long* step_counter, float* mulv, void* z_bf16, float* kl_partial,
+                   void* stream);
+
+/* Backward of reparameterize + KL:
+ *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
+ * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums
+ * dbh_partial [Bp/64][2Lp] (bias grads of fc21|fc22).  Block 0 also finishes the
+ * loss: loss_out[0] = sum(mse_partial)/(B S) + kl_beta*(-0.5*sum(kl_partial)/(B L)),
+ * loss_out[1] = mse term, loss_out[2] = KL term (pass NULL partials to skip).  When
+ * step_counter != NULL and ring > 0, loss_out is a ring of [ring][4] floats and the
+ * slot written is (*step_counter - 1) % ring, so graph replays log every step. */
+int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
+                   const float* mulv, const float* eps, float kl_beta, void* dmulv_bf16,
+                   float* dbh_partial, const float* mse_partial, int n_mse,
+                   const float* kl_partial, int n_kl, float* loss_out,
+                   const long long* step_counter, int ring, void* stream);
+
+/* loss_function(recon_x, x, mu, logvar, kl_beta, segment_length), model.py:38-47, as ONE
+ * wave-reduced kernel over exact-shape fp32 tensors; also emits the gradients autograd
+ * would produce for (recon, mu, logvar) so loss.backward() needs no second pass.
+ * workspace: rv_loss_fused_workspace_bytes() bytes, zero-initialised once by the caller.
+ * loss_out[0..2] = total, mse, kld.  Any of the gradient pointers may be NULL. */
+long rv_loss_fused_workspace_bytes(void);
+int rv_loss_fused(const float* recon, const float* x, const float* mu, const float* logvar,
+                  long B, long S, long L, float kl_beta, float* loss_out, float* d_recon,
+                  float* d_mu, float* d_logvar, void* workspace, void* stream);
+
+/* z = mu + eps*exp(logvar/2), exact-shape fp32 (VAE.reparameterize called on its own,
+ * e.g. tutorial.ipynb:505).  eps_in NULL -> generated from (seed, offset). */
+int rv_reparameterize(const float* mu, const float* logvar, long n, const float* eps_in,
+                      float* eps_out, unsigned long long seed, unsigned long long offset,
+                      float* z, void* stream);
+
+/* Standard normal draws (replaces torch.randn_like, model.py:25). */
+int rv_randn(float* out, long n, unsigned long long seed, unsigned long long offset,
+             void* stream);
+
+/* One parameter tensor as seen by the fused optimizer / gradient finaliser. */
+typedef struct rv_param_desc {
+  long offset;             /* element offset of the tensor in the flat fp32 arenas   */
+  long rows, cols;         /* exact shape ([out,in]; bias: rows=1)                   */
+  const float* grad_slabs; /* partial-gradient slabs: element (r,c) of slab s is at  */
+  long grad_ld;            /*   grad_slabs[s*grad_split_stride + r*grad_ld + c]      */
+  long grad_split_stride;
+  int grad_splits;
+  void* shadow_bf16;       /* padded bf16 copy refreshed with the new weight (or NULL) */
+  float* shadow_f32;       /* padded fp32 copy (biases as read by GEMM epilogues), or NULL */
+  long shadow_ld;
+} rv_param_desc;
+
+/* torch.optim.Adam(lr) step (train.py:163,193: betas 0.9/0.999, eps 1e-8, no weight
+ * decay, no amsgrad) over the flat arenas in one launch: sums the gradient slabs,
+ * updates exp_avg / exp_avg_sq / param, rewrites the bf16 shadow, and (optional)
+ * stores the summed gradient to grad_out (flat, exact) for inspection.
+ * t = *step_counter (1-based).  grad_scale multiplies the summed gradient first
+ * (1/world_size after an all-reduce SUM).  `descs` is HOST memory (copied per call). */
+int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                  float* exp_avg_sq, float* grad_out, float lr, float grad_scale,
+                  const long long* step_counter, void* stream);
+
+/* Sum gradient slabs into the flat exact-shape gradient arena only (no update):
+ * what loss.backward() leaves in .grad; also the all-reduce payload builder. */
+int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream);
+
+/* ---- whole-step plan: one call enqueues forward, loss, backward (and Adam) ---- */
+typedef struct rv_plan rv_plan;
+
+typedef struct rv_plan_buffers {
+  /* flat fp32 arenas, PARAM order fc1.w fc1.b fc21.w fc21.b fc22.w fc22.b fc3.w fc3.b fc4.w fc4.b */
+  float* param; float* exp_avg; float* exp_avg_sq; float* grad; /* grad may be NULL */
+  void* workspace;             /* rv_plan_workspace_bytes() bytes, zero-initialised   */
+  long long* step_counter;     /* device int64, number of steps started               */
+  float* loss_ring;            /* [ring][4] fp32: total, mse, kld, unused             */
+  int ring;
+} rv_plan_buffers;
+
+#define RV_PHASE_FWD 1      /* cast, fc1, heads, reparam, fc3, fc4+loss              */
+#define RV_PHASE_BWD_A 2    /* fc4 dgrad/wgrad, fc3 wgrad/dgrad, reparam bwd          */
+#define RV_PHASE_BWD_B 4    /* heads dgrad/wgrad, fc1 wgrad                           */
+#define RV_PHASE_FINALIZE_A 8  /* fc3,fc4 slabs -> flat fp32 grad arena (bucket A: ready after BWD_A) */
+#define RV_PHASE_FINALIZE_B 32 /* fc1,fc21,fc22 slabs -> flat grad arena (bucket B)                  */
+#define RV_PHASE_ADAM 16       /* optimizer + bf16 shadow refresh                                    */
+#define RV_PHASE_ALL_LOCAL (1 | 2 | 4 | 16)
+
+int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
+void rv_plan_destroy(rv_plan*);
+long rv_plan_workspace_bytes(const rv_plan*);
+int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
+/* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
+int rv_plan_refresh_shadows(rv_plan*, void* stream);
+/* Enqueue the selected phases of one training step (train.py:184-193) on `stream`.
+ * x: exact [B,S] fp32 frames.  eps: explicit [B,L] or NULL (on-device RNG, `seed`).
+ * recon_out: optional exact [B,S].  adam_from_flat != 0 makes the Adam phase read the
+ * flat grad arena (e.g. after an all-reduce), scaled by grad_scale, instead of the slabs. */
+int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* recon_out,
+                 float kl_beta, float lr, float grad_scale, int adam_from_flat,
+                 unsigned long long seed, void* stream);
+/* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */
+void* rv_plan_buffer(rv_plan*, const char* name, long* n_bytes);
+
+/* ---- hipGraph capture of any sequence of the calls above on one stream ---- */
+typedef struct rv_graph rv_graph;
+int rv_graph_begin(void* stream);
+int rv_graph_end(void* stream, rv_graph** out);
+int rv_graph_launch(rv_graph*, void* stream);
+void rv_graph_destroy(rv_graph*);
+
+/* Timing helper for bench.py: HIP events on the caller's stream. */
+int rv_event_create(void** ev);
+int rv_event_record(void* ev, void* stream);
+int rv_event_elapsed_ms_sync(void* ev_start, void* ev_stop, float* ms);
+void rv_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAWVAE_HIP_H */

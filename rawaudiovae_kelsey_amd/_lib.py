@@ -1,0 +1,141 @@
+"""ctypes binding of librawvae_hip.so (C ABI: include/rawvae_hip.h).
+
+The library is the product path: if it is missing or a call fails this module
+raises -- there is no CPU or PyTorch fallback for GPU tensors.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librawvae_hip.so")
+
+c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
+c_u64, c_i64 = C.c_ulonglong, C.c_longlong
+
+
+class RvError(RuntimeError):
+    pass
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("offset", c_long), ("rows", c_long), ("cols", c_long),
+                ("grad_slabs", c_void_p), ("grad_ld", c_long), ("grad_split_stride", c_long),
+                ("grad_splits", c_int), ("shadow_bf16", c_void_p), ("shadow_f32", c_void_p),
+                ("shadow_ld", c_long)]
+
+
+class PlanBuffers(C.Structure):
+    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("grad", c_void_p), ("workspace", c_void_p), ("step_counter", c_void_p),
+                ("loss_ring", c_void_p), ("ring", c_int)]
+
+
+PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
+PHASE_FINALIZE_A, PHASE_ADAM, PHASE_FINALIZE_B = 8, 16, 32
+PHASE_ALL_LOCAL = PHASE_FWD | PHASE_BWD_A | PHASE_BWD_B | PHASE_ADAM
+ACT_NONE, ACT_RELU = 0, 1
+
+# name -> (restype, argtypes); every int-returning entry is error-checked by _wrap.
+_SIGS = {
+    "rv_version": (c_int, []),
+    "rv_last_error": (C.c_char_p, []),
+    "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
+    "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long,
+                                 c_void_p, c_void_p]),
+    "rv_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
+                              c_int, c_void_p, c_long, c_void_p]),
+    "rv_linear_fwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+                                  c_long, c_int, c_void_p, c_long, c_void_p]),
+    "rv_decode_out_loss_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+                                       c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long,
+                                       c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "rv_linear_dgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
+                                c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
+                                c_int, c_void_p]),
+    "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
+                                c_void_p, c_long, c_void_p]),
+    "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
+                               c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
+                               c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "rv_loss_fused_workspace_bytes": (c_long, []),
+    "rv_loss_fused": (c_int, [c_void_p] * 4 + [c_long, c_long, c_long, c_float] + [c_void_p] * 6),
+    "rv_reparameterize": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_u64, c_u64,
+                                  c_void_p, c_void_p]),
+    "rv_randn": (c_int, [c_void_p, c_long, c_u64, c_u64, c_void_p]),
+    "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_float, c_float, c_void_p, c_void_p]),
+    "rv_grad_finalize": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
+    "rv_plan_create": (c_int, [C.POINTER(c_void_p), c_long, c_long, c_long, c_long]),
+    "rv_plan_destroy": (None, [c_void_p]),
+    "rv_plan_workspace_bytes": (c_long, [c_void_p]),
+    "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
+    "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
+    "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                             c_float, c_int, c_u64, c_void_p]),
+    "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
+    "rv_graph_begin": (c_int, [c_void_p]),
+    "rv_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "rv_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "rv_graph_destroy": (None, [c_void_p]),
+    "rv_event_create": (c_int, [C.POINTER(c_void_p)]),
+    "rv_event_record": (c_int, [c_void_p, c_void_p]),
+    "rv_event_elapsed_ms_sync": (c_int, [c_void_p, c_void_p, C.POINTER(c_float)]),
+    "rv_event_destroy": (None, [c_void_p]),
+}
+
+EXPORTED = tuple(_SIGS)
+_lib = None
+
+
+def _wrap(fn, name):
+    def call(*a):
+        rc = fn(*a)
+        if rc != 0:
+            msg = _lib.rv_last_error()
+            raise RvError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
+        return rc
+    call.__name__ = name
+    return call
+
+
+class _Lib:
+    def __init__(self, path):
+        self._cdll = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            checked = res is c_int and name != "rv_version"
+            setattr(self, name, _wrap(fn, name) if checked else fn)
+
+
+def lib():
+    """Load librawvae_hip.so once.  Raises RvError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvError(
+                "librawvae_hip.so not found at %s: build it with `python -c \"import "
+                "__graft_entry__ as g; g.build()\"` or `make -C rawaudiovae_kelsey_amd/csrc`. "
+                "There is no fallback path." % LIB_PATH)
+        _lib = _Lib(LIB_PATH)
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream or None
+
+
+def pad_dims(B, S, H, L):
+    o = [c_long() for _ in range(4)]
+    lib().rv_pad_dims(B, S, H, L, *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)

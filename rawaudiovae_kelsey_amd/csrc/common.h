@@ -1,0 +1,75 @@
+// Shared device/host helpers for librawvae_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace rv {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef const __attribute__((address_space(1))) void* glb_cptr;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+// tanh(y) = 1 - 2/(1+exp(2y)); abs error ~1e-7 (hardware exp2/rcp), saturates cleanly.
+__device__ __forceinline__ float fast_tanh(float y) {
+  const float e = __expf(2.0f * y);
+  return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+}
+
+}  // namespace rv
+
+// ---- host-side error plumbing (C-ABI functions return int, never throw) ----
+enum {
+  RV_OK = 0,
+  RV_ERR_SHAPE = -1,
+  RV_ERR_NULL = -2,
+  RV_ERR_HIP = -3,
+  RV_ERR_UNSUPPORTED = -4,
+  RV_ERR_STATE = -5,
+};
+
+extern thread_local char rv_err_buf[512];
+int rv_fail(int code, const char* fmt, ...);
+
+#define RV_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return rv_fail(RV_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,         \
+                     hipGetErrorString(_e));                                          \
+  } while (0)
+
+#define RV_CHECK_LAUNCH() RV_HIP(hipGetLastError())
+
+#define RV_REQUIRE(cond, code, ...)                        \
+  do {                                                     \
+    if (!(cond)) return rv_fail(code, __VA_ARGS__);        \
+  } while (0)

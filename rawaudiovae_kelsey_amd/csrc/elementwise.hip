@@ -1,0 +1,513 @@
+// HBM-bound kernels of the VAE training step (gfx950): operand cast/pad, on-device
+// normal RNG, reparameterisation forward/backward fused with the KL term, the
+// standalone single-kernel loss (MSE + KL + their gradients), and the fused
+// multi-tensor Adam / gradient finaliser.  C ABI: include/rawvae_hip.h.
+#include "common.h"
+#include "../../include/rawvae_hip.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+using namespace rv;
+
+thread_local char rv_err_buf[512] = "";
+
+int rv_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(rv_err_buf, sizeof(rv_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+  uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+
+// Four N(0,1) draws for counter (idx4, offset): Box-Muller on two uniform pairs.
+__device__ __forceinline__ void normal4(uint64_t seed, uint64_t idx4, uint64_t offset, float* o) {
+  const u32x4 r = philox4x32_10(seed, idx4, offset);
+  const float inv32 = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)r.x + 0.5f) * inv32, u1 = ((float)r.y + 0.5f) * inv32;
+  const float u2 = ((float)r.z + 0.5f) * inv32, u3 = ((float)r.w + 0.5f) * inv32;
+  const float ra = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f) + 1e-30f));
+  const float rb = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f) + 1e-30f));
+  float s, c;
+  sincospif(2.0f * u1, &s, &c);
+  o[0] = ra * c; o[1] = ra * s;
+  sincospif(2.0f * u3, &s, &c);
+  o[2] = rb * c; o[3] = rb * s;
+}
+
+__device__ __forceinline__ float normal1(uint64_t seed, uint64_t idx, uint64_t offset) {
+  float o[4];
+  normal4(seed, idx >> 2, offset, o);
+  return o[idx & 3];
+}
+
+__global__ void __launch_bounds__(256) k_randn(float* out, long n, uint64_t seed, uint64_t offset) {
+  const long n4 = (n + 3) / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float o[4];
+    normal4(seed, (uint64_t)i, offset, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i * 4 + j < n) out[i * 4 + j] = o[j];
+  }
+}
+
+// ------------------------------------------------------------------ cast + pad
+// One thread per 8 output bf16 (16 B store).  Source rows are read as two float4
+// when in range and aligned, scalar at the ragged edge.
+__global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__ src, long rows,
+                                                       long cols, long ld_src,
+                                                       bf16_t* __restrict__ dst, long rows_p,
+                                                       long cols_p, long long* step_counter) {
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
+  const long cpr = cols_p / 8;
+  const long total = rows_p * cpr;
+  const bool vec_ok = (ld_src % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr, c = (i % cpr) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (r < rows) {
+      const float* s = src + r * ld_src + c;
+      if (vec_ok && c + 8 <= cols) {
+        const float4 a = *reinterpret_cast<const float4*>(s);
+        const float4 b = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c + j < cols) v[j] = s[j];
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(dst + r * cols_p + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------ reparam forward + KL
+// One thread per (b, l) of the padded [Bp, Lp] latent grid.
+__global__ void __launch_bounds__(256)
+k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, long B, long L,
+              const float* __restrict__ eps_in, float* __restrict__ eps_out, uint64_t seed,
+              const long long* __restrict__ step_counter, float* __restrict__ mulv,
+              bf16_t* __restrict__ z, float* __restrict__ kl_partial) {
+  __shared__ float red[4];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long b = i / Lp, l = i % Lp;
+  const long L2p = 2 * Lp;
+  float kl = 0.f;
+  if (b < Bp) {
+    float mu = 0.f, lv = 0.f, zz = 0.f;
+    if (b < B && l < L) {
+      for (int s = 0; s < splits; ++s) {
+        const float* sl = slabs + (long)s * Bp * L2p + b * L2p;
+        mu += sl[l];
+        lv += sl[Lp + l];
+      }
+      float e;
+      if (eps_in) {
+        e = eps_in[b * L + l];
+      } else {
+        e = normal1(seed, (uint64_t)(b * L + l), step_counter ? (uint64_t)*step_counter : 0);
+        eps_out[b * L + l] = e;
+      }
+      const float sd = __expf(0.5f * lv);
+      zz = mu + e * sd;
+      kl = 1.f + lv - mu * mu - sd * sd;
+    }
+    mulv[b * L2p + l] = mu;
+    mulv[b * L2p + Lp + l] = lv;
+    z[b * Lp + l] = (bf16_t)zz;
+  }
+  const float s = block_sum_256(kl, red);
+  if (threadIdx.x == 0) kl_partial[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ reparam backward (+ loss finish)
+// Block handles 64 batch rows x all Lp columns: thread -> (l = tid % Lp, r0 = tid / Lp),
+// rows r0, r0 + 256/Lp, ...  Column sums (bias grads of fc21|fc22) are reduced through LDS.
+__global__ void __launch_bounds__(256)
+k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, long B, long L,
+              long S, const float* __restrict__ mulv, const float* __restrict__ eps, float kl_beta,
+              bf16_t* __restrict__ dmulv, float* __restrict__ dbh_partial,
+              const float* __restrict__ mse_partial, int n_mse,
+              const float* __restrict__ kl_partial, int n_kl, float* __restrict__ loss_out,
+              const long long* __restrict__ step_counter, int ring) {
+  extern __shared__ float sh[];  // [256/Lp... ] sized 2*256 floats
+  const int tid = threadIdx.x;
+  const long L2p = 2 * Lp;
+  const int rows_par = (int)(256 / Lp);  // Lp in {64,128,256}
+  const int l = (int)(tid % Lp), r0 = (int)(tid / Lp);
+  const float inv_nk = 1.0f / ((float)B * (float)L);
+  float cs_mu = 0.f, cs_lv = 0.f;
+  for (int r = r0; r < 64; r += rows_par) {
+    const long b = (long)blockIdx.x * 64 + r;
+    float dmu = 0.f, dlv = 0.f;
+    if (b < B && l < L) {
+      float dz = 0.f;
+      for (int s = 0; s < splits; ++s) dz += dz_slabs[(long)s * Bp * Lp + b * Lp + l];
+      const float mu = mulv[b * L2p + l], lv = mulv[b * L2p + Lp + l];
+      const float e = eps[b * L + l];
+      const float sd = __expf(0.5f * lv);
+      dmu = dz + kl_beta * mu * inv_nk;
+      dlv = dz * e * 0.5f * sd + kl_beta * 0.5f * (sd * sd - 1.f) * inv_nk;
+    }
+    dmulv[b * L2p + l] = (bf16_t)dmu;
+    dmulv[b * L2p + Lp + l] = (bf16_t)dlv;
+    cs_mu += dmu;
+    cs_lv += dlv;
+  }
+  sh[tid] = cs_mu;
+  sh[256 + tid] = cs_lv;
+  __syncthreads();
+  if (dbh_partial && tid < Lp) {
+    float a = 0.f, c = 0.f;
+    for (int q = 0; q < rows_par; ++q) {
+      a += sh[q * Lp + tid];
+      c += sh[256 + q * Lp + tid];
+    }
+    dbh_partial[(long)blockIdx.x * L2p + tid] = a;
+    dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
+  }
+  if (blockIdx.x == 0 && loss_out && mse_partial && kl_partial) {
+    __syncthreads();
+    float m = 0.f, k = 0.f;
+    for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+    for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+    float* red = sh;
+    m = block_sum_256(m, red);
+    k = block_sum_256(k, red);
+    if (tid == 0) {
+      const float mse = m / ((float)B * (float)S);
+      const float kld = -0.5f * k * inv_nk;
+      if (step_counter && ring > 0) loss_out += 4 * ((*step_counter - 1) % ring);
+      loss_out[0] = mse + kl_beta * kld;
+      loss_out[1] = mse;
+      loss_out[2] = kld;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ standalone fused loss
+// loss_function (model.py:38-47) in one launch.  Every block reduces its slice with
+// wave shuffles, publishes two partials, and the last block to arrive (agent-scope
+// release / ticket / acquire) sums the partials in index order, so the result does not
+// depend on arrival order.  Workspace: [0] ticket (u32), [64..] partials.
+constexpr int LOSS_MAX_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256)
+k_loss_fused(const float* __restrict__ recon, const float* __restrict__ x,
+             const float* __restrict__ mu, const float* __restrict__ lv, long n_r, long n_k,
+             float kl_beta, float* __restrict__ loss_out, float* __restrict__ d_recon,
+             float* __restrict__ d_mu, float* __restrict__ d_lv, unsigned* ws) {
+  __shared__ float red[4];
+  __shared__ unsigned is_last;
+  float* part = reinterpret_cast<float*>(ws + 64);
+  const float g_r = 2.0f / (float)n_r;
+  const float g_k = kl_beta / (float)n_k;
+  const long stride = (long)gridDim.x * 256;
+  const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
+  float sq = 0.f, kl = 0.f;
+  const bool vec = ((n_r & 3) == 0) &&
+                   (((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(x) |
+                      reinterpret_cast<uintptr_t>(d_recon)) & 15) == 0);
+  if (vec) {
+    const long n4 = n_r >> 2;
+    for (long i = t0; i < n4; i += stride) {
+      const float4 r = reinterpret_cast<const float4*>(recon)[i];
+      const float4 t = reinterpret_cast<const float4*>(x)[i];
+      const float4 d = make_float4(r.x - t.x, r.y - t.y, r.z - t.z, r.w - t.w);
+      sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      if (d_recon)
+        reinterpret_cast<float4*>(d_recon)[i] = make_float4(g_r * d.x, g_r * d.y, g_r * d.z, g_r * d.w);
+    }
+  } else {
+    for (long i = t0; i < n_r; i += stride) {
+      const float d = recon[i] - x[i];
+      sq += d * d;
+      if (d_recon) d_recon[i] = g_r * d;
+    }
+  }
+  for (long i = t0; i < n_k; i += stride) {
+    const float m = mu[i], l = lv[i];
+    const float e = __expf(l);
+    kl += 1.f + l - m * m - e;
+    if (d_mu) d_mu[i] = g_k * m;
+    if (d_lv) d_lv[i] = 0.5f * g_k * (e - 1.f);
+  }
+  sq = block_sum_256(sq, red);
+  kl = block_sum_256(kl, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = sq;
+    part[2 * blockIdx.x + 1] = kl;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (is_last) {
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+      a += part[2 * i];
+      b += part[2 * i + 1];
+    }
+    a = block_sum_256(a, red);
+    b = block_sum_256(b, red);
+    if (threadIdx.x == 0) {
+      const float mse = a / (float)n_r;
+      const float kld = -0.5f * b / (float)n_k;
+      loss_out[0] = mse + kl_beta * kld;
+      loss_out[1] = mse;
+      loss_out[2] = kld;
+      __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_reparameterize(const float* __restrict__ mu, const float* __restrict__ lv, long n,
+                 const float* __restrict__ eps_in, float* __restrict__ eps_out, uint64_t seed,
+                 uint64_t offset, float* __restrict__ z) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float e;
+    if (eps_in) {
+      e = eps_in[i];
+    } else {
+      e = normal1(seed, (uint64_t)i, offset);
+      if (eps_out) eps_out[i] = e;
+    }
+    z[i] = mu[i] + e * __expf(0.5f * lv[i]);
+  }
+}
+
+// ------------------------------------------------------------------ Adam / gradient finaliser
+constexpr int MAX_DESC = 16;
+struct DescTable {
+  rv_param_desc d[MAX_DESC];
+  long blk_start[MAX_DESC + 1];  // first block of each tensor
+  int n;
+};
+
+constexpr int ADAM_EPT = 4;  // elements per thread
+
+template <bool UPDATE>
+__global__ void __launch_bounds__(256)
+k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
+       float* __restrict__ v_arena, float* __restrict__ grad_out, float lr, float grad_scale,
+       const long long* __restrict__ step_counter) {
+  int t = 0;
+  while (t + 1 < tab.n && (long)blockIdx.x >= tab.blk_start[t + 1]) ++t;
+  const rv_param_desc d = tab.d[t];
+  const long n = d.rows * d.cols;
+  const long base = ((long)blockIdx.x - tab.blk_start[t]) * (256 * ADAM_EPT);
+  float bc1 = 1.f, bc2s = 1.f;
+  if constexpr (UPDATE) {
+    const float tt = (float)(*step_counter);
+    bc1 = 1.0f - powf(0.9f, tt);
+    bc2s = sqrtf(1.0f - powf(0.999f, tt));
+  }
+  const float step_size = lr / bc1;
+#pragma unroll
+  for (int e = 0; e < ADAM_EPT; ++e) {
+    const long i = base + e * 256 + threadIdx.x;
+    if (i >= n) break;
+    const long r = i / d.cols, c = i % d.cols;
+    float g = 0.f;
+    for (int s = 0; s < d.grad_splits; ++s)
+      g += d.grad_slabs[(long)s * d.grad_split_stride + r * d.grad_ld + c];
+    g *= grad_scale;
+    const long o = d.offset + i;
+    if (grad_out) grad_out[o] = g;
+    if constexpr (UPDATE) {
+      const float m = 0.9f * m_arena[o] + 0.1f * g;
+      const float v = 0.999f * v_arena[o] + 0.001f * g * g;
+      m_arena[o] = m;
+      v_arena[o] = v;
+      const float w = param[o] - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
+      param[o] = w;
+      if (d.shadow_bf16) reinterpret_cast<bf16_t*>(d.shadow_bf16)[r * d.shadow_ld + c] = (bf16_t)w;
+      if (d.shadow_f32) d.shadow_f32[r * d.shadow_ld + c] = w;
+    }
+  }
+}
+
+int build_table(const rv_param_desc* descs, int n, DescTable* tab) {
+  RV_REQUIRE(descs && n > 0 && n <= MAX_DESC, RV_ERR_SHAPE, "param desc count %d out of range", n);
+  tab->n = n;
+  long blk = 0;
+  for (int i = 0; i < n; ++i) {
+    tab->d[i] = descs[i];
+    RV_REQUIRE(descs[i].rows > 0 && descs[i].cols > 0 && descs[i].grad_slabs && descs[i].grad_splits >= 1,
+               RV_ERR_SHAPE, "param desc %d invalid", i);
+    tab->blk_start[i] = blk;
+    blk += (descs[i].rows * descs[i].cols + 256 * ADAM_EPT - 1) / (256 * ADAM_EPT);
+  }
+  tab->blk_start[n] = blk;
+  return RV_OK;
+}
+
+inline unsigned grid_for(long n_threads, long cap = 2048) {
+  long g = (n_threads + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rv_version(void) { return 100; }
+const char* rv_last_error(void) { return rv_err_buf; }
+
+int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, long* Lp) {
+  RV_REQUIRE(B > 0 && S > 0 && H > 0 && L > 0, RV_ERR_SHAPE, "rv_pad_dims: non-positive extent");
+  RV_REQUIRE(L <= 256, RV_ERR_UNSUPPORTED, "latent_dim %ld > 256 not supported", L);
+  if (Bp) *Bp = (B + 127) / 128 * 128;
+  if (Sp) *Sp = (S + 127) / 128 * 128;
+  if (Hp) *Hp = (H + 127) / 128 * 128;
+  if (Lp) {
+    long lp = 64;
+    while (lp < L) lp *= 2;  // 64, 128, 256: keeps 256 % Lp == 0 for the reparam kernels
+    *Lp = lp;
+  }
+  return RV_OK;
+}
+
+int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long rows_p,
+                     long cols_p, long long* step_counter, void* stream) {
+  RV_REQUIRE(src && dst, RV_ERR_NULL, "rv_cast_pad_bf16: null pointer");
+  RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols,
+             RV_ERR_SHAPE, "rv_cast_pad_bf16: bad extents %ld %ld -> %ld %ld", rows, cols, rows_p, cols_p);
+  const long total = rows_p * (cols_p / 8);
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, step_counter);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_randn(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream) {
+  RV_REQUIRE(out && n >= 0, RV_ERR_NULL, "rv_randn: bad args");
+  if (n == 0) return RV_OK;
+  hipLaunchKernelGGL(k_randn, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n,
+                     (uint64_t)seed, (uint64_t)offset);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_reparam_fwd(const float* slabs, int splits, long Bp, long Lp, long B, long L,
+                   const float* eps_in, float* eps_out, unsigned long long seed,
+                   const long long* step_counter, float* mulv, void* z, float* kl_partial,
+                   void* stream) {
+  RV_REQUIRE(slabs && mulv && z && kl_partial, RV_ERR_NULL, "rv_reparam_fwd: null pointer");
+  RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_reparam_fwd: need eps_in or eps_out");
+  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && (Bp * Lp) % 256 == 0, RV_ERR_SHAPE, "rv_reparam_fwd: bad extents");
+  hipLaunchKernelGGL(k_reparam_fwd, dim3((unsigned)(Bp * Lp / 256)), dim3(256), 0, (hipStream_t)stream,
+                     slabs, splits, Bp, Lp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv,
+                     (bf16_t*)z, kl_partial);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
+                   const float* mulv, const float* eps, float kl_beta, void* dmulv,
+                   float* dbh_partial, const float* mse_partial, int n_mse,
+                   const float* kl_partial, int n_kl, float* loss_out,
+                   const long long* step_counter, int ring, void* stream) {
+  RV_REQUIRE(dz_slabs && mulv && eps && dmulv, RV_ERR_NULL, "rv_reparam_bwd: null pointer");
+  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && Bp % 64 == 0 && 256 % Lp == 0, RV_ERR_SHAPE,
+             "rv_reparam_bwd: bad extents (Lp must divide 256)");
+  hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / 64)), dim3(256), 512 * sizeof(float),
+                     (hipStream_t)stream, dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta,
+                     (bf16_t*)dmulv, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
+                     step_counter, ring);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+long rv_loss_fused_workspace_bytes(void) { return 256 + 2 * LOSS_MAX_BLOCKS * (long)sizeof(float); }
+
+int rv_loss_fused(const float* recon, const float* x, const float* mu, const float* logvar, long B,
+                  long S, long L, float kl_beta, float* loss_out, float* d_recon, float* d_mu,
+                  float* d_logvar, void* workspace, void* stream) {
+  RV_REQUIRE(recon && x && mu && logvar && loss_out && workspace, RV_ERR_NULL, "rv_loss_fused: null pointer");
+  RV_REQUIRE(B > 0 && S > 0 && L > 0, RV_ERR_SHAPE, "rv_loss_fused: empty input");
+  const long n_r = B * S, n_k = B * L;
+  unsigned grid = grid_for((n_r + 3) / 4, LOSS_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_loss_fused, dim3(grid), dim3(256), 0, (hipStream_t)stream, recon, x, mu, logvar,
+                     n_r, n_k, kl_beta, loss_out, d_recon, d_mu, d_logvar, (unsigned*)workspace);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_reparameterize(const float* mu, const float* logvar, long n, const float* eps_in,
+                      float* eps_out, unsigned long long seed, unsigned long long offset, float* z,
+                      void* stream) {
+  RV_REQUIRE(mu && logvar && z && n >= 0, RV_ERR_NULL, "rv_reparameterize: bad args");
+  if (n == 0) return RV_OK;
+  hipLaunchKernelGGL(k_reparameterize, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar,
+                     n, eps_in, eps_out, (uint64_t)seed, (uint64_t)offset, z);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                  float* exp_avg_sq, float* grad_out, float lr, float grad_scale,
+                  const long long* step_counter, void* stream) {
+  RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_adam_multi: null pointer");
+  DescTable tab;
+  int rc = build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
+                     (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
+                     step_counter);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream) {
+  RV_REQUIRE(grad_out, RV_ERR_NULL, "rv_grad_finalize: null pointer");
+  DescTable tab;
+  int rc = build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
+                     (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, grad_out,
+                     0.f, 1.f, (const long long*)nullptr);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Host-side launchers for the bf16 MFMA GEMM family (C ABI: include/rawvae_hip.h).
+#include "gemm_bf16.h"
+#include "../../include/rawvae_hip.h"
+
+using namespace rv;
+
+namespace {
+
+template <int BM, int BN, bool AK, bool BK, int EPI>
+int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = gemm_bf16_kernel<BM, BN, AK, BK, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+// Tile choice: 128x128 when both extents allow it, 64x64 otherwise (latent-sized N).
+template <bool AK, bool BK, int EPI>
+int launch_auto(const GemmArgs& a, long Mp, long Np, long Kp, int splits, hipStream_t st) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0, RV_ERR_SHAPE, "gemm: empty extent");
+  RV_REQUIRE(Mp % 64 == 0 && Np % 64 == 0 && Kp % 64 == 0, RV_ERR_SHAPE,
+             "gemm: extents must be multiples of 64 (got %ld %ld %ld)", Mp, Np, Kp);
+  RV_REQUIRE(splits >= 1 && (Kp / 64) % splits == 0, RV_ERR_SHAPE,
+             "gemm: K tiles %ld not divisible by splits %d", Kp / 64, splits);
+  RV_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0, RV_ERR_SHAPE, "gemm: leading dims must be multiples of 8");
+  RV_REQUIRE((((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0, RV_ERR_SHAPE, "gemm: operands must be 16-byte aligned");
+  if (Mp % 128 == 0 && Np % 128 == 0) return launch<128, 128, AK, BK, EPI>(a, Mp, Np, splits, st);
+  return launch<64, 64, AK, BK, EPI>(a, Mp, Np, splits, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rv_linear_fwd(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp,
+                  long Np, long Kp, int act, void* y, long ldy, void* stream) {
+  RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd: null operand");
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd: act %d", act);
+  GemmArgs a{};
+  a.A = (const bf16_t*)x; a.lda = ldx; a.B = (const bf16_t*)w; a.ldb = ldw;
+  a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
+  return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
+}
+
+int rv_linear_fwd_f32(const void* x, long ldx, const void* w, long ldw, const float* bias,
+                      long Mp, long Np, long Kp, int splits, float* y, long ldy, void* stream) {
+  RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd_f32: null operand");
+  GemmArgs a{};
+  a.A = (const bf16_t*)x; a.lda = ldx; a.B = (const bf16_t*)w; a.ldb = ldw;
+  a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.bias = bias; a.out_f32 = y; a.ld_f32 = ldy; a.split_stride_f32 = Mp * ldy;
+  return launch_auto<true, true, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+int rv_decode_out_loss_fwd(const void* h3, long ldh, const void* w4, long ldw, const float* b4,
+                           long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx,
+                           float* recon, long ld_recon, void* dP4, long ld_dp4,
+                           float* mse_partial, float* db4_partial, void* stream) {
+  RV_REQUIRE(h3 && w4, RV_ERR_NULL, "rv_decode_out_loss_fwd: null operand");
+  RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_decode_out_loss_fwd: B,S exceed padded extents");
+  RV_REQUIRE(!x || dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd: x given without dP4 output");
+  RV_REQUIRE(Bp % 128 == 0 && Sp % 128 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd: Bp,Sp must be multiples of 128");
+  GemmArgs a{};
+  a.A = (const bf16_t*)h3; a.lda = ldh; a.B = (const bf16_t*)w4; a.ldb = ldw;
+  a.k_tiles = (int)(Hp / 64); a.M_valid = (int)B; a.N_valid = (int)S;
+  a.bias = b4; a.x = x; a.ld_x = ldx; a.recon = recon; a.ld_recon = ld_recon;
+  a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
+  a.scale = 2.0f / ((float)B * (float)S);
+  return launch_auto<true, true, EPI_TANH_LOSS>(a, Bp, Sp, Hp, 1, (hipStream_t)stream);
+}
+
+int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp, long Np, long Kp,
+                    const void* mask, long ldmask, void* dx, long lddx, float* colsum,
+                    float* dx32, long lddx32, int splits, void* stream) {
+  RV_REQUIRE(dy && w, RV_ERR_NULL, "rv_linear_dgrad: null operand");
+  GemmArgs a{};
+  a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)w; a.ldb = ldw;
+  a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  if (mask) {
+    RV_REQUIRE(dx, RV_ERR_NULL, "rv_linear_dgrad: mask given without bf16 output");
+    RV_REQUIRE(!colsum || (Mp % 128 == 0 && Np % 128 == 0), RV_ERR_SHAPE,
+               "rv_linear_dgrad: colsum needs 128-multiples");
+    a.k_tiles = (int)(Kp / 64); a.mask = (const bf16_t*)mask; a.ld_mask = ldmask;
+    a.out_bf16 = (bf16_t*)dx; a.ld_bf16 = lddx; a.colsum = colsum;
+    return launch_auto<true, false, EPI_MASK_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
+  }
+  RV_REQUIRE(dx32, RV_ERR_NULL, "rv_linear_dgrad: no output given");
+  a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1));
+  a.out_f32 = dx32; a.ld_f32 = lddx32; a.split_stride_f32 = Mp * lddx32;
+  return launch_auto<true, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp,
+                    int splits, float* dw, long lddw, void* stream) {
+  RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad: null operand");
+  GemmArgs a{};
+  a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
+  a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.out_f32 = dw; a.ld_f32 = lddw; a.split_stride_f32 = Mp * lddw;
+  return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+}  // extern "C"

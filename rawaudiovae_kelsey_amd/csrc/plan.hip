@@ -1,0 +1,319 @@
+// Whole-step plan: one host call enqueues the 14 kernels of a training step
+// (train.py:184-193) on a stream; hipGraph capture/replay and HIP-event timing
+// helpers.  C ABI: include/rawvae_hip.h.
+#include "common.h"
+#include "../../include/rawvae_hip.h"
+
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Buf {
+  const char* name;
+  long bytes;
+  long off;
+};
+
+long align256(long b) { return (b + 255) / 256 * 256; }
+
+int pick_splits(long tiles, long k_tiles) {
+  int s = 1;
+  while (tiles * s < 256 && s < 16 && k_tiles % (2 * s) == 0 && k_tiles / (2 * s) >= 2) s *= 2;
+  return s;
+}
+
+}  // namespace
+
+struct rv_plan {
+  long B, S, H, L, Bp, Sp, Hp, Lp, L2p;
+  int s_heads, s_dz, s_w4, s_w3, s_wh, s_w1;  // split-K factors
+  int n_mse, n_kl, n_mt;                      // partial counts; n_mt = Bp/128 row tiles
+  long off[10];                               // element offsets of the 10 params in the flat arenas
+  long n_params;
+  std::vector<Buf> bufs;
+  long ws_bytes;
+  rv_plan_buffers b;
+  bool bound;
+  rv_param_desc d_slab[10], d_flat[10];
+
+  char* ws(const char* name, long* nbytes = nullptr) const {
+    for (const Buf& x : bufs)
+      if (!strcmp(x.name, name)) {
+        if (nbytes) *nbytes = x.bytes;
+        return (char*)b.workspace + x.off;
+      }
+    return nullptr;
+  }
+  void add(const char* name, long bytes) {
+    bufs.push_back({name, bytes, ws_bytes});
+    ws_bytes += align256(bytes);
+  }
+};
+
+extern "C" {
+
+int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
+  RV_REQUIRE(out, RV_ERR_NULL, "rv_plan_create: null out");
+  rv_plan* p = new (std::nothrow) rv_plan();
+  RV_REQUIRE(p, RV_ERR_STATE, "rv_plan_create: out of host memory");
+  p->B = B; p->S = S; p->H = H; p->L = L;
+  int rc = rv_pad_dims(B, S, H, L, &p->Bp, &p->Sp, &p->Hp, &p->Lp);
+  if (rc) { delete p; return rc; }
+  p->L2p = 2 * p->Lp;
+  const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
+  const bool lat128 = (Lp % 128 == 0);
+  p->s_heads = pick_splits((Bp / 128) * (L2p / 128), Hp / 64);
+  p->s_dz = lat128 ? pick_splits((Bp / 128) * (Lp / 128), Hp / 64) : pick_splits((Bp / 64) * (Lp / 64), Hp / 64);
+  p->s_w4 = pick_splits((Sp / 128) * (Hp / 128), Bp / 64);
+  p->s_w3 = lat128 ? pick_splits((Hp / 128) * (Lp / 128), Bp / 64) : pick_splits((Hp / 64) * (Lp / 64), Bp / 64);
+  p->s_wh = pick_splits((L2p / 128) * (Hp / 128), Bp / 64);
+  p->s_w1 = pick_splits((Hp / 128) * (Sp / 128), Bp / 64);
+  p->n_mt = (int)(Bp / 128);
+  p->n_mse = (int)((Bp / 128) * (Sp / 128));
+  p->n_kl = (int)(Bp * Lp / 256);
+  const long sizes[10] = {H * S, H, L * H, L, L * H, L, H * L, H, S * H, S};
+  long o = 0;
+  for (int i = 0; i < 10; ++i) { p->off[i] = o; o += sizes[i]; }
+  p->n_params = o;
+  p->ws_bytes = 0;
+  p->add("xb", Bp * Sp * 2);
+  p->add("W1b", Hp * Sp * 2);
+  p->add("Whb", L2p * Hp * 2);
+  p->add("W3b", Hp * Lp * 2);
+  p->add("W4b", Sp * Hp * 2);
+  p->add("b1p", Hp * 4);
+  p->add("bhp", L2p * 4);
+  p->add("b3p", Hp * 4);
+  p->add("b4p", Sp * 4);
+  p->add("h1", Bp * Hp * 2);
+  p->add("mulv_slabs", (long)p->s_heads * Bp * L2p * 4);
+  p->add("mulv", Bp * L2p * 4);
+  p->add("eps", Bp * Lp * 4);
+  p->add("z", Bp * Lp * 2);
+  p->add("h3", Bp * Hp * 2);
+  p->add("dP4", Bp * Sp * 2);
+  p->add("dP3", Bp * Hp * 2);
+  p->add("dz_slabs", (long)p->s_dz * Bp * Lp * 4);
+  p->add("dmulv", Bp * L2p * 2);
+  p->add("dP1", Bp * Hp * 2);
+  p->add("dW1", (long)p->s_w1 * Hp * Sp * 4);
+  p->add("dWh", (long)p->s_wh * L2p * Hp * 4);
+  p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
+  p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
+  p->add("db1p", (long)p->n_mt * Hp * 4);
+  p->add("dbhp", (Bp / 64) * L2p * 4);
+  p->add("db3p", (long)p->n_mt * Hp * 4);
+  p->add("db4p", (long)p->n_mt * Sp * 4);
+  p->add("mse_part", (long)p->n_mse * 4);
+  p->add("kl_part", (long)p->n_kl * 4);
+  p->bound = false;
+  *out = p;
+  return RV_OK;
+}
+
+void rv_plan_destroy(rv_plan* p) { delete p; }
+
+long rv_plan_workspace_bytes(const rv_plan* p) { return p ? p->ws_bytes : 0; }
+
+void* rv_plan_buffer(rv_plan* p, const char* name, long* n_bytes) {
+  if (!p || !p->bound || !name) return nullptr;
+  return p->ws(name, n_bytes);
+}
+
+int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
+  RV_REQUIRE(p && b, RV_ERR_NULL, "rv_plan_bind: null");
+  RV_REQUIRE(b->param && b->exp_avg && b->exp_avg_sq && b->workspace && b->step_counter && b->loss_ring &&
+                 b->ring > 0,
+             RV_ERR_NULL, "rv_plan_bind: missing buffer");
+  RV_REQUIRE(((uintptr_t)b->workspace & 255) == 0, RV_ERR_SHAPE, "rv_plan_bind: workspace must be 256-byte aligned");
+  p->b = *b;
+  p->bound = true;
+  const long H = p->H, S = p->S, L = p->L, Hp = p->Hp, Sp = p->Sp, Lp = p->Lp, L2p = p->L2p, Bp = p->Bp;
+  float* dW1 = (float*)p->ws("dW1"); float* dWh = (float*)p->ws("dWh");
+  float* dW3 = (float*)p->ws("dW3"); float* dW4 = (float*)p->ws("dW4");
+  float* db1 = (float*)p->ws("db1p"); float* dbh = (float*)p->ws("dbhp");
+  float* db3 = (float*)p->ws("db3p"); float* db4 = (float*)p->ws("db4p");
+  char* W1b = p->ws("W1b"); char* Whb = p->ws("Whb"); char* W3b = p->ws("W3b"); char* W4b = p->ws("W4b");
+  float* b1p = (float*)p->ws("b1p"); float* bhp = (float*)p->ws("bhp");
+  float* b3p = (float*)p->ws("b3p"); float* b4p = (float*)p->ws("b4p");
+  const int n_mt = p->n_mt, n_b64 = (int)(Bp / 64);
+  //                 offset     rows cols slabs        ld   split_stride  splits     bf16 shadow          f32 shadow  ld
+  rv_param_desc d[10] = {
+      {p->off[0], H, S, dW1, Sp, Hp * Sp, p->s_w1, W1b, nullptr, Sp},
+      {p->off[1], 1, H, db1, Hp, Hp, n_mt, nullptr, b1p, Hp},
+      {p->off[2], L, H, dWh, Hp, L2p * Hp, p->s_wh, Whb, nullptr, Hp},
+      {p->off[3], 1, L, dbh, L2p, L2p, n_b64, nullptr, bhp, L2p},
+      {p->off[4], L, H, dWh + Lp * Hp, Hp, L2p * Hp, p->s_wh, Whb + Lp * Hp * 2, nullptr, Hp},
+      {p->off[5], 1, L, dbh + Lp, L2p, L2p, n_b64, nullptr, bhp + Lp, L2p},
+      {p->off[6], H, L, dW3, Lp, Hp * Lp, p->s_w3, W3b, nullptr, Lp},
+      {p->off[7], 1, H, db3, Hp, Hp, n_mt, nullptr, b3p, Hp},
+      {p->off[8], S, H, dW4, Hp, Sp * Hp, p->s_w4, W4b, nullptr, Hp},
+      {p->off[9], 1, S, db4, Sp, Sp, n_mt, nullptr, b4p, Sp},
+  };
+  for (int i = 0; i < 10; ++i) {
+    p->d_slab[i] = d[i];
+    p->d_flat[i] = d[i];
+    if (b->grad) {
+      p->d_flat[i].grad_slabs = b->grad + d[i].offset;
+      p->d_flat[i].grad_ld = d[i].cols;
+      p->d_flat[i].grad_split_stride = 0;
+      p->d_flat[i].grad_splits = 1;
+    }
+  }
+  return RV_OK;
+}
+
+int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_refresh_shadows: plan not bound");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < 10; ++i) {
+    const rv_param_desc& d = p->d_slab[i];
+    const float* src = p->b.param + d.offset;
+    if (d.shadow_bf16) {
+      // weights: every [rows,cols] block is cast into its padded home; padding is zeroed
+      long rows_p, cols_p = d.shadow_ld;
+      if (i == 0 || i == 6) rows_p = p->Hp;
+      else if (i == 8) rows_p = p->Sp;
+      else rows_p = p->Lp;
+      int rc = rv_cast_pad_bf16(src, d.rows, d.cols, d.cols, d.shadow_bf16, rows_p, cols_p, nullptr, stream);
+      if (rc) return rc;
+    } else {
+      long pad = (i == 3 || i == 5) ? p->Lp : d.shadow_ld;
+      RV_HIP(hipMemsetAsync(d.shadow_f32, 0, pad * sizeof(float), st));
+      RV_HIP(hipMemcpyAsync(d.shadow_f32, src, d.cols * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  }
+  return RV_OK;
+}
+
+int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float* recon_out,
+                 float kl_beta, float lr, float grad_scale, int adam_from_flat,
+                 unsigned long long seed, void* stream) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step: plan not bound");
+  const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
+  void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
+  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
+  float* mulv_slabs = (float*)p->ws("mulv_slabs"); float* mulv = (float*)p->ws("mulv");
+  float* eps_buf = (float*)p->ws("eps"); float* dz_slabs = (float*)p->ws("dz_slabs");
+  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const float* eps_used = eps ? eps : eps_buf;
+  int rc;
+#define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+  if (phases & RV_PHASE_FWD) {
+    RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
+    RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, p->b.step_counter, stream));
+    RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+    RV_TRY(rv_linear_fwd_f32(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, L2p, Hp, p->s_heads,
+                             mulv_slabs, L2p, stream));
+    RV_TRY(rv_reparam_fwd(mulv_slabs, p->s_heads, Bp, Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z,
+                          kl_part, stream));
+    RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
+    RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
+                                  recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+  }
+  if (phases & RV_PHASE_BWD_A) {
+    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"),
+                           nullptr, 0, 1, stream));
+    RV_TRY(rv_linear_wgrad(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, (float*)p->ws("dW4"), Hp, stream));
+    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
+                           p->s_dz, stream));
+    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
+    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
+                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
+                          p->b.step_counter, p->b.ring, stream));
+  }
+  if (phases & RV_PHASE_FINALIZE_A) {
+    RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
+    RV_TRY(rv_grad_finalize(p->d_slab + 6, 4, p->b.grad, stream));
+  }
+  if (phases & RV_PHASE_BWD_B) {
+    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
+                           nullptr, 0, 1, stream));
+    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+  }
+  if (phases & RV_PHASE_FINALIZE_B) {
+    RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
+    RV_TRY(rv_grad_finalize(p->d_slab, 6, p->b.grad, stream));
+  }
+  if (phases & RV_PHASE_ADAM) {
+    RV_REQUIRE(!adam_from_flat || p->b.grad, RV_ERR_STATE, "rv_plan_step: adam_from_flat needs a grad arena");
+    RV_TRY(rv_adam_multi(adam_from_flat ? p->d_flat : p->d_slab, 10, p->b.param, p->b.exp_avg, p->b.exp_avg_sq,
+                         nullptr, lr, grad_scale, p->b.step_counter, stream));
+  }
+#undef RV_TRY
+  return RV_OK;
+}
+
+// --------------------------------------------------------------------- hipGraph
+struct rv_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+int rv_graph_begin(void* stream) {
+  RV_REQUIRE(stream, RV_ERR_NULL, "rv_graph_begin: capture needs a non-default stream");
+  RV_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return RV_OK;
+}
+
+int rv_graph_end(void* stream, rv_graph** out) {
+  RV_REQUIRE(stream && out, RV_ERR_NULL, "rv_graph_end: null");
+  hipGraph_t g = nullptr;
+  RV_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  RV_REQUIRE(g, RV_ERR_STATE, "rv_graph_end: capture produced no graph");
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return rv_fail(RV_ERR_HIP, "hipGraphInstantiate -> %s", hipGetErrorString(err));
+  }
+  rv_graph* r = new (std::nothrow) rv_graph{g, e};
+  RV_REQUIRE(r, RV_ERR_STATE, "rv_graph_end: out of host memory");
+  *out = r;
+  return RV_OK;
+}
+
+int rv_graph_launch(rv_graph* g, void* stream) {
+  RV_REQUIRE(g, RV_ERR_NULL, "rv_graph_launch: null graph");
+  RV_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return RV_OK;
+}
+
+void rv_graph_destroy(rv_graph* g) {
+  if (!g) return;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+// --------------------------------------------------------------------- events
+int rv_event_create(void** ev) {
+  RV_REQUIRE(ev, RV_ERR_NULL, "rv_event_create: null");
+  hipEvent_t e;
+  RV_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return RV_OK;
+}
+
+int rv_event_record(void* ev, void* stream) {
+  RV_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return RV_OK;
+}
+
+int rv_event_elapsed_ms_sync(void* a, void* b, float* ms) {
+  RV_REQUIRE(ms, RV_ERR_NULL, "rv_event_elapsed_ms_sync: null");
+  RV_HIP(hipEventSynchronize((hipEvent_t)b));
+  RV_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return RV_OK;
+}
+
+void rv_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+
+}  // extern "C"

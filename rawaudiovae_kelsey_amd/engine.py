@@ -1,0 +1,183 @@
+"""Fused training-step engine: the reference's inner loop
+(`optimizer.zero_grad(); model(data); loss_function(...); loss.backward();
+optimizer.step()` -- train.py:184-193, train_iterable.py:200-210) as ONE host call
+that enqueues 14 hand-written gfx950 kernels through the C ABI (`rv_plan_step`).
+
+PyTorch is used for device memory and streams only.  Parameters, Adam moments and
+(optionally) gradients live in flat fp32 arenas in `PARAM_NAMES` order; the
+`nn.Parameter`s of a `VAE` can be re-pointed at views of the arena so that
+`state_dict()` / checkpoints keep the reference's keys and layouts.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (PHASE_ADAM, PHASE_ALL_LOCAL, PHASE_BWD_A, PHASE_BWD_B, PHASE_FINALIZE_A,
+                   PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr, stream_ptr)
+
+PARAM_NAMES = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias",
+               "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias")
+
+
+def param_shapes(S, H, L):
+    return {"fc1.weight": (H, S), "fc1.bias": (H,), "fc21.weight": (L, H), "fc21.bias": (L,),
+            "fc22.weight": (L, H), "fc22.bias": (L,), "fc3.weight": (H, L), "fc3.bias": (H,),
+            "fc4.weight": (S, H), "fc4.bias": (S,)}
+
+
+class TrainEngine:
+    """Owns the arenas + workspace of one (S, H, L, B) training configuration."""
+
+    def __init__(self, segment_length, n_units, latent_dim, batch_size, device="cuda",
+                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True):
+        self.S, self.H, self.L, self.B = int(segment_length), int(n_units), int(latent_dim), int(batch_size)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.RvError("TrainEngine needs a GPU device (got %s); there is no CPU path" % device)
+        self.kl_beta, self.lr, self.seed, self.ring = float(kl_beta), float(lr), int(seed), int(ring)
+        L_ = lib()
+        self._plan = C.c_void_p()
+        L_.rv_plan_create(C.byref(self._plan), self.B, self.S, self.H, self.L)
+        self.shapes = param_shapes(self.S, self.H, self.L)
+        self.offsets, o = {}, 0
+        for k in PARAM_NAMES:
+            self.offsets[k] = o
+            n = 1
+            for d in self.shapes[k]:
+                n *= d
+            o += n
+        self.n_params = o
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.param = torch.zeros(o, **f32)
+        self.exp_avg = torch.zeros(o, **f32)
+        self.exp_avg_sq = torch.zeros(o, **f32)
+        self.grad = torch.zeros(o, **f32) if grad_arena else None
+        ws_bytes = L_.rv_plan_workspace_bytes(self._plan)
+        self.workspace = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.loss_ring = torch.zeros(self.ring, 4, **f32)
+        self._bufs = PlanBuffers(ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                 ptr(self.grad), ws_ptr, ptr(self.step_counter),
+                                 ptr(self.loss_ring), self.ring)
+        L_.rv_plan_bind(self._plan, C.byref(self._bufs))
+        self.host_steps = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                lib().rv_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------
+    def view(self, arena, name):
+        n = 1
+        for d in self.shapes[name]:
+            n *= d
+        o = self.offsets[name]
+        return arena[o:o + n].view(self.shapes[name])
+
+    def param_views(self):
+        return {k: self.view(self.param, k) for k in PARAM_NAMES}
+
+    def grad_views(self):
+        return {k: self.view(self.grad, k) for k in PARAM_NAMES}
+
+    def load_params(self, params):
+        """params: name -> array/tensor with the reference's nn.Linear shapes."""
+        with torch.no_grad():
+            for k in PARAM_NAMES:
+                src = params[k]
+                if not torch.is_tensor(src):
+                    src = torch.as_tensor(src)
+                self.view(self.param, k).copy_(src.to(self.device, torch.float32))
+        self.refresh_shadows()
+
+    def refresh_shadows(self, stream=None):
+        lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
+
+    def adopt(self, module):
+        """Copy a VAE module's parameters into the arena and re-point the module's
+        nn.Parameters at the arena views (state_dict keys/layouts unchanged)."""
+        sd = dict(module.named_parameters())
+        with torch.no_grad():
+            for k in PARAM_NAMES:
+                v = self.view(self.param, k)
+                v.copy_(sd[k].detach().to(self.device, torch.float32))
+                sd[k].data = v
+        self.refresh_shadows()
+
+    # ---- stepping -------------------------------------------------------
+    def step(self, x, eps=None, recon_out=None, phases=PHASE_ALL_LOCAL, grad_scale=1.0,
+             adam_from_flat=False, stream=None):
+        """Enqueue the selected phases for one batch `x` [B, S] fp32 (contiguous, on device)."""
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != self.B * self.S:
+            raise _lib.RvError("step: x must be contiguous fp32 with %d x %d elements" % (self.B, self.S))
+        if eps is not None and (eps.dtype != torch.float32 or not eps.is_contiguous()
+                                or eps.numel() != self.B * self.L):
+            raise _lib.RvError("step: eps must be contiguous fp32 [B, L]")
+        lib().rv_plan_step(self._plan, int(phases), ptr(x), ptr(eps), ptr(recon_out), self.kl_beta,
+                           self.lr, float(grad_scale), int(bool(adam_from_flat)), self.seed,
+                           stream_ptr(stream))
+        if phases & PHASE_FWD:
+            self.host_steps += 1
+
+    def buffer(self, name, dtype, shape):
+        """Typed view of a workspace buffer (tests / inspection)."""
+        n = C.c_long()
+        p = lib().rv_plan_buffer(self._plan, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        off = p - self.workspace.data_ptr()
+        raw = self.workspace[off:off + n.value]
+        return raw.view(dtype).view(shape)
+
+    def padded(self):
+        return _lib.pad_dims(self.B, self.S, self.H, self.L)
+
+    def outputs(self):
+        """mu, logvar of the last forward as exact-shape fp32 copies."""
+        Bp, Sp, Hp, Lp = self.padded()
+        mulv = self.buffer("mulv", torch.float32, (Bp, 2 * Lp))
+        return mulv[:self.B, :self.L].contiguous(), mulv[:self.B, Lp:Lp + self.L].contiguous()
+
+    def last_loss(self):
+        """(total, mse, kld) of the most recent step; synchronises."""
+        slot = (self.host_steps - 1) % self.ring
+        return tuple(float(v) for v in self.loss_ring[slot, :3].tolist())
+
+    def losses(self, n):
+        """Totals of the last n steps (n <= ring), oldest first; synchronises."""
+        n = min(n, self.ring, self.host_steps)
+        idx = [(self.host_steps - n + i) % self.ring for i in range(n)]
+        return self.loss_ring[idx, 0].tolist()
+
+
+class Graph:
+    """hipGraph capture of a sequence of engine calls on `stream` (a torch.cuda.Stream)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self._g = C.c_void_p()
+
+    def __enter__(self):
+        lib().rv_graph_begin(self.stream.cuda_stream)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib().rv_graph_end(self.stream.cuda_stream, C.byref(self._g))
+        return False
+
+    def launch(self, stream=None):
+        lib().rv_graph_launch(self._g, (stream or self.stream).cuda_stream)
+
+    def __del__(self):
+        try:
+            if self._g:
+                lib().rv_graph_destroy(self._g)
+                self._g = None
+        except Exception:
+            pass

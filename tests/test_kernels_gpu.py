@@ -1,0 +1,243 @@
+"""Per-kernel parity tests (GPU): every C-ABI entry point against the CPU oracle /
+numpy on the same seeded inputs.  bf16 operands are rounded identically on both
+sides, so GEMM tolerances only cover fp32 accumulation-order differences."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rawaudiovae_kelsey_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _lib.lib()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def sp():
+    return torch.cuda.current_stream().cuda_stream or None
+
+
+def rand_bf16(rng, shape, scale=1.0):
+    a = (rng.standard_normal(shape) * scale).astype(np.float32)
+    return O.bf16_round(a)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 192), (128, 256, 128), (64, 64, 64),
+                                   (192, 64, 128), (64, 192, 256)])
+def test_linear_fwd_bias_relu(L, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K))
+    b = rng.standard_normal(N).astype(np.float32)
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(b)
+    y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    for act in (0, 1):
+        L.rv_linear_fwd(xd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), M, N, K, act, y.data_ptr(), N, sp())
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        if act:
+            ref = np.maximum(ref, 0)
+        got = y.float().cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-2 * np.abs(ref).max())
+        # bf16 output: error must be within one bf16 ulp of the exact value
+        assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 256, 1), (128, 128, 256, 4), (64, 64, 128, 2),
+                                          (256, 128, 128, 2)])
+def test_linear_fwd_f32_splits(L, M, N, K, splits):
+    rng = np.random.default_rng(7)
+    x, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K))
+    b = rng.standard_normal(N).astype(np.float32)
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(b)
+    y = torch.full((splits, M, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_fwd_f32(xd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), M, N, K, splits, y.data_ptr(), N, sp())
+    got = y.sum(0).cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 128, 1), (128, 256, 192, 1), (64, 64, 128, 2),
+                                          (192, 64, 256, 4), (256, 128, 64, 1)])
+def test_linear_dgrad_f32(L, M, N, K, splits):
+    """dX[M,N] = dY[M,K] @ W[K,N] with W consumed in [out=K, in=N] layout (transposing LDS reads)."""
+    rng = np.random.default_rng(11)
+    dy, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N))
+    dyd, wd = dev(dy, torch.bfloat16), dev(w, torch.bfloat16)
+    out = torch.full((splits, M, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad(dyd.data_ptr(), K, wd.data_ptr(), N, M, N, K, None, 0, None, 0, None,
+                      out.data_ptr(), N, splits, sp())
+    ref = dy.astype(np.float64) @ w.astype(np.float64)
+    np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+def test_linear_dgrad_mask_colsum(L):
+    M, N, K = 256, 256, 128
+    rng = np.random.default_rng(12)
+    dy, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N))
+    h = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
+    dyd, wd, hd = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(h, torch.bfloat16)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    cs = torch.zeros((M // 128, N), dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad(dyd.data_ptr(), K, wd.data_ptr(), N, M, N, K, hd.data_ptr(), N, out.data_ptr(), N,
+                      cs.data_ptr(), None, 0, 1, sp())
+    ref = (dy.astype(np.float64) @ w.astype(np.float64)) * (h > 0)
+    got = out.float().cpu().numpy()
+    assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), ref.sum(0), rtol=1e-4, atol=1e-4 * np.abs(ref.sum(0)).max())
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 128, 1), (128, 256, 256, 2), (64, 64, 256, 4),
+                                          (192, 64, 128, 1), (256, 128, 512, 4)])
+def test_linear_wgrad(L, M, N, K, splits):
+    """dW[M,N] = dY[K,M]^T @ X[K,N]; K is the batch."""
+    rng = np.random.default_rng(13)
+    dy, x = rand_bf16(rng, (K, M)), rand_bf16(rng, (K, N))
+    dyd, xd = dev(dy, torch.bfloat16), dev(x, torch.bfloat16)
+    out = torch.full((splits, M, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_wgrad(dyd.data_ptr(), M, xd.data_ptr(), N, M, N, K, splits, out.data_ptr(), N, sp())
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+def test_gemm_identity_asymmetric(L):
+    """A = I against an asymmetric B catches transposed C writes / swapped fragment maps."""
+    M = N = K = 128
+    a = np.eye(M, dtype=np.float32)
+    b = O.bf16_round((np.arange(K * N, dtype=np.float32).reshape(K, N) % 251) - 100)
+    ad, bd = dev(a, torch.bfloat16), dev(b, torch.bfloat16)
+    out = torch.zeros((1, M, N), dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad(ad.data_ptr(), K, bd.data_ptr(), N, M, N, K, None, 0, None, 0, None, out.data_ptr(), N, 1, sp())
+    np.testing.assert_array_equal(out[0].cpu().numpy(), b)
+    L.rv_linear_wgrad(ad.data_ptr(), M, bd.data_ptr(), N, M, N, K, 1, out.data_ptr(), N, sp())
+    np.testing.assert_array_equal(out[0].cpu().numpy(), b)
+    bt = np.ascontiguousarray(b.T)
+    btd = dev(bt, torch.bfloat16)
+    L.rv_linear_fwd_f32(ad.data_ptr(), K, btd.data_ptr(), K, None, M, N, K, 1, out.data_ptr(), N, sp())
+    np.testing.assert_array_equal(out[0].cpu().numpy(), b)
+
+
+def test_cast_pad(L):
+    rng = np.random.default_rng(3)
+    for rows, cols, rp, cp in [(16, 64, 128, 128), (37, 100, 128, 128), (128, 256, 128, 256), (5, 7, 128, 128)]:
+        a = rng.standard_normal((rows, cols)).astype(np.float32)
+        ad = dev(a)
+        out = torch.full((rp, cp), 9.0, dtype=torch.bfloat16, device="cuda")
+        ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+        L.rv_cast_pad_bf16(ad.data_ptr(), rows, cols, cols, out.data_ptr(), rp, cp, ctr.data_ptr(), sp())
+        got = out.float().cpu().numpy()
+        np.testing.assert_array_equal(got[:rows, :cols], O.bf16_round(a))
+        assert np.all(got[rows:] == 0) and np.all(got[:, cols:] == 0)
+        assert int(ctr.item()) == 1
+
+
+def test_randn_statistics(L):
+    from scipy import stats
+    n = 1 << 20
+    out = torch.zeros(n + 3, dtype=torch.float32, device="cuda")
+    L.rv_randn(out.data_ptr(), n + 3, 1234, 5, sp())
+    a = out.cpu().numpy().astype(np.float64)
+    assert np.isfinite(a).all()
+    assert abs(a.mean()) < 5e-3 and abs(a.std() - 1) < 5e-3
+    assert abs(stats.skew(a)) < 2e-2 and abs(stats.kurtosis(a)) < 5e-2
+    assert stats.kstest(a[:200000], "norm").pvalue > 1e-3
+    out2 = torch.zeros_like(out)
+    L.rv_randn(out2.data_ptr(), n + 3, 1234, 5, sp())
+    assert torch.equal(out, out2)
+    L.rv_randn(out2.data_ptr(), n + 3, 1234, 6, sp())
+    assert not torch.equal(out, out2)
+    assert abs(np.corrcoef(a, out2.cpu().numpy())[0, 1]) < 5e-3
+
+
+@pytest.mark.parametrize("B,S,Lt", [(16, 64, 8), (32, 512, 8), (100, 1000, 3), (4096, 1024, 64)])
+def test_loss_fused(L, B, S, Lt):
+    rng = np.random.default_rng(5)
+    recon = np.tanh(rng.standard_normal((B, S))).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, S)).astype(np.float32)
+    mu = rng.standard_normal((B, Lt)).astype(np.float32)
+    lv = (0.3 * rng.standard_normal((B, Lt))).astype(np.float32)
+    kl_beta = 1e-4
+    ws = torch.zeros(L.rv_loss_fused_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    rd, xd, md, ld = dev(recon), dev(x), dev(mu), dev(lv)
+    out = torch.zeros(4, device="cuda")
+    dr, dm, dl = torch.zeros_like(rd), torch.zeros_like(md), torch.zeros_like(ld)
+    for _ in range(2):  # second call checks the ticket re-arms
+        L.rv_loss_fused(rd.data_ptr(), xd.data_ptr(), md.data_ptr(), ld.data_ptr(), B, S, Lt, kl_beta,
+                        out.data_ptr(), dr.data_ptr(), dm.data_ptr(), dl.data_ptr(), ws.data_ptr(), sp())
+        loss, mse, kld = O.loss_function(recon.astype(np.float64), x.astype(np.float64), mu.astype(np.float64),
+                                         lv.astype(np.float64), kl_beta)
+        got = out.cpu().numpy()
+        assert abs(got[0] - loss) <= 1e-5 * abs(loss)
+        assert abs(got[1] - mse) <= 1e-5 * abs(mse) and abs(got[2] - kld) <= 1e-4 * abs(kld) + 1e-7
+    np.testing.assert_allclose(dr.cpu().numpy(), 2 * (recon - x) / (B * S), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(dm.cpu().numpy(), kl_beta * mu / (B * Lt), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(dl.cpu().numpy(), kl_beta * 0.5 * (np.exp(lv) - 1) / (B * Lt), rtol=1e-4, atol=1e-12)
+
+
+def test_reparameterize(L):
+    rng = np.random.default_rng(6)
+    n = 1000
+    mu, lv, eps = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    z = torch.zeros(n, device="cuda")
+    mud, lvd, epd = dev(mu), dev(lv), dev(eps)  # keep the device tensors alive across the calls
+    L.rv_reparameterize(mud.data_ptr(), lvd.data_ptr(), n, epd.data_ptr(), None, 0, 0, z.data_ptr(), sp())
+    np.testing.assert_allclose(z.cpu().numpy(), mu + eps * np.exp(0.5 * lv), rtol=2e-6, atol=1e-6)
+    e_out = torch.zeros(n, device="cuda")
+    L.rv_reparameterize(mud.data_ptr(), lvd.data_ptr(), n, None, e_out.data_ptr(), 9, 1, z.data_ptr(), sp())
+    e = e_out.cpu().numpy()
+    np.testing.assert_allclose(z.cpu().numpy(), mu + e * np.exp(0.5 * lv), rtol=2e-6, atol=1e-6)
+    assert abs(e.mean()) < 0.15 and abs(e.std() - 1) < 0.15
+
+
+def test_adam_multi_and_finalize(L):
+    from rawaudiovae_kelsey_amd._lib import ParamDesc
+    rng = np.random.default_rng(8)
+    shapes = [(5, 7), (1, 11), (3, 4)]
+    n = sum(r * c for r, c in shapes)
+    param = rng.standard_normal(n).astype(np.float32)
+    m0 = (0.01 * rng.standard_normal(n)).astype(np.float32)
+    v0 = (1e-4 * rng.random(n)).astype(np.float32)
+    pd, md, vd = dev(param), dev(m0), dev(v0)
+    gout = torch.zeros(n, device="cuda")
+    descs = (ParamDesc * len(shapes))()
+    keep, grads, off = [], [], 0
+    shadows = []
+    for i, (r, c) in enumerate(shapes):
+        splits, ld = 3, c + 5
+        slab = rng.standard_normal((splits, r + 2, ld)).astype(np.float32)
+        sd = dev(slab)
+        keep.append(sd)
+        grads.append(slab[:, :r, :c].sum(0))
+        sh = torch.zeros((r + 1, c + 3), dtype=torch.bfloat16, device="cuda")
+        shadows.append(sh)
+        descs[i] = ParamDesc(off, r, c, sd.data_ptr(), ld, (r + 2) * ld, splits, sh.data_ptr(), None, c + 3)
+        off += r * c
+    ctr = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    L.rv_grad_finalize(descs, len(shapes), gout.data_ptr(), sp())
+    gflat = np.concatenate([g.reshape(-1) for g in grads])
+    np.testing.assert_allclose(gout.cpu().numpy(), gflat, rtol=1e-6, atol=1e-6)
+    L.rv_adam_multi(descs, len(shapes), pd.data_ptr(), md.data_ptr(), vd.data_ptr(), None, 1e-3, 0.5,
+                    ctr.data_ptr(), sp())
+    g = 0.5 * gflat.astype(np.float64)
+    m = 0.9 * m0 + 0.1 * g
+    v = 0.999 * v0 + 0.001 * g * g
+    t = 3
+    p = param - (1e-3 / (1 - 0.9 ** t)) * m / (np.sqrt(v) / np.sqrt(1 - 0.999 ** t) + 1e-8)
+    np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=1e-5, atol=1e-6)
+    o = 0
+    for (r, c), sh in zip(shapes, shadows):
+        got = sh.float().cpu().numpy()
+        np.testing.assert_array_equal(got[:r, :c], O.bf16_round(pd.cpu().numpy()[o:o + r * c].reshape(r, c)))
+        assert np.all(got[r:] == 0) and np.all(got[:, c:] == 0)
+        o += r * c
