@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X training path: audio frames/sec for a full training
+step (forward + fused loss + backward + Adam) on synthetic 1024-sample frames.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / configs[2]): S=1024, H=2048, L=64, per-GPU batch
+4096, bf16 MFMA inputs with fp32 accumulation, fp32 master weights and Adam state.
+A step is one pass of the hot path over one resident batch (a pool of 8 distinct
+device-resident batches is cycled); eps is drawn on-device.  One process per GPU;
+with N > 1 the fp32 gradients are all-reduced over RCCL in two buckets, the first
+overlapped with the rest of backward (weak scaling: per-GPU batch fixed).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the TN weight-
+gradient GEMM, launched twice per step), timed live with HIP events; `cpu_baseline`
+is the stock-PyTorch CPU port of the same step (oracle/torch_port.py) timed on this
+node's host cores (N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+S, H, L, B = 1024, 2048, 64, 4096
+KL_BETA, LR = 1e-4, 1e-4
+POOL = 8
+PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def time_dominant_kernel(eng, reps=50):
+    """Average duration of the TN wgrad GEMM (dW4 = dP4^T h3: M=S, N=H, K=B) with HIP
+    events on the launching stream.  Returns (ms_per_launch, flops_per_launch)."""
+    import torch
+    from rawaudiovae_kelsey_amd._lib import lib, stream_ptr
+    Lb = lib()
+    Bp, Sp, Hp, Lp = eng.padded()
+    dP4 = eng.buffer("dP4", torch.bfloat16, (Bp, Sp))
+    h3 = eng.buffer("h3", torch.bfloat16, (Bp, Hp))
+    splits = 2
+    out = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
+    st = stream_ptr()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    Lb.rv_event_create(C.byref(e0))
+    Lb.rv_event_create(C.byref(e1))
+
+    def launch():
+        Lb.rv_linear_wgrad(dP4.data_ptr(), Sp, h3.data_ptr(), Hp, Sp, Hp, Bp, splits, out.data_ptr(), Hp, st)
+    for _ in range(5):
+        launch()
+    Lb.rv_event_record(e0, st)
+    for _ in range(reps):
+        launch()
+    Lb.rv_event_record(e1, st)
+    ms = C.c_float()
+    Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
+    Lb.rv_event_destroy(e0)
+    Lb.rv_event_destroy(e1)
+    return ms.value / reps, 2.0 * S * H * B
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from oracle.inputs import flops_per_frame, make_frames, make_params
+    from rawaudiovae_kelsey_amd import engine as E
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
+    eng.load_params(make_params(S, H, L, 0))
+    pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
+    comp = torch.cuda.Stream(device=dev)
+    use_graph = world == 1 and not args.no_graph
+    off_a = eng.offsets["fc3.weight"]  # grad arena: [fc1, fc21, fc22 | fc3, fc4]
+
+    def ddp_step(x):
+        eng.step(x, phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_FINALIZE_A, stream=comp)
+        wa = dist.all_reduce(eng.grad[off_a:], async_op=True)  # overlaps with BWD_B
+        eng.step(x, phases=E.PHASE_BWD_B | E.PHASE_FINALIZE_B, stream=comp)
+        wb = dist.all_reduce(eng.grad[:off_a], async_op=True)
+        wa.wait()
+        wb.wait()
+        eng.step(x, phases=E.PHASE_ADAM, grad_scale=1.0 / world, adam_from_flat=True, stream=comp)
+
+    graphs = []
+    with torch.cuda.stream(comp):
+        eng.step(pool[0], stream=comp)  # eager warm-up (sets kernel attributes before capture)
+        torch.cuda.synchronize()
+        if use_graph:
+            for x in pool:
+                g = E.Graph(comp)
+                with g:
+                    eng.step(x, stream=comp)
+                graphs.append(g)
+
+        def one_step(i):
+            if world > 1:
+                ddp_step(pool[i % POOL])
+            elif use_graph:
+                graphs[i % POOL].launch()
+                eng.host_steps += 1
+            else:
+                eng.step(pool[i % POOL], stream=comp)
+
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        last = eng.losses(min(8, args.steps))
+        kern_ms, kern_flops = time_dominant_kernel(eng) if rank == 0 else (None, None)
+
+    if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
+        print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)
+        sys.exit(3)
+
+    if rank == 0:
+        frames = float(B) * world * args.steps
+        value = frames / dt
+        achieved = kern_flops / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "audio frames/sec (fwd+bwd+step), 1024-sample frames",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
+                                   "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "grad_allreduce": "fp32, 2 buckets" if world > 1 else None},
+            "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
+            "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "final_loss": last[-1],
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,TN,EPI_F32> (weight-gradient GEMM "
+                                                    "dW=dY^T X, M=1024 N=2048 K=4096, split-K 2)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "us_per_launch": kern_ms * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.torch_port import time_cpu_step
+            fps, ms, n, threads = time_cpu_step(S, H, L, B, make_params(S, H, L, 0), make_frames(B, S, 1234),
+                                                seconds=args.cpu_seconds)
+            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": "%d steps of the same C2 step (B=4096) in stock PyTorch fp32 on the "
+                                             "host, median %.1f ms/step" % (n, ms)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

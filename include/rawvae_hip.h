@@ -43,13 +43,13 @@ const char* rv_last_error(void);
 /* Padded extents used by every bf16 operand: Bp, Sp, Hp multiples of 128, Lp of 64. */
 int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, long* Lp);
 
-/* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (ld = cols_p).
+/* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (leading dim ld_dst).
  * Replaces the implicit fp32 operand read of F.linear (model.py:20) for frames and
  * is how weight shadows are (re)built after load_state_dict.  If `step_counter` is
  * non-NULL the kernel also increments *step_counter (device int64) once: it is the
  * first kernel of a training step. */
 int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16,
-                     long rows_p, long cols_p, long long* step_counter, void* stream);
+                     long rows_p, long cols_p, long ld_dst, long long* step_counter, void* stream);
 
 /* y = act(x W^T + b) -> bf16.  nn.Linear + F.relu, model.py:20 (fc1) and :29 (fc3).
  * x [Mp,Kp] bf16, w [Np,Kp] bf16 (nn.Linear [out,in] layout), bias [Np] fp32 or NULL. */
@@ -134,6 +134,26 @@ int rv_loss_fused(const float* recon, const float* x, const float* mu, const flo
 int rv_reparameterize(const float* mu, const float* logvar, long n, const float* eps_in,
                       float* eps_out, unsigned long long seed, unsigned long long offset,
                       float* z, void* stream);
+
+/* Backward of reparameterize for callers that use it on its own: dmu = dz,
+ * dlv = dz*eps*exp(logvar/2)/2 (either output may be NULL). */
+int rv_reparameterize_bwd(const float* dz, const float* eps, const float* logvar, long n,
+                          float* dmu, float* dlv, void* stream);
+
+/* Backward of F.tanh (model.py:30) for VAE.decode used without the fused loss:
+ * dP4 = d_recon*(1-recon^2), exact fp32 [B,S] inputs -> zero-padded bf16 [Bp,Sp]. */
+int rv_tanh_bwd_pack(const float* d_recon, const float* recon, long B, long S, void* dP4_bf16,
+                     long Bp, long Sp, void* stream);
+
+/* Partial column sums (bias gradients): out[rb][c] = sum of rows [256 rb, 256 rb+256) of
+ * column c; src is fp32 or bf16 [rows, cols] with leading dim ld.  ceil(rows/256) slabs,
+ * summed by rv_grad_finalize / rv_adam_multi. */
+int rv_colsum_partial(const void* src, int is_bf16, long rows, long cols, long ld, float* out,
+                      long ld_out, void* stream);
+
+/* out[i] = a[i] * scalar[0] (device scalar): applies the upstream gradient of the 0-dim
+ * loss tensor to the gradients rv_loss_fused saved. */
+int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* stream);
 
 /* Standard normal draws (replaces torch.randn_like, model.py:25). */
 int rv_randn(float* out, long n, unsigned long long seed, unsigned long long offset,

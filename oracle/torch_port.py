@@ -56,7 +56,14 @@ def time_cpu_step(S, H, L, B, params, x, seconds=15.0, warmup=2, kl_beta=1e-4, l
     """Time zero_grad/forward/loss/backward/Adam.step on the host CPU.
     Returns (frames_per_s, ms_per_step_median, steps_timed, threads)."""
     import os
-    threads = threads or os.cpu_count()
+    if not threads:
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count()
+        # a one-GPU box is given a 16-core share of a much larger host; more threads than
+        # that only oversubscribes (measured: 256 threads -> 12.7 s/step)
+        threads = min(threads, int(os.environ.get("RV_CPU_THREADS", "16")))
     torch.set_num_threads(threads)
     model = PortVAE(S, H, L).load_numpy(params)
     opt = torch.optim.Adam(model.parameters(), lr=lr)

@@ -40,8 +40,12 @@ _SIGS = {
     "rv_version": (c_int, []),
     "rv_last_error": (C.c_char_p, []),
     "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
-    "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long,
+    "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
+    "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "rv_tanh_bwd_pack": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p]),
+    "rv_colsum_partial": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
+    "rv_scale_by": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                               c_int, c_void_p, c_long, c_void_p]),
     "rv_linear_fwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,

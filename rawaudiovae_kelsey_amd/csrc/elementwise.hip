@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(256) k_randn(float* out, long n, uint64_t seed
 __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__ src, long rows,
                                                        long cols, long ld_src,
                                                        bf16_t* __restrict__ dst, long rows_p,
-                                                       long cols_p, long long* step_counter) {
+                                                       long cols_p, long ld_dst,
+                                                       long long* step_counter) {
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
   const long cpr = cols_p / 8;
   const long total = rows_p * cpr;
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-    *reinterpret_cast<bf16x8*>(dst + r * cols_p + c) = o;
+    *reinterpret_cast<bf16x8*>(dst + r * ld_dst + c) = o;
   }
 }
 
@@ -313,6 +314,60 @@ k_reparameterize(const float* __restrict__ mu, const float* __restrict__ lv, lon
   }
 }
 
+// ------------------------------------------------------------------ API-path helpers
+// dP4 = d_recon * (1 - recon^2) -> zero-padded bf16 (backward of F.tanh, model.py:30).
+__global__ void __launch_bounds__(256)
+k_tanh_bwd_pack(const float* __restrict__ d_recon, const float* __restrict__ recon, long B, long S,
+                bf16_t* __restrict__ out, long Bp, long Sp) {
+  const long total = Bp * Sp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / Sp, c = i % Sp;
+    float v = 0.f;
+    if (r < B && c < S) {
+      const float y = recon[r * S + c];
+      v = d_recon[r * S + c] * (1.f - y * y);
+    }
+    out[i] = (bf16_t)v;
+  }
+}
+
+// Partial column sums: block (cx, ry) sums rows [256*ry, 256*ry+256) of columns
+// [64*cx, 64*cx+64) -> out[ry][col].  Deterministic; finished by rv_grad_finalize.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_colsum_partial(const T* __restrict__ src, long rows, long cols, long ld, float* __restrict__ out,
+                 long ld_out) {
+  __shared__ float sh[256];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + c;
+  const long r0 = (long)blockIdx.y * 256;
+  float s = 0.f;
+  if (col < cols)
+    for (long r = r0 + q; r < r0 + 256 && r < rows; r += 4) s += (float)src[r * ld + col];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && col < cols) out[(long)blockIdx.y * ld_out + col] = sh[c] + sh[64 + c] + sh[128 + c] + sh[192 + c];
+}
+
+// Backward of z = mu + eps*exp(logvar/2) (model.py:23-26): dmu = dz, dlv = dz*eps*std/2.
+__global__ void __launch_bounds__(256)
+k_reparameterize_bwd(const float* __restrict__ dz, const float* __restrict__ eps,
+                     const float* __restrict__ lv, long n, float* __restrict__ dmu,
+                     float* __restrict__ dlv) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = dz[i];
+    if (dmu) dmu[i] = g;
+    if (dlv) dlv[i] = g * eps[i] * 0.5f * __expf(0.5f * lv[i]);
+  }
+}
+
+// out = a * scalar[0] (upstream gradient of the 0-dim loss applied to a saved gradient).
+__global__ void __launch_bounds__(256)
+k_scale_by(const float* __restrict__ a, const float* __restrict__ scalar, long n, float* __restrict__ out) {
+  const float g = scalar[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * g;
+}
+
 // ------------------------------------------------------------------ Adam / gradient finaliser
 constexpr int MAX_DESC = 16;
 struct DescTable {
@@ -408,13 +463,14 @@ int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, lo
 }
 
 int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long rows_p,
-                     long cols_p, long long* step_counter, void* stream) {
+                     long cols_p, long ld_dst, long long* step_counter, void* stream) {
   RV_REQUIRE(src && dst, RV_ERR_NULL, "rv_cast_pad_bf16: null pointer");
-  RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols,
-             RV_ERR_SHAPE, "rv_cast_pad_bf16: bad extents %ld %ld -> %ld %ld", rows, cols, rows_p, cols_p);
+  RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols &&
+                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst & 15) == 0,
+             RV_ERR_SHAPE, "rv_cast_pad_bf16: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
   const long total = rows_p * (cols_p / 8);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, step_counter);
+                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -480,6 +536,49 @@ int rv_reparameterize(const float* mu, const float* logvar, long n, const float*
   if (n == 0) return RV_OK;
   hipLaunchKernelGGL(k_reparameterize, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar,
                      n, eps_in, eps_out, (uint64_t)seed, (uint64_t)offset, z);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_tanh_bwd_pack(const float* d_recon, const float* recon, long B, long S, void* dP4, long Bp,
+                     long Sp, void* stream) {
+  RV_REQUIRE(d_recon && recon && dP4, RV_ERR_NULL, "rv_tanh_bwd_pack: null pointer");
+  RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_tanh_bwd_pack: bad extents");
+  hipLaunchKernelGGL(k_tanh_bwd_pack, dim3(grid_for(Bp * Sp, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     d_recon, recon, B, S, (bf16_t*)dP4, Bp, Sp);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_colsum_partial(const void* src, int is_bf16, long rows, long cols, long ld, float* out,
+                      long ld_out, void* stream) {
+  RV_REQUIRE(src && out, RV_ERR_NULL, "rv_colsum_partial: null pointer");
+  RV_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ld_out >= cols, RV_ERR_SHAPE, "rv_colsum_partial: bad extents");
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 255) / 256));
+  if (is_bf16)
+    hipLaunchKernelGGL(k_colsum_partial<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, rows, cols, ld, out, ld_out);
+  else
+    hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, rows, cols, ld, out, ld_out);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_reparameterize_bwd(const float* dz, const float* eps, const float* logvar, long n, float* dmu,
+                          float* dlv, void* stream) {
+  RV_REQUIRE(dz && eps && logvar, RV_ERR_NULL, "rv_reparameterize_bwd: null pointer");
+  if (n == 0) return RV_OK;
+  hipLaunchKernelGGL(k_reparameterize_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dz, eps,
+                     logvar, n, dmu, dlv);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* stream) {
+  RV_REQUIRE(a && scalar && out, RV_ERR_NULL, "rv_scale_by: null pointer");
+  if (n == 0) return RV_OK;
+  hipLaunchKernelGGL(k_scale_by, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, scalar, n, out);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -179,7 +179,7 @@ int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
       if (i == 0 || i == 6) rows_p = p->Hp;
       else if (i == 8) rows_p = p->Sp;
       else rows_p = p->Lp;
-      int rc = rv_cast_pad_bf16(src, d.rows, d.cols, d.cols, d.shadow_bf16, rows_p, cols_p, nullptr, stream);
+      int rc = rv_cast_pad_bf16(src, d.rows, d.cols, d.cols, d.shadow_bf16, rows_p, cols_p, cols_p, nullptr, stream);
       if (rc) return rc;
     } else {
       long pad = (i == 3 || i == 5) ? p->Lp : d.shadow_ld;
@@ -205,7 +205,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
   if (phases & RV_PHASE_FWD) {
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
-    RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, p->b.step_counter, stream));
+    RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
     RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
     RV_TRY(rv_linear_fwd_f32(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, L2p, Hp, p->s_heads,
                              mulv_slabs, L2p, stream));

@@ -144,15 +144,20 @@ class TrainEngine:
         mulv = self.buffer("mulv", torch.float32, (Bp, 2 * Lp))
         return mulv[:self.B, :self.L].contiguous(), mulv[:self.B, Lp:Lp + self.L].contiguous()
 
+    def steps_done(self):
+        """Number of steps started on the device (reads the device counter; synchronises)."""
+        return int(self.step_counter.item())
+
     def last_loss(self):
         """(total, mse, kld) of the most recent step; synchronises."""
-        slot = (self.host_steps - 1) % self.ring
+        slot = (self.steps_done() - 1) % self.ring
         return tuple(float(v) for v in self.loss_ring[slot, :3].tolist())
 
     def losses(self, n):
         """Totals of the last n steps (n <= ring), oldest first; synchronises."""
-        n = min(n, self.ring, self.host_steps)
-        idx = [(self.host_steps - n + i) % self.ring for i in range(n)]
+        done = self.steps_done()
+        n = min(n, self.ring, done)
+        idx = [(done - n + i) % self.ring for i in range(n)]
         return self.loss_ring[idx, 0].tolist()
 
 

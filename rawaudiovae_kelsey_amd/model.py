@@ -1,0 +1,79 @@
+"""`VAE` and `loss_function` with the reference's exact surface
+(/root/reference/rawvae/model.py:5-47), computing on MI355X through the HIP
+kernels of librawvae_hip.so.
+
+Kept from the reference: constructor signature `VAE(segment_length, n_units,
+latent_dim)`, attributes, the five `nn.Linear` sub-modules (so `state_dict()` keys
+`fc{1,21,22,3,4}.{weight,bias}`, `[out,in]` fp32 layouts and the default
+initialisation are identical -- reference checkpoints load both ways), methods
+`encode / reparameterize / decode / forward`, and
+`loss_function(recon_x, x, mu, logvar, kl_beta, segment_length)`.
+
+Added (optional, keyword-only): an explicit `eps` for `reparameterize`/`forward`
+(parity runs: the reference draws it from torch's global generator, model.py:25),
+and `VAE.engine(batch_size, ...)`, which returns the fused whole-step
+`TrainEngine` sharing this module's parameters.
+
+The module computes on the GPU only; CPU tensors raise (there is no fallback).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class VAE(nn.Module):
+    def __init__(self, segment_length, n_units, latent_dim):
+        super().__init__()
+        self.segment_length = segment_length
+        self.n_units = n_units
+        self.latent_dim = latent_dim
+        # same construction order as the reference => same init under the same seed
+        self.fc1 = nn.Linear(segment_length, n_units)
+        self.fc21 = nn.Linear(n_units, latent_dim)
+        self.fc22 = nn.Linear(n_units, latent_dim)
+        self.fc3 = nn.Linear(latent_dim, n_units)
+        self.fc4 = nn.Linear(n_units, segment_length)
+        self._rng_seed = 0x5EED
+        self._rng_calls = 0
+
+    # -- reference methods -------------------------------------------------
+    def encode(self, x):
+        x2 = x.reshape(-1, self.segment_length)
+        return ops.EncodeFn.apply(x2, self.fc1.weight, self.fc1.bias, self.fc21.weight, self.fc21.bias,
+                                  self.fc22.weight, self.fc22.bias)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        self._rng_calls += 1
+        return ops.ReparamFn.apply(mu, logvar, eps, self._rng_seed, self._rng_calls)
+
+    def decode(self, z):
+        z2 = z.reshape(-1, self.latent_dim)
+        return ops.DecodeFn.apply(z2, self.fc3.weight, self.fc3.bias, self.fc4.weight, self.fc4.bias)
+
+    def forward(self, x, eps=None):
+        mu, logvar = self.encode(x.view(-1, self.segment_length))
+        z = self.reparameterize(mu, logvar, eps)
+        return self.decode(z), mu, logvar
+
+    # -- additions -----------------------------------------------------------
+    def manual_seed(self, seed):
+        """Seed of the on-device eps generator (stands in for torch.manual_seed's role)."""
+        self._rng_seed, self._rng_calls = int(seed), 0
+        return self
+
+    def engine(self, batch_size, kl_beta, lr, seed=0, **kw):
+        """Fused training-step engine whose parameter arena this module's Parameters
+        are re-pointed at (train.py:163,184-193 in one call per batch)."""
+        from .engine import TrainEngine
+        dev = self.fc1.weight.device
+        eng = TrainEngine(self.segment_length, self.n_units, self.latent_dim, batch_size, device=dev,
+                          kl_beta=kl_beta, lr=lr, seed=seed, **kw)
+        eng.adopt(self)
+        return eng
+
+
+def loss_function(recon_x, x, mu, logvar, kl_beta, segment_length):
+    """mean squared reconstruction error + kl_beta * KL(q(z|x) || N(0,1)), both `mean`
+    reductions, returned as a 0-dim tensor (model.py:38-47)."""
+    return ops.LossFn.apply(recon_x, x.reshape(-1, segment_length), mu, logvar, kl_beta)

@@ -1,0 +1,260 @@
+"""torch.autograd.Functions behind the reference's method surface
+(`VAE.encode / reparameterize / decode`, `loss_function` -- rawvae/model.py:19-47).
+
+Each Function's forward and backward are sequences of C-ABI kernel launches
+(include/rawvae_hip.h) on PyTorch's current stream.  PyTorch supplies device
+memory and the autograd graph only; no arithmetic of the model runs in ATen.
+Boundary tensors (frames, mu, logvar, z, recon, parameters, gradients) are fp32
+with the reference's exact shapes; between kernels activations live as zero-padded
+bf16 operands.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_RELU, ParamDesc, lib, pad_dims, ptr, stream_ptr
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.RvError(
+                "rawvae (MI355X build) computes on the GPU only: got a %s tensor. Move the model "
+                "and the data to the device (`model.to('cuda')`, `x.to('cuda')`)." % t.device)
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def _bf16_empty(rows, cols, dev):
+    return torch.empty((rows, cols), dtype=torch.bfloat16, device=dev)
+
+
+def cast_pad(src, rows_p, cols_p, out=None, ld_dst=None):
+    """fp32 [r, c] -> zero-padded bf16 [rows_p, cols_p] (optionally into a column block)."""
+    src = _f32c(src)
+    r, c = (src.shape if src.dim() == 2 else (1, src.numel()))
+    if out is None:
+        out = _bf16_empty(rows_p, cols_p, src.device)
+        ld_dst = cols_p
+    lib().rv_cast_pad_bf16(ptr(src), r, c, c, ptr(out), rows_p, cols_p, ld_dst, None, stream_ptr())
+    return out
+
+
+def _pad_bias(b, n_p):
+    out = torch.zeros(n_p, dtype=torch.float32, device=b.device)
+    out[:b.numel()].copy_(b.detach())
+    return out
+
+
+def _slab_sum(slabs, splits, rows_p, ld, rows, cols, row0=0, col0=0):
+    """Sum `splits` fp32 slabs [rows_p, ld] and crop to an exact [rows, cols] tensor."""
+    out = torch.empty((rows, cols), dtype=torch.float32, device=slabs.device)
+    d = (ParamDesc * 1)()
+    base = slabs.data_ptr() + 4 * (row0 * ld + col0)
+    d[0] = ParamDesc(0, rows, cols, base, ld, rows_p * ld, splits, None, None, 0)
+    lib().rv_grad_finalize(d, 1, ptr(out), stream_ptr())
+    return out
+
+
+def _splits_for(tiles, k_tiles):
+    s = 1
+    while tiles * s < 256 and s < 16 and k_tiles % (2 * s) == 0 and k_tiles // (2 * s) >= 2:
+        s *= 2
+    return s
+
+
+def _tile(m, n):
+    return 128 if (m % 128 == 0 and n % 128 == 0) else 64
+
+
+def _wgrad(dy, x, Mp, Np, Kp):
+    """dW slabs for dy [Kp, Mp], x [Kp, Np] (both bf16 padded). Returns (slabs, splits)."""
+    t = _tile(Mp, Np)
+    splits = _splits_for((Mp // t) * (Np // t), Kp // 64)
+    slabs = torch.empty((splits, Mp, Np), dtype=torch.float32, device=dy.device)
+    lib().rv_linear_wgrad(ptr(dy), Mp, ptr(x), Np, Mp, Np, Kp, splits, ptr(slabs), Np, stream_ptr())
+    return slabs, splits
+
+
+def _colsum(src, is_bf16, rows, cols, ld):
+    nb = (rows + 255) // 256
+    part = torch.empty((nb, cols), dtype=torch.float32, device=src.device)
+    lib().rv_colsum_partial(ptr(src), int(is_bf16), rows, cols, ld, ptr(part), cols, stream_ptr())
+    return _slab_sum(part, nb, 1, cols, 1, cols).view(cols)
+
+
+class EncodeFn(torch.autograd.Function):
+    """h1 = relu(x W1^T + b1); mu, logvar = h1 [W21;W22]^T + [b21;b22]   (model.py:19-21)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W21, b21, W22, b22):
+        _require_cuda(x, W1)
+        L_ = lib()
+        x = _f32c(x)
+        B, S = x.shape
+        H, Ld = W1.shape[0], W21.shape[0]
+        Bp, Sp, Hp, Lp = pad_dims(B, S, H, Ld)
+        st = stream_ptr()
+        xb = cast_pad(x, Bp, Sp)
+        W1b = cast_pad(W1.detach(), Hp, Sp)
+        Whb = _bf16_empty(2 * Lp, Hp, x.device)
+        cast_pad(W21.detach(), Lp, Hp, out=Whb[:Lp], ld_dst=Hp)
+        cast_pad(W22.detach(), Lp, Hp, out=Whb[Lp:], ld_dst=Hp)
+        bh = torch.zeros(2 * Lp, dtype=torch.float32, device=x.device)
+        bh[:Ld].copy_(b21.detach())
+        bh[Lp:Lp + Ld].copy_(b22.detach())
+        h1 = _bf16_empty(Bp, Hp, x.device)
+        L_.rv_linear_fwd(ptr(xb), Sp, ptr(W1b), Sp, ptr(_pad_bias(b1, Hp)), Bp, Hp, Sp, ACT_RELU, ptr(h1), Hp, st)
+        mulv = torch.empty((Bp, 2 * Lp), dtype=torch.float32, device=x.device)
+        L_.rv_linear_fwd_f32(ptr(h1), Hp, ptr(Whb), Hp, ptr(bh), Bp, 2 * Lp, Hp, 1, ptr(mulv), 2 * Lp, st)
+        ctx.save_for_backward(xb, h1, Whb)
+        ctx.dims = (B, S, H, Ld, Bp, Sp, Hp, Lp)
+        return mulv[:B, :Ld].contiguous(), mulv[:B, Lp:Lp + Ld].contiguous()
+
+    @staticmethod
+    def backward(ctx, dmu, dlv):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input frames is not part of the training path")
+        L_ = lib()
+        xb, h1, Whb = ctx.saved_tensors
+        B, S, H, Ld, Bp, Sp, Hp, Lp = ctx.dims
+        st = stream_ptr()
+        dmu = _f32c(dmu if dmu is not None else torch.zeros((B, Ld), device=xb.device))
+        dlv = _f32c(dlv if dlv is not None else torch.zeros((B, Ld), device=xb.device))
+        dmulv = _bf16_empty(Bp, 2 * Lp, xb.device)
+        cast_pad(dmu, Bp, Lp, out=dmulv, ld_dst=2 * Lp)
+        cast_pad(dlv, Bp, Lp, out=dmulv[:, Lp:], ld_dst=2 * Lp)
+        dP1 = _bf16_empty(Bp, Hp, xb.device)
+        cs1 = torch.empty((Bp // 128, Hp), dtype=torch.float32, device=xb.device)
+        L_.rv_linear_dgrad(ptr(dmulv), 2 * Lp, ptr(Whb), Hp, Bp, Hp, 2 * Lp, ptr(h1), Hp, ptr(dP1), Hp,
+                           ptr(cs1), None, 0, 1, st)
+        sl_h, s_h = _wgrad(dmulv, h1, 2 * Lp, Hp, Bp)
+        sl_1, s_1 = _wgrad(dP1, xb, Hp, Sp, Bp)
+        dW1 = _slab_sum(sl_1, s_1, Hp, Sp, H, S)
+        db1 = _slab_sum(cs1, Bp // 128, 1, Hp, 1, H).view(H)
+        dW21 = _slab_sum(sl_h, s_h, 2 * Lp, Hp, Ld, H)
+        dW22 = _slab_sum(sl_h, s_h, 2 * Lp, Hp, Ld, H, row0=Lp)
+        db21 = _colsum(dmu, False, B, Ld, Ld)
+        db22 = _colsum(dlv, False, B, Ld, Ld)
+        return None, dW1, db1, dW21, db21, dW22, db22
+
+
+class ReparamFn(torch.autograd.Function):
+    """z = mu + eps * exp(0.5 logvar)   (model.py:23-26); eps explicit or drawn on-device."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, seed, offset):
+        _require_cuda(mu, logvar, eps)
+        mu, logvar = _f32c(mu), _f32c(logvar)
+        n = mu.numel()
+        z = torch.empty_like(mu)
+        if eps is None:
+            eps_used = torch.empty_like(mu)
+            lib().rv_reparameterize(ptr(mu), ptr(logvar), n, None, ptr(eps_used), seed, offset, ptr(z), stream_ptr())
+        else:
+            eps_used = _f32c(eps)
+            lib().rv_reparameterize(ptr(mu), ptr(logvar), n, ptr(eps_used), None, 0, 0, ptr(z), stream_ptr())
+        ctx.save_for_backward(eps_used, logvar)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        eps, logvar = ctx.saved_tensors
+        dz = _f32c(dz)
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        lib().rv_reparameterize_bwd(ptr(dz), ptr(eps), ptr(logvar), dz.numel(), ptr(dmu), ptr(dlv), stream_ptr())
+        return dmu, dlv, None, None, None
+
+
+class DecodeFn(torch.autograd.Function):
+    """h3 = relu(z W3^T + b3); recon = tanh(h3 W4^T + b4)   (model.py:28-30)."""
+
+    @staticmethod
+    def forward(ctx, z, W3, b3, W4, b4):
+        _require_cuda(z, W3)
+        L_ = lib()
+        z = _f32c(z)
+        B, Ld = z.shape
+        H, S = W3.shape[0], W4.shape[0]
+        Bp, Sp, Hp, Lp = pad_dims(B, S, H, Ld)
+        st = stream_ptr()
+        zb = cast_pad(z, Bp, Lp)
+        W3b = cast_pad(W3.detach(), Hp, Lp)
+        W4b = cast_pad(W4.detach(), Sp, Hp)
+        h3 = _bf16_empty(Bp, Hp, z.device)
+        L_.rv_linear_fwd(ptr(zb), Lp, ptr(W3b), Lp, ptr(_pad_bias(b3, Hp)), Bp, Hp, Lp, ACT_RELU, ptr(h3), Hp, st)
+        recon = torch.empty((B, S), dtype=torch.float32, device=z.device)
+        L_.rv_decode_out_loss_fwd(ptr(h3), Hp, ptr(W4b), Hp, ptr(_pad_bias(b4, Sp)), Bp, Sp, Hp, B, S,
+                                  None, 0, ptr(recon), S, None, 0, None, None, st)
+        ctx.save_for_backward(zb, h3, W3b, W4b, recon)
+        ctx.dims = (B, S, H, Ld, Bp, Sp, Hp, Lp)
+        return recon
+
+    @staticmethod
+    def backward(ctx, d_recon):
+        L_ = lib()
+        zb, h3, W3b, W4b, recon = ctx.saved_tensors
+        B, S, H, Ld, Bp, Sp, Hp, Lp = ctx.dims
+        st = stream_ptr()
+        dev = zb.device
+        d_recon = _f32c(d_recon)
+        dP4 = _bf16_empty(Bp, Sp, dev)
+        L_.rv_tanh_bwd_pack(ptr(d_recon), ptr(recon), B, S, ptr(dP4), Bp, Sp, st)
+        db4 = _colsum(dP4, True, Bp, Sp, Sp)[:S].contiguous()
+        dP3 = _bf16_empty(Bp, Hp, dev)
+        cs3 = torch.empty((Bp // 128, Hp), dtype=torch.float32, device=dev)
+        L_.rv_linear_dgrad(ptr(dP4), Sp, ptr(W4b), Hp, Bp, Hp, Sp, ptr(h3), Hp, ptr(dP3), Hp, ptr(cs3),
+                           None, 0, 1, st)
+        sl_4, s_4 = _wgrad(dP4, h3, Sp, Hp, Bp)
+        sl_3, s_3 = _wgrad(dP3, zb, Hp, Lp, Bp)
+        dW4 = _slab_sum(sl_4, s_4, Sp, Hp, S, H)
+        dW3 = _slab_sum(sl_3, s_3, Hp, Lp, H, Ld)
+        db3 = _slab_sum(cs3, Bp // 128, 1, Hp, 1, H).view(H)
+        dz = None
+        if ctx.needs_input_grad[0]:
+            t = _tile(Bp, Lp)
+            s_z = _splits_for((Bp // t) * (Lp // t), Hp // 64)
+            dzs = torch.empty((s_z, Bp, Lp), dtype=torch.float32, device=dev)
+            L_.rv_linear_dgrad(ptr(dP3), Hp, ptr(W3b), Lp, Bp, Lp, Hp, None, 0, None, 0, None, ptr(dzs), Lp, s_z, st)
+            dz = _slab_sum(dzs, s_z, Bp, Lp, B, Ld)
+        return dz, dW3, db3, dW4, db4
+
+
+class LossFn(torch.autograd.Function):
+    """loss_function (model.py:38-47) as one fused kernel; gradients are produced in the
+    same pass and only scaled by the upstream gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, recon, x, mu, logvar, kl_beta):
+        _require_cuda(recon, x, mu, logvar)
+        recon, x, mu, logvar = _f32c(recon), _f32c(x), _f32c(mu), _f32c(logvar)
+        B, S = recon.shape
+        Ld = mu.shape[1]
+        dev = recon.device
+        ws = torch.zeros(lib().rv_loss_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        d_recon = torch.empty_like(recon) if need[0] else None
+        d_mu = torch.empty_like(mu) if need[2] else None
+        d_lv = torch.empty_like(logvar) if need[3] else None
+        lib().rv_loss_fused(ptr(recon), ptr(x), ptr(mu), ptr(logvar), B, S, Ld, float(kl_beta), ptr(out),
+                            ptr(d_recon), ptr(d_mu), ptr(d_lv), ptr(ws), stream_ptr())
+        ctx.grads = (d_recon, d_mu, d_lv)
+        ctx.parts = out
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g).view(1)
+        outs = []
+        for t in ctx.grads:
+            if t is None:
+                outs.append(None)
+                continue
+            o = torch.empty_like(t)
+            lib().rv_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), stream_ptr())
+            outs.append(o)
+        return outs[0], None, outs[1], outs[2], None

@@ -1,0 +1,133 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol
+the header declares, the VAE surface matches the reference's (keys, shapes, init,
+pickle path), and the product path never routes through the oracle."""
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from conftest import GOLDEN, REPO  # noqa: E402
+
+
+def _header_symbols():
+    with open(os.path.join(REPO, "include", "rawvae_hip.h")) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from rawaudiovae_kelsey_amd import _lib
+    lib = _lib.lib()
+    names = _header_symbols()
+    assert len(names) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "header declares %s but the library does not export it" % n
+        assert n in _lib.EXPORTED, "%s has no ctypes signature in _lib.py" % n
+    assert set(_lib.EXPORTED) <= set(names), set(_lib.EXPORTED) - set(names)
+    assert lib.rv_version() >= 100
+
+
+def test_pad_dims_and_errors():
+    from rawaudiovae_kelsey_amd import _lib
+    assert _lib.pad_dims(4096, 1024, 2048, 64) == (4096, 1024, 2048, 64)
+    assert _lib.pad_dims(32, 512, 2048, 8) == (128, 512, 2048, 64)
+    assert _lib.pad_dims(2137, 1000, 96, 100) == (2176, 1024, 128, 128)
+    assert _lib.pad_dims(1, 1, 1, 256)[3] == 256
+    with pytest.raises(_lib.RvError):
+        _lib.pad_dims(0, 1, 1, 1)
+    with pytest.raises(_lib.RvError):
+        _lib.pad_dims(1, 1, 1, 257)
+
+
+def test_vae_surface_matches_reference():
+    from rawvae.model import VAE, loss_function  # the reference's import path (train.py:11)
+    m = VAE(1024, 2048, 256)
+    assert (m.segment_length, m.n_units, m.latent_dim) == (1024, 2048, 256)
+    sd = m.state_dict()
+    assert list(sd) == ["fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias",
+                        "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias"]
+    assert sd["fc1.weight"].shape == (2048, 1024) and sd["fc21.weight"].shape == (256, 2048)
+    assert sd["fc3.weight"].shape == (2048, 256) and sd["fc4.weight"].shape == (1024, 2048)
+    assert sum(p.numel() for p in m.parameters()) == 5772800  # default.ini model size
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    for name in ("encode", "reparameterize", "decode", "forward"):
+        assert callable(getattr(m, name))
+    assert callable(loss_function)
+
+
+def test_default_init_is_bitwise_the_references():
+    """Same construction order + nn.Linear default init => same tensors under the same seed
+    (fixture: statistics of the reference's VAE(64,96,8) under torch.manual_seed(0))."""
+    from rawvae.model import VAE
+    with open(os.path.join(GOLDEN, "summary.json")) as f:
+        st = json.load(f)["init_seed0_64_96_8"]
+    torch.manual_seed(0)
+    m = VAE(64, 96, 8)
+    for k, v in m.state_dict().items():
+        a = v.numpy().astype(np.float64)
+        assert a.min() == st[k]["min"] and a.max() == st[k]["max"], k
+        assert abs(a.sum() - st[k]["sum"]) < 1e-9 and list(a.reshape(-1)[:4]) == st[k]["first"], k
+        assert np.abs(a).max() <= st[k]["bound"]
+
+
+def test_pickle_path_and_state_dict_roundtrip():
+    from rawvae.model import VAE
+    m = VAE(64, 96, 8)
+    buf = io.BytesIO()
+    torch.save(m, buf)  # train.py:244 saves the whole module
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert type(m2).__module__ == "rawvae.model" and type(m2).__name__ == "VAE"
+    state = {"epoch": 3, "state_dict": m.state_dict(),
+             "optimizer": torch.optim.Adam(m.parameters(), lr=1e-4).state_dict()}  # train.py:208-212
+    buf = io.BytesIO()
+    torch.save(state, buf)
+    buf.seek(0)
+    st = torch.load(buf, weights_only=False)
+    m3 = VAE(64, 96, 8)
+    m3.load_state_dict(st["state_dict"])
+    for a, b in zip(m.parameters(), m3.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_cpu_tensors_fail_loudly():
+    from rawaudiovae_kelsey_amd._lib import RvError
+    from rawvae.model import VAE, loss_function
+    m = VAE(64, 96, 8)
+    with pytest.raises(RvError):
+        m(torch.zeros(2, 64))
+    with pytest.raises(RvError):
+        loss_function(torch.zeros(2, 64), torch.zeros(2, 64), torch.zeros(2, 8), torch.zeros(2, 8), 1e-4, 64)
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    with pytest.raises(RvError):
+        TrainEngine(64, 96, 8, 16, device="cpu")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from rawaudiovae_kelsey_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librawvae_hip.so")
+    with pytest.raises(_lib.RvError, match="no fallback"):
+        _lib.lib()
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for root in ("rawaudiovae_kelsey_amd", "rawvae"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h")):
+                    with open(os.path.join(dp, fn)) as f:
+                        txt = f.read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt.replace(
+                            "(/root/reference/rawvae/model.py", ""):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

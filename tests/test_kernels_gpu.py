@@ -133,7 +133,7 @@ def test_cast_pad(L):
         ad = dev(a)
         out = torch.full((rp, cp), 9.0, dtype=torch.bfloat16, device="cuda")
         ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
-        L.rv_cast_pad_bf16(ad.data_ptr(), rows, cols, cols, out.data_ptr(), rp, cp, ctr.data_ptr(), sp())
+        L.rv_cast_pad_bf16(ad.data_ptr(), rows, cols, cols, out.data_ptr(), rp, cp, cp, ctr.data_ptr(), sp())
         got = out.float().cpu().numpy()
         np.testing.assert_array_equal(got[:rows, :cols], O.bf16_round(a))
         assert np.all(got[rows:] == 0) and np.all(got[:, cols:] == 0)
