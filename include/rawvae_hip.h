@@ -108,7 +108,7 @@ int rv_reparam_fwd(const float* mulv_slabs, int splits, long Bp, long Lp, long B
 /* Backward of reparameterize + KL:
  *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
  * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums
- * dbh_partial [Bp/64][2Lp] (bias grads of fc21|fc22).  Block 0 also finishes the
+ * dbh_partial [Bp/16][2Lp] (bias grads of fc21|fc22).  One block also finishes the
  * loss: loss_out[0] = sum(mse_partial)/(B S) + kl_beta*(-0.5*sum(kl_partial)/(B L)),
  * loss_out[1] = mse term, loss_out[2] = KL term (pass NULL partials to skip).  When
  * step_counter != NULL and ring > 0, loss_out is a ring of [ring][4] floats and the

@@ -152,8 +152,11 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
 }
 
 // ------------------------------------------------------------------ reparam backward (+ loss finish)
-// Block handles 64 batch rows x all Lp columns: thread -> (l = tid % Lp, r0 = tid / Lp),
-// rows r0, r0 + 256/Lp, ...  Column sums (bias grads of fc21|fc22) are reduced through LDS.
+// Block = RB_ROWS batch rows x all Lp columns; thread -> (l = tid % Lp, r0 = tid / Lp), rows
+// r0, r0 + 256/Lp, ...  Column sums (bias grads of fc21|fc22) are reduced through LDS into
+// one partial row per block.  The last grid block also finishes the loss scalar.
+constexpr int RB_ROWS = 16;
+
 __global__ void __launch_bounds__(256)
 k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, long B, long L,
               long S, const float* __restrict__ mulv, const float* __restrict__ eps, float kl_beta,
@@ -161,15 +164,15 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
               const float* __restrict__ mse_partial, int n_mse,
               const float* __restrict__ kl_partial, int n_kl, float* __restrict__ loss_out,
               const long long* __restrict__ step_counter, int ring) {
-  extern __shared__ float sh[];  // [256/Lp... ] sized 2*256 floats
+  __shared__ float sh[512];
   const int tid = threadIdx.x;
   const long L2p = 2 * Lp;
   const int rows_par = (int)(256 / Lp);  // Lp in {64,128,256}
   const int l = (int)(tid % Lp), r0 = (int)(tid / Lp);
   const float inv_nk = 1.0f / ((float)B * (float)L);
   float cs_mu = 0.f, cs_lv = 0.f;
-  for (int r = r0; r < 64; r += rows_par) {
-    const long b = (long)blockIdx.x * 64 + r;
+  for (int r = r0; r < RB_ROWS; r += rows_par) {
+    const long b = (long)blockIdx.x * RB_ROWS + r;
     float dmu = 0.f, dlv = 0.f;
     if (b < B && l < L) {
       float dz = 0.f;
@@ -197,14 +200,13 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
     dbh_partial[(long)blockIdx.x * L2p + tid] = a;
     dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
   }
-  if (blockIdx.x == 0 && loss_out && mse_partial && kl_partial) {
+  if (blockIdx.x == gridDim.x - 1 && loss_out && mse_partial && kl_partial) {
     __syncthreads();
     float m = 0.f, k = 0.f;
     for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
     for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
-    float* red = sh;
-    m = block_sum_256(m, red);
-    k = block_sum_256(k, red);
+    m = block_sum_256(m, sh);
+    k = block_sum_256(k, sh);
     if (tid == 0) {
       const float mse = m / ((float)B * (float)S);
       const float kld = -0.5f * k * inv_nk;
@@ -376,8 +378,49 @@ struct DescTable {
   int n;
 };
 
-constexpr int ADAM_EPT = 4;  // elements per thread
 
+// Sum of the gradient slabs for 4 consecutive elements of one row.
+template <bool VEC>
+__device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long c, int nvalid) {
+  const float* base = d.grad_slabs + r * d.grad_ld + c;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  if constexpr (VEC) {
+    for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent 16-B loads in flight
+      const float4 a = *reinterpret_cast<const float4*>(base + (long)(s + 0) * d.grad_split_stride);
+      const float4 b = *reinterpret_cast<const float4*>(base + (long)(s + 1) * d.grad_split_stride);
+      const float4 e = *reinterpret_cast<const float4*>(base + (long)(s + 2) * d.grad_split_stride);
+      const float4 f = *reinterpret_cast<const float4*>(base + (long)(s + 3) * d.grad_split_stride);
+      g.x += (a.x + b.x) + (e.x + f.x); g.y += (a.y + b.y) + (e.y + f.y);
+      g.z += (a.z + b.z) + (e.z + f.z); g.w += (a.w + b.w) + (e.w + f.w);
+    }
+    for (; s < d.grad_splits; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (long)s * d.grad_split_stride);
+      g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+    }
+  } else {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (; s + 4 <= d.grad_splits; s += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) {
+          const float* q = base + j + (long)s * d.grad_split_stride;
+          t[j] += (q[0] + q[d.grad_split_stride]) + (q[2 * d.grad_split_stride] + q[3 * d.grad_split_stride]);
+        }
+    }
+    for (; s < d.grad_splits; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) t[j] += base[j + (long)s * d.grad_split_stride];
+    g = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return g;
+}
+
+__host__ __device__ inline bool adam_coop(const rv_param_desc& d) { return d.rows == 1 && d.grad_splits >= 16; }
+
+// Each thread owns 4 consecutive elements of one row (rows are processed in
+// 4-element groups, so a group never straddles a row).
 template <bool UPDATE>
 __global__ void __launch_bounds__(256)
 k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
@@ -386,36 +429,87 @@ k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_are
   int t = 0;
   while (t + 1 < tab.n && (long)blockIdx.x >= tab.blk_start[t + 1]) ++t;
   const rv_param_desc d = tab.d[t];
-  const long n = d.rows * d.cols;
-  const long base = ((long)blockIdx.x - tab.blk_start[t]) * (256 * ADAM_EPT);
-  float bc1 = 1.f, bc2s = 1.f;
+  const long gpr = (d.cols + 3) / 4;  // 4-element groups per row
+  const bool coop = adam_coop(d);     // bias rows with many partials: one WAVE per group
+  const long blk = (long)blockIdx.x - tab.blk_start[t];
+  const long grp = coop ? blk * 4 + (threadIdx.x >> 6) : blk * 256 + threadIdx.x;
+  if (grp >= gpr * d.rows) return;
+  const long r = grp / gpr, c = (grp % gpr) * 4;
+  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
+  const long o = d.offset + r * d.cols + c;
+  const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
+  float4 g;
+  if (coop) {
+    // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
+    const int lane = threadIdx.x & 63;
+    float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = lane; s < d.grad_splits; s += 64) {
+      const float* q = d.grad_slabs + (long)s * d.grad_split_stride + r * d.grad_ld + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) tsum[j] += q[j];
+    }
+    g = make_float4(wave_sum(tsum[0]), wave_sum(tsum[1]), wave_sum(tsum[2]), wave_sum(tsum[3]));
+    if (lane != 0) return;
+  } else {
+    g = vec ? slab_sum4<true>(d, r, c, 4) : slab_sum4<false>(d, r, c, nvalid);
+  }
+  g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
+  float gv[4] = {g.x, g.y, g.z, g.w};
+  if (grad_out) {
+    if (vec) *reinterpret_cast<float4*>(grad_out + o) = g;
+    else
+      for (int j = 0; j < nvalid; ++j) grad_out[o + j] = gv[j];
+  }
   if constexpr (UPDATE) {
     const float tt = (float)(*step_counter);
-    bc1 = 1.0f - powf(0.9f, tt);
-    bc2s = sqrtf(1.0f - powf(0.999f, tt));
-  }
-  const float step_size = lr / bc1;
-#pragma unroll
-  for (int e = 0; e < ADAM_EPT; ++e) {
-    const long i = base + e * 256 + threadIdx.x;
-    if (i >= n) break;
-    const long r = i / d.cols, c = i % d.cols;
-    float g = 0.f;
-    for (int s = 0; s < d.grad_splits; ++s)
-      g += d.grad_slabs[(long)s * d.grad_split_stride + r * d.grad_ld + c];
-    g *= grad_scale;
-    const long o = d.offset + i;
-    if (grad_out) grad_out[o] = g;
-    if constexpr (UPDATE) {
-      const float m = 0.9f * m_arena[o] + 0.1f * g;
-      const float v = 0.999f * v_arena[o] + 0.001f * g * g;
-      m_arena[o] = m;
-      v_arena[o] = v;
-      const float w = param[o] - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
-      param[o] = w;
-      if (d.shadow_bf16) reinterpret_cast<bf16_t*>(d.shadow_bf16)[r * d.shadow_ld + c] = (bf16_t)w;
-      if (d.shadow_f32) d.shadow_f32[r * d.shadow_ld + c] = w;
+    const float bc1 = 1.0f - powf(0.9f, tt);
+    const float bc2s = sqrtf(1.0f - powf(0.999f, tt));
+    const float step_size = lr / bc1;
+    float mv[4], vv[4], wv[4];
+    if (vec) {
+      const float4 m4 = *reinterpret_cast<const float4*>(m_arena + o);
+      const float4 v4 = *reinterpret_cast<const float4*>(v_arena + o);
+      const float4 w4 = *reinterpret_cast<const float4*>(param + o);
+      mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+      vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+      wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+    } else {
+      for (int j = 0; j < 4; ++j) {
+        mv[j] = j < nvalid ? m_arena[o + j] : 0.f;
+        vv[j] = j < nvalid ? v_arena[o + j] : 0.f;
+        wv[j] = j < nvalid ? param[o + j] : 0.f;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
+      vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
+      wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(m_arena + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v_arena + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      *reinterpret_cast<float4*>(param + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    } else {
+      for (int j = 0; j < nvalid; ++j) {
+        m_arena[o + j] = mv[j];
+        v_arena[o + j] = vv[j];
+        param[o + j] = wv[j];
+      }
+    }
+    if (d.shadow_bf16) {
+      bf16_t* sp = reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c;
+      if (nvalid == 4 && (d.shadow_ld & 3) == 0) {
+        bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+        *reinterpret_cast<bf16x4*>(sp) = b4;
+      } else {
+        for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
+      }
+    }
+    if (d.shadow_f32)
+      for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
   }
 }
 
@@ -428,7 +522,10 @@ int build_table(const rv_param_desc* descs, int n, DescTable* tab) {
     RV_REQUIRE(descs[i].rows > 0 && descs[i].cols > 0 && descs[i].grad_slabs && descs[i].grad_splits >= 1,
                RV_ERR_SHAPE, "param desc %d invalid", i);
     tab->blk_start[i] = blk;
-    blk += (descs[i].rows * descs[i].cols + 256 * ADAM_EPT - 1) / (256 * ADAM_EPT);
+    {
+      const long groups = descs[i].rows * ((descs[i].cols + 3) / 4);
+      blk += adam_coop(descs[i]) ? (groups + 3) / 4 : (groups + 255) / 256;
+    }
   }
   tab->blk_start[n] = blk;
   return RV_OK;
@@ -504,9 +601,9 @@ int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, 
                    const float* kl_partial, int n_kl, float* loss_out,
                    const long long* step_counter, int ring, void* stream) {
   RV_REQUIRE(dz_slabs && mulv && eps && dmulv, RV_ERR_NULL, "rv_reparam_bwd: null pointer");
-  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && Bp % 64 == 0 && 256 % Lp == 0, RV_ERR_SHAPE,
+  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && Bp % RB_ROWS == 0 && 256 % Lp == 0, RV_ERR_SHAPE,
              "rv_reparam_bwd: bad extents (Lp must divide 256)");
-  hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / 64)), dim3(256), 512 * sizeof(float),
+  hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / RB_ROWS)), dim3(256), 0,
                      (hipStream_t)stream, dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta,
                      (bf16_t*)dmulv, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
                      step_counter, ring);

@@ -39,6 +39,7 @@ struct GemmArgs {
   const bf16_t* B;
   long lda, ldb;
   int k_tiles;           // 64-deep K tiles per split (grid.z = splits)
+  int tiles_m, tiles_n;  // output tiles (grid.x = tiles_m * tiles_n)
   int M_valid, N_valid;  // unpadded extents (row/col masks in epilogues)
   int relu;              // EPI_BIAS_ACT_BF16: apply ReLU
   float* out_f32;
@@ -113,17 +114,47 @@ __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int k
   }
 }
 
-template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int EPI>
+// Wait until at most `tiles` staged tiles (GL LDS-DMA instructions each) are still in flight.
+template <int GL>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GL) : "memory");
+  else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GL) : "memory");
+  else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// NSTAGE-deep LDS ring, software-pipelined for ONE wave per SIMD (128x128 tiles hold
+// 128 KiB of ring, so a CU runs one block and nothing else hides a stall):
+//   * all NSTAGE slots are staged up front; tiles are retired with a COUNTED vmcnt
+//     (never 0 in steady state) and ONE raw s_barrier per K tile;
+//   * the barrier sits in the MIDDLE of a tile's MFMAs: after the second-half fragments of
+//     tile kt are in registers, wait(tile kt+1 landed) -> barrier -> refill the slot of
+//     tile kt with tile kt+NSTAGE -> read the first-half fragments of tile kt+1 -> second
+//     half of tile kt's MFMAs.  Every ds_read is therefore issued one MFMA half-phase
+//     (16 MFMAs, >=256 cycles) before its consumer, and the DMA refill has NSTAGE-1 tiles
+//     of MFMA time to land.
+// The barrier publishes every wave's share of tile kt+1 and orders the refill after all
+// reads of the vacated slot (each wave drains lgkmcnt before arriving).
+template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
+  constexpr int GL = STAGE / 1024 / 4;  // LDS-DMA instructions per wave per tile
+  static_assert(NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64, "vmcnt is a 6-bit counter");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_n = blockIdx.x, tile_m = blockIdx.y, split = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and
+  // b+8 share an L2), so give each XCD a contiguous run of tile ids: its tiles then share
+  // A row panels through that XCD's L2 instead of every XCD streaming every panel.
+  // Bijective for any grid size; a different placement only changes speed.
+  const int tiles_n = p.tiles_n, nwg = p.tiles_n * p.tiles_m;
+  const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int tid_lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int tile_m = tid_lin / tiles_n, tile_n = tid_lin - tile_m * tiles_n, split = blockIdx.z;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const long k0 = (long)split * p.k_tiles * 64;
 
@@ -138,110 +169,243 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_tile<BM, A_KMAJ>(Ag, p.lda, smem, wave, lane);
-  stage_tile<BN, B_KMAJ>(Bg, p.ldb, smem + A_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int nk = p.k_tiles;
-  for (int kt = 0; kt < nk; ++kt) {
-    lds_char* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      lds_char* nxt = smem + ((kt + 1) & 1) * STAGE;
-      stage_tile<BM, A_KMAJ>(Ag + (kt + 1) * a_step, p.lda, nxt, wave, lane);
-      stage_tile<BN, B_KMAJ>(Bg + (kt + 1) * b_step, p.ldb, nxt + A_BYTES, wave, lane);
+#pragma unroll
+  for (int s = 0; s < NSTAGE; ++s)
+    if (s < nk) {
+      stage_tile<BM, A_KMAJ>(Ag + s * a_step, p.lda, smem + s * STAGE, wave, lane);
+      stage_tile<BN, B_KMAJ>(Bg + s * b_step, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
     }
+  // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
+  wait_tiles_in_flight<GL>(nk - 1 < NSTAGE - 1 ? nk - 1 : NSTAGE - 1);
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MI], bfr[NI];
+  for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(smem, wm * WTM + mi * 16, 0, lane);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        af[mi] = load_frag<BM, A_KMAJ>(cur, wm * WTM + mi * 16, kk, lane);
+  for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(smem + A_BYTES, wn * WTN + ni * 16, 0, lane);
+
+  int slot = 0;  // ring slot of tile kt
+  for (int kt = 0; kt < nk; ++kt) {
+    const lds_char* cur = smem + slot * STAGE;
+    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    // The first MFMA of the tile goes BEFORE the second-half fragment reads: the compiler
+    // waits lgkmcnt(0) at the first use of a0/b0 (loaded across the loop back-edge), which
+    // is free here and would otherwise also drain the reads issued just above it.
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b0[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a1[mi] = load_frag<BM, A_KMAJ>(cur, wm * WTM + mi * 16, 1, lane);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b1[ni] = load_frag<BN, B_KMAJ>(cur + A_BYTES, wn * WTN + ni * 16, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        bfr[ni] = load_frag<BN, B_KMAJ>(cur + A_BYTES, wn * WTN + ni * 16, kk, lane);
+        if (mi + ni > 0)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      // tiles issued so far: 0 .. min(kt+NSTAGE-1, nk-1); newer than kt+1:
+      const int newer = nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading slot `slot`
+      wait_tiles_in_flight<GL>(newer);
+      __builtin_amdgcn_s_barrier();
+      if (kt + NSTAGE < nk) {
+        lds_char* rf = smem + slot * STAGE;
+        stage_tile<BM, A_KMAJ>(Ag + (long)(kt + NSTAGE) * a_step, p.lda, rf, wave, lane);
+        stage_tile<BN, B_KMAJ>(Bg + (long)(kt + NSTAGE) * b_step, p.ldb, rf + A_BYTES, wave, lane);
+      }
+      const lds_char* nxt = smem + nslot * STAGE;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(nxt, wm * WTM + mi * 16, 0, lane);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(nxt + A_BYTES, wn * WTN + ni * 16, 0, lane);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot;
   }
+  __syncthreads();  // every wave is done with the ring before the epilogue reuses LDS
 
   // ------------------------------ epilogue ------------------------------
-  // acc[mi][ni][j] = C[row][col], row = m0 + wm*WTM + mi*16 + (lane>>4)*4 + j,
-  //                              col = n0 + wn*WTN + ni*16 + (lane&15).
-  const long row_base = m0 + wm * WTM + (lane >> 4) * 4;
-  const long col_base = n0 + wn * WTN + (lane & 15);
-  float cs[NI];
+  // acc[mi][ni][j] = C[wave row mi*16 + (lane>>4)*4 + j][wave col ni*16 + (lane&15)].
+  // Each wave transposes its WTM x WTN fp32 tile through its own LDS region so that global
+  // traffic is row-contiguous: a lane then owns 8 consecutive columns of one row (16-B bf16
+  // stores, 32-B fp32 loads/stores; WTN/8 lanes cover a row of the wave tile).  All global
+  // LOADS of the epilogue are issued before its first store (loads and stores share the
+  // in-order vmcnt counter).
+  constexpr int LDW = WTN + 4;       // padded row: fragment writes 2-way conflict at most
+  constexpr int LPRW = WTN / 8;      // lanes per row of the wave tile (8 columns each)
+  constexpr int RPP = 64 / LPRW;     // rows per pass
+  constexpr int IT = WTM / RPP;
+  static_assert(4 * WTM * LDW * 4 <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  float* ep = (float*)smem_generic + wave * (WTM * LDW);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) cs[ni] = 0.f;
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ep[(mi * 16 + (lane >> 4) * 4 + j) * LDW + ni * 16 + (lane & 15)] = acc[mi][ni][j];
+  // same-wave LDS hand-off: the hardware keeps a wave's DS ops in order; only the compiler's
+  // view needs the dependency, which the shared array gives it.
+
+  const int er = lane / LPRW, ec = (lane % LPRW) * 8;  // row within the pass, first of 8 columns
+  const long col = n0 + wn * WTN + ec;
+  const long row0 = m0 + wm * WTM + er;
+  float v[IT][8];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const f32x4 lo = *(const f32x4*)(ep + (it * RPP + er) * LDW + ec);
+    const f32x4 hi = *(const f32x4*)(ep + (it * RPP + er) * LDW + ec + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
+  }
+
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
   float sq = 0.f;
 
+  float bias[8];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  if constexpr (EPI != EPI_MASK_BF16) {
+    if (p.bias && (EPI != EPI_F32 || split == 0)) {  // split-K: slab 0 carries the bias
+      const f32x4 lo = *(const f32x4*)(p.bias + col), hi = *(const f32x4*)(p.bias + col + 4);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const long col = col_base + ni * 16;
-      float b = 0.f;
-      if constexpr (EPI == EPI_F32) {
-        if (p.bias && split == 0) b = p.bias[col];  // slab 0 carries the bias
-      } else if constexpr (EPI != EPI_MASK_BF16) {
-        if (p.bias) b = p.bias[col];
+      for (int e = 0; e < 4; ++e) { bias[e] = lo[e]; bias[4 + e] = hi[e]; }
+    }
+  }
+
+  if constexpr (EPI == EPI_BIAS_ACT_BF16) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = v[it][e] + bias[e];
+        if (p.relu) t = fmaxf(t, 0.f);
+        o[e] = (bf16_t)t;
       }
+      *(bf16x8*)(p.out_bf16 + (row0 + it * RPP) * p.ld_bf16 + col) = o;
+    }
+  } else if constexpr (EPI == EPI_F32) {
+    float* out = p.out_f32 + split * p.split_stride_f32;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long row = row_base + mi * 16 + j;
-        float v = acc[mi][ni][j] + b;
-        if constexpr (EPI == EPI_BIAS_ACT_BF16) {
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.out_bf16[row * p.ld_bf16 + col] = (bf16_t)v;
-        } else if constexpr (EPI == EPI_F32) {
-          p.out_f32[split * p.split_stride_f32 + row * p.ld_f32 + col] = v;
-        } else if constexpr (EPI == EPI_TANH_LOSS) {
-          const float r = fast_tanh(v);
-          const bool valid = row < p.M_valid && col < p.N_valid;
-          if (p.recon && valid) p.recon[row * p.ld_recon + col] = r;
-          if (p.x) {
-            float d = 0.f;
-            if (valid) d = r - p.x[row * p.ld_x + col];
-            sq += d * d;
-            const float g = p.scale * d * (1.f - r * r);
-            cs[ni] += g;
-            p.out_bf16[row * p.ld_bf16 + col] = (bf16_t)g;
+    for (int it = 0; it < IT; ++it) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[e]; hi[e] = v[it][4 + e] + bias[4 + e]; }
+      *(f32x4*)(out + (row0 + it * RPP) * p.ld_f32 + col) = lo;
+      *(f32x4*)(out + (row0 + it * RPP) * p.ld_f32 + col + 4) = hi;
+    }
+  } else if constexpr (EPI == EPI_TANH_LOSS) {
+    // target frames: exact [M_valid, N_valid] fp32.  Rows/columns past the valid extent are
+    // read from a clamped address and masked by select (no per-element branches).
+    const bool vec_x = p.x && (p.ld_x & 3) == 0 && col + 8 <= p.N_valid &&
+                       ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    float xin[IT][8];
+    if (p.x) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const long r = row0 + it * RPP;
+        const long rc = r < p.M_valid ? r : p.M_valid - 1;
+        if (vec_x) {
+          const f32x4 lo = *(const f32x4*)(p.x + rc * p.ld_x + col);
+          const f32x4 hi = *(const f32x4*)(p.x + rc * p.ld_x + col + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xin[it][e] = lo[e]; xin[it][4 + e] = hi[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const long cc = col + e < p.N_valid ? col + e : p.N_valid - 1;
+            xin[it][e] = p.x[rc * p.ld_x + cc];
           }
-        } else {  // EPI_MASK_BF16
-          const float mk = (float)p.mask[row * p.ld_mask + col];
-          v = mk > 0.f ? v : 0.f;
-          cs[ni] += v;
-          p.out_bf16[row * p.ld_bf16 + col] = (bf16_t)v;
         }
       }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const long r = row0 + it * RPP;
+      const bool rv_ = r < p.M_valid;
+      bf16x8 o;
+      float rec[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        rec[e] = fast_tanh(v[it][e] + bias[e]);
+        const bool valid = rv_ && col + e < p.N_valid;
+        float g = 0.f;
+        if (p.x) {
+          const float d = valid ? rec[e] - xin[it][e] : 0.f;
+          sq += d * d;
+          g = p.scale * d * (1.f - rec[e] * rec[e]);
+          cs[e] += g;
+        }
+        o[e] = (bf16_t)g;
+      }
+      if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
+      if (p.recon && rv_) {
+        if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
+          *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
+          *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < p.N_valid) p.recon[r * p.ld_recon + col + e] = rec[e];
+        }
+      }
+    }
+  } else {  // EPI_MASK_BF16
+    bf16x8 mk[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) mk[it] = *(const bf16x8*)(p.mask + (row0 + it * RPP) * p.ld_mask + col);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
+        cs[e] += t;
+        o[e] = (bf16_t)t;
+      }
+      *(bf16x8*)(p.out_bf16 + (row0 + it * RPP) * p.ld_bf16 + col) = o;
     }
   }
 
   if constexpr (EPI == EPI_TANH_LOSS || EPI == EPI_MASK_BF16) {
-    float* red = (float*)smem_generic;  // LDS is free: the loop ended on a barrier
     if (p.colsum) {
+      // lanes with equal (lane % LPRW) own the same 8 columns: butterfly over the row bits
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        float s = cs[ni];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (lane < 16) red[wm * BN + wn * WTN + ni * 16 + lane] = s;
+      for (int e = 0; e < 8; ++e) {
+        float s_ = cs[e];
+#pragma unroll
+        for (int o = LPRW; o < 64; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+        cs[e] = s_;
+      }
+      __syncthreads();  // all waves finished reading their staging regions
+      float* red = (float*)smem_generic;
+      if (lane < LPRW) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wm * BN + wn * WTN + lane * 8 + e] = cs[e];
       }
       __syncthreads();
-      if (tid < BN)
-        p.colsum[(long)tile_m * gridDim.x * BN + n0 + tid] = red[tid] + red[BN + tid];
-      __syncthreads();
+      if (tid < BN) p.colsum[(long)tile_m * tiles_n * BN + n0 + tid] = red[tid] + red[BN + tid];
     }
     if constexpr (EPI == EPI_TANH_LOSS) {
       if (p.blocksum) {
-        const float s = block_sum_256(sq, red);
-        if (tid == 0) p.blocksum[tile_m * gridDim.x + tile_n] = s;
+        __syncthreads();
+        float* red = (float*)smem_generic;
+        const float s_ = block_sum_256(sq, red);
+        if (tid == 0) p.blocksum[tile_m * tiles_n + tile_n] = s_;
       }
     }
   }

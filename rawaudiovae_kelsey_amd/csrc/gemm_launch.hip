@@ -6,17 +6,22 @@ using namespace rv;
 
 namespace {
 
+constexpr int NSTAGE = 4;  // LDS ring depth: 128 KiB for 128x128 tiles (1 block/CU), 64 KiB for 64x64
+
 template <int BM, int BN, bool AK, bool BK, int EPI>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_bf16_kernel<BM, BN, AK, BK, EPI>;
+  constexpr int smem = NSTAGE * (BM + BN) * 128;
+  auto kern = gemm_bf16_kernel<BM, BN, AK, BK, EPI, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
-  dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  GemmArgs g = a;
+  g.tiles_m = (int)(Mp / BM);
+  g.tiles_n = (int)(Np / BN);
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

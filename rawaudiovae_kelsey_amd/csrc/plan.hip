@@ -105,7 +105,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
   p->add("db1p", (long)p->n_mt * Hp * 4);
-  p->add("dbhp", (Bp / 64) * L2p * 4);
+  p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt * Hp * 4);
   p->add("db4p", (long)p->n_mt * Sp * 4);
   p->add("mse_part", (long)p->n_mse * 4);
@@ -140,7 +140,7 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   char* W1b = p->ws("W1b"); char* Whb = p->ws("Whb"); char* W3b = p->ws("W3b"); char* W4b = p->ws("W4b");
   float* b1p = (float*)p->ws("b1p"); float* bhp = (float*)p->ws("bhp");
   float* b3p = (float*)p->ws("b3p"); float* b4p = (float*)p->ws("b4p");
-  const int n_mt = p->n_mt, n_b64 = (int)(Bp / 64);
+  const int n_mt = p->n_mt, n_b64 = (int)(Bp / 16);  // reparam_bwd: one partial row per 16 batch rows
   //                 offset     rows cols slabs        ld   split_stride  splits     bf16 shadow          f32 shadow  ld
   rv_param_desc d[10] = {
       {p->off[0], H, S, dW1, Sp, Hp * Sp, p->s_w1, W1b, nullptr, Sp},
