@@ -43,6 +43,17 @@ const char* rv_last_error(void);
 /* Padded extents used by every bf16 operand: Bp, Sp, Hp multiples of 128, Lp of 64. */
 int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, long* Lp);
 
+/* GEMM tiling decisions, exposed because callers size partial-sum buffers from them.
+ * rv_gemm_pick: recommended split-K count (<= max_splits, power of two) and the block tile
+ * (bm x bn) for a padded Mp x Np x Kp GEMM.  rv_gemm_tile: the tile the library uses when a
+ * GEMM is launched with a given split count; per-row-tile outputs (column-sum partials,
+ * MSE partials) then have Mp/bm row tiles and Np/bn column tiles.
+ * rv_gemm_force_tile: test hook, pins the tile configuration (0: 64x64, 1: 128x128,
+ * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves) wherever it divides the extents; -1 = auto. */
+int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
+int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
+int rv_gemm_force_tile(int tile);
+
 /* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (leading dim ld_dst).
  * Replaces the implicit fp32 operand read of F.linear (model.py:20) for frames and
  * is how weight shadows are (re)built after load_state_dict.  If `step_counter` is
@@ -68,8 +79,8 @@ int rv_linear_fwd_f32(const void* x_bf16, long ldx, const void* w_bf16, long ldw
  *   recon   (optional) exact [B,S] fp32
  *   if x != NULL: mse_partial[block] = sum (recon-x)^2 over the block's valid elements
  *                 dP4 bf16 [Bp,Sp]   = (2/(B*S)) (recon-x)(1-recon^2)   (0 in padding)
- *                 db4_partial [Bp/128][Sp] column sums of dP4 (optional)
- * n_mse_partials = (Bp/128)*(Sp/128). */
+ *                 db4_partial [Bp/bm][Sp] column sums of dP4 (optional)
+ * with (bm, bn) = rv_gemm_tile(Bp, Sp, 1): n_mse_partials = (Bp/bm)*(Sp/bn). */
 int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, long ldw,
                            const float* b4, long Bp, long Sp, long Hp, long B, long S,
                            const float* x, long ldx, float* recon, long ld_recon,
@@ -79,7 +90,8 @@ int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, l
 /* dX = dY W (autograd of F.linear, train.py:191).  dy [Mp,Kp] bf16, w [Kp,Np] bf16
  * ([out,in] layout, consumed as-is through transposing LDS reads).
  *   mask != NULL : dx_bf16 = (mask > 0) ? dX : 0   (ReLU', threshold_backward) and
- *                  colsum_partial [Mp/128][Np] (optional) = column sums = bias grads
+ *                  colsum_partial [Mp/bm][Np] (optional) = column sums = bias grads,
+ *                  bm from rv_gemm_tile(Mp, Np, 1)
  *   mask == NULL : dx_f32 written as `splits` fp32 partial slabs [Mp,Np]. */
 int rv_linear_dgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, long Mp,
                     long Np, long Kp, const void* mask_bf16, long ldmask, void* dx_bf16,

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librawvae_hip.so")
+LIB_PATH = os.environ.get("RV_LIB", os.path.join(_HERE, "librawvae_hip.so"))  # RV_LIB: experiment builds
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 c_u64, c_i64 = C.c_ulonglong, C.c_longlong
@@ -40,6 +40,9 @@ _SIGS = {
     "rv_version": (c_int, []),
     "rv_last_error": (C.c_char_p, []),
     "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
+    "rv_gemm_pick": (c_int, [c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 3),
+    "rv_gemm_tile": (c_int, [c_long, c_long, c_int] + [C.POINTER(c_int)] * 2),
+    "rv_gemm_force_tile": (c_int, [c_int]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
@@ -137,6 +140,20 @@ def stream_ptr(stream=None):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return s.cuda_stream or None
+
+
+def gemm_pick(Mp, Np, Kp, max_splits=16):
+    """(bm, bn, splits) the library recommends for a padded Mp x Np x Kp GEMM."""
+    o = [c_int() for _ in range(3)]
+    lib().rv_gemm_pick(Mp, Np, Kp, max_splits, *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)
+
+
+def gemm_tile(Mp, Np, splits=1):
+    """(bm, bn) block tile used for a GEMM launched with `splits` K splits."""
+    o = [c_int() for _ in range(2)]
+    lib().rv_gemm_tile(Mp, Np, splits, *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)
 
 
 def pad_dims(B, S, H, L):

@@ -60,20 +60,21 @@ struct GemmArgs {
 
 template <int ROWS>
 __device__ __forceinline__ int swz_mn(int k) {
-  if constexpr (ROWS == 128)
-    return (k & 3) | (((k >> 3) & 1) << 2);  // 8 x 32-B chunks per 256-B k-row
+  if constexpr (ROWS >= 128)
+    return (k & 3) | (((k >> 3) & 1) << 2);  // >= 8 x 32-B chunks per k-row (256/512-B rows)
   else
     return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);  // 4 x 32-B chunks per 128-B k-row
 }
 
-// Stage one ROWS x 64 operand tile into LDS.  `g` is the tile origin.
-template <int ROWS, bool KMAJ>
+// Stage one ROWS x 64 operand tile into LDS with NW waves.  `g` is the tile origin.
+template <int ROWS, bool KMAJ, int NW>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, lds_char* lds,
                                            int wave, int lane) {
   constexpr int NINSTR = ROWS * 128 / 1024;  // 1-KiB wave-instructions per tile
+  static_assert(NINSTR % NW == 0, "tile must split evenly over the waves");
 #pragma unroll
-  for (int i = 0; i < NINSTR / 4; ++i) {
-    const int t = wave + 4 * i;
+  for (int i = 0; i < NINSTR / NW; ++i) {
+    const int t = wave + NW * i;
     const bf16_t* src;
     if constexpr (KMAJ) {
       const int r = 8 * t + (lane >> 3);
@@ -81,8 +82,8 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
       src = g + (long)r * ld + c * 8;
     } else {
       constexpr int LPR = ROWS * 2 / 16;  // lanes per k-row
-      const int kr = t * (64 / LPR) + lane / LPR;
-      const int p16 = lane % LPR;
+      const int kr = LPR >= 64 ? t / (LPR / 64) : t * (64 / LPR) + lane / LPR;
+      const int p16 = LPR >= 64 ? (t % (LPR / 64)) * 64 + lane : lane % LPR;
       const int c32 = (p16 >> 1) ^ swz_mn<ROWS>(kr);
       src = g + (long)kr * ld + (c32 * 2 + (p16 & 1)) * 8;
     }
@@ -123,30 +124,45 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// NSTAGE-deep LDS ring, software-pipelined for ONE wave per SIMD (128x128 tiles hold
-// 128 KiB of ring, so a CU runs one block and nothing else hides a stall):
+// Sum over the block's NW waves; result valid in thread 0.  `red` = NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < NW; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+// Block tile BM x BN computed by a WGM x WGN grid of waves (wave tile BM/WGM x BN/WGN).
+//
+// NSTAGE-deep LDS ring, software-pipelined so it also runs at one wave per SIMD:
 //   * all NSTAGE slots are staged up front; tiles are retired with a COUNTED vmcnt
 //     (never 0 in steady state) and ONE raw s_barrier per K tile;
 //   * the barrier sits in the MIDDLE of a tile's MFMAs: after the second-half fragments of
 //     tile kt are in registers, wait(tile kt+1 landed) -> barrier -> refill the slot of
 //     tile kt with tile kt+NSTAGE -> read the first-half fragments of tile kt+1 -> second
 //     half of tile kt's MFMAs.  Every ds_read is therefore issued one MFMA half-phase
-//     (16 MFMAs, >=256 cycles) before its consumer, and the DMA refill has NSTAGE-1 tiles
-//     of MFMA time to land.
+//     before its consumer, and the DMA refill has NSTAGE-1 tiles of MFMA time to land.
 // The barrier publishes every wave's share of tile kt+1 and orders the refill after all
-// reads of the vacated slot (each wave drains lgkmcnt before arriving).
-template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
-__global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
+// reads of the vacated slot (each wave's fragment reads have returned before it arrives).
+template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char* smem = (lds_char*)smem_generic;
+  constexpr int NW = WGM * WGN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 16, NI = WTN / 16;
-  constexpr int GL = STAGE / 1024 / 4;  // LDS-DMA instructions per wave per tile
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
   static_assert(NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64, "vmcnt is a 6-bit counter");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and
   // b+8 share an L2), so give each XCD a contiguous run of tile ids: its tiles then share
   // A row panels through that XCD's L2 instead of every XCD streaming every panel.
@@ -173,8 +189,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < nk) {
-      stage_tile<BM, A_KMAJ>(Ag + s * a_step, p.lda, smem + s * STAGE, wave, lane);
-      stage_tile<BN, B_KMAJ>(Bg + s * b_step, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
+      stage_tile<BM, A_KMAJ, NW>(Ag + s * a_step, p.lda, smem + s * STAGE, wave, lane);
+      stage_tile<BN, B_KMAJ, NW>(Bg + s * b_step, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
     }
   // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
   wait_tiles_in_flight<GL>(nk - 1 < NSTAGE - 1 ? nk - 1 : NSTAGE - 1);
@@ -210,13 +226,18 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
     if (kt + 1 < nk) {
       // tiles issued so far: 0 .. min(kt+NSTAGE-1, nk-1); newer than kt+1:
       const int newer = nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading slot `slot`
+      // This wave must be done reading slot `slot` before the barrier lets anyone refill it:
+      // a register USE of the second-half fragments makes the compiler place the wait here.
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a1[mi]));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(b1[ni]));
       wait_tiles_in_flight<GL>(newer);
       __builtin_amdgcn_s_barrier();
       if (kt + NSTAGE < nk) {
         lds_char* rf = smem + slot * STAGE;
-        stage_tile<BM, A_KMAJ>(Ag + (long)(kt + NSTAGE) * a_step, p.lda, rf, wave, lane);
-        stage_tile<BN, B_KMAJ>(Bg + (long)(kt + NSTAGE) * b_step, p.ldb, rf + A_BYTES, wave, lane);
+        stage_tile<BM, A_KMAJ, NW>(Ag + (long)(kt + NSTAGE) * a_step, p.lda, rf, wave, lane);
+        stage_tile<BN, B_KMAJ, NW>(Bg + (long)(kt + NSTAGE) * b_step, p.ldb, rf + A_BYTES, wave, lane);
       }
       const lds_char* nxt = smem + nslot * STAGE;
 #pragma unroll
@@ -239,14 +260,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
   // acc[mi][ni][j] = C[wave row mi*16 + (lane>>4)*4 + j][wave col ni*16 + (lane&15)].
   // Each wave transposes its WTM x WTN fp32 tile through its own LDS region so that global
   // traffic is row-contiguous: a lane then owns 8 consecutive columns of one row (16-B bf16
-  // stores, 32-B fp32 loads/stores; WTN/8 lanes cover a row of the wave tile).  All global
-  // LOADS of the epilogue are issued before its first store (loads and stores share the
-  // in-order vmcnt counter).
-  constexpr int LDW = WTN + 4;       // padded row: fragment writes 2-way conflict at most
-  constexpr int LPRW = WTN / 8;      // lanes per row of the wave tile (8 columns each)
-  constexpr int RPP = 64 / LPRW;     // rows per pass
-  constexpr int IT = WTM / RPP;
-  static_assert(4 * WTM * LDW * 4 <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
+  // stores, 32-B fp32 loads/stores; WTN/8 lanes cover a row of the wave tile).  Within a
+  // chunk of passes all global LOADS are issued before the first store (loads and stores
+  // share the in-order vmcnt counter).
+  constexpr int LDW = WTN + 4;    // padded row: fragment writes 2-way conflict at most
+  constexpr int LPRW = WTN / 8;   // lanes per row of the wave tile (8 columns each)
+  constexpr int RPP = 64 / LPRW;  // rows per pass
+  constexpr int IT = WTM / RPP;   // passes
+  constexpr int CH = IT < 8 ? IT : 8;  // passes per chunk (bounds live registers)
+  static_assert(NW * WTM * LDW * 4 <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
   float* ep = (float*)smem_generic + wave * (WTM * LDW);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -255,20 +277,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         ep[(mi * 16 + (lane >> 4) * 4 + j) * LDW + ni * 16 + (lane & 15)] = acc[mi][ni][j];
-  // same-wave LDS hand-off: the hardware keeps a wave's DS ops in order; only the compiler's
-  // view needs the dependency, which the shared array gives it.
+  // same-wave LDS hand-off: the hardware keeps a wave's DS ops in order.
 
   const int er = lane / LPRW, ec = (lane % LPRW) * 8;  // row within the pass, first of 8 columns
   const long col = n0 + wn * WTN + ec;
   const long row0 = m0 + wm * WTM + er;
-  float v[IT][8];
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const f32x4 lo = *(const f32x4*)(ep + (it * RPP + er) * LDW + ec);
-    const f32x4 hi = *(const f32x4*)(ep + (it * RPP + er) * LDW + ec + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
-  }
 
   float cs[8];
 #pragma unroll
@@ -285,99 +298,112 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
       for (int e = 0; e < 4; ++e) { bias[e] = lo[e]; bias[4 + e] = hi[e]; }
     }
   }
+  const bool vec_x = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && col + 8 <= p.N_valid &&
+                     ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
-  if constexpr (EPI == EPI_BIAS_ACT_BF16) {
+#pragma unroll 1
+  for (int c0 = 0; c0 < IT; c0 += CH) {
+    float v[CH][8];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      bf16x8 o;
+    for (int it = 0; it < CH; ++it) {
+      const f32x4 lo = *(const f32x4*)(ep + ((c0 + it) * RPP + er) * LDW + ec);
+      const f32x4 hi = *(const f32x4*)(ep + ((c0 + it) * RPP + er) * LDW + ec + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = v[it][e] + bias[e];
-        if (p.relu) t = fmaxf(t, 0.f);
-        o[e] = (bf16_t)t;
+      for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
+    }
+    const long rowc = row0 + (long)c0 * RPP;
+
+    if constexpr (EPI == EPI_BIAS_ACT_BF16) {
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = v[it][e] + bias[e];
+          if (p.relu) t = fmaxf(t, 0.f);
+          o[e] = (bf16_t)t;
+        }
+        *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
       }
-      *(bf16x8*)(p.out_bf16 + (row0 + it * RPP) * p.ld_bf16 + col) = o;
-    }
-  } else if constexpr (EPI == EPI_F32) {
-    float* out = p.out_f32 + split * p.split_stride_f32;
+    } else if constexpr (EPI == EPI_F32) {
+      float* out = p.out_f32 + split * p.split_stride_f32;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      f32x4 lo, hi;
+      for (int it = 0; it < CH; ++it) {
+        f32x4 lo, hi;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[e]; hi[e] = v[it][4 + e] + bias[4 + e]; }
-      *(f32x4*)(out + (row0 + it * RPP) * p.ld_f32 + col) = lo;
-      *(f32x4*)(out + (row0 + it * RPP) * p.ld_f32 + col + 4) = hi;
-    }
-  } else if constexpr (EPI == EPI_TANH_LOSS) {
-    // target frames: exact [M_valid, N_valid] fp32.  Rows/columns past the valid extent are
-    // read from a clamped address and masked by select (no per-element branches).
-    const bool vec_x = p.x && (p.ld_x & 3) == 0 && col + 8 <= p.N_valid &&
-                       ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-    float xin[IT][8];
-    if (p.x) {
+        for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[e]; hi[e] = v[it][4 + e] + bias[4 + e]; }
+        *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col) = lo;
+        *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col + 4) = hi;
+      }
+    } else if constexpr (EPI == EPI_TANH_LOSS) {
+      // target frames: exact [M_valid, N_valid] fp32.  Rows/columns past the valid extent are
+      // read from a clamped address and masked by select (no per-element branches).
+      float xin[CH][8];
+      if (p.x) {
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const long r = row0 + it * RPP;
-        const long rc = r < p.M_valid ? r : p.M_valid - 1;
-        if (vec_x) {
-          const f32x4 lo = *(const f32x4*)(p.x + rc * p.ld_x + col);
-          const f32x4 hi = *(const f32x4*)(p.x + rc * p.ld_x + col + 4);
+        for (int it = 0; it < CH; ++it) {
+          const long r = rowc + it * RPP;
+          const long rc = r < p.M_valid ? r : p.M_valid - 1;
+          if (vec_x) {
+            const f32x4 lo = *(const f32x4*)(p.x + rc * p.ld_x + col);
+            const f32x4 hi = *(const f32x4*)(p.x + rc * p.ld_x + col + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { xin[it][e] = lo[e]; xin[it][4 + e] = hi[e]; }
-        } else {
+            for (int e = 0; e < 4; ++e) { xin[it][e] = lo[e]; xin[it][4 + e] = hi[e]; }
+          } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const long cc = col + e < p.N_valid ? col + e : p.N_valid - 1;
-            xin[it][e] = p.x[rc * p.ld_x + cc];
+            for (int e = 0; e < 8; ++e) {
+              const long cc = col + e < p.N_valid ? col + e : p.N_valid - 1;
+              xin[it][e] = p.x[rc * p.ld_x + cc];
+            }
           }
         }
       }
-    }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const long r = row0 + it * RPP;
-      const bool rv_ = r < p.M_valid;
-      bf16x8 o;
-      float rec[8];
+      for (int it = 0; it < CH; ++it) {
+        const long r = rowc + it * RPP;
+        const bool rv_ = r < p.M_valid;
+        bf16x8 o;
+        float rec[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        rec[e] = fast_tanh(v[it][e] + bias[e]);
-        const bool valid = rv_ && col + e < p.N_valid;
-        float g = 0.f;
-        if (p.x) {
-          const float d = valid ? rec[e] - xin[it][e] : 0.f;
-          sq += d * d;
-          g = p.scale * d * (1.f - rec[e] * rec[e]);
-          cs[e] += g;
+        for (int e = 0; e < 8; ++e) {
+          rec[e] = fast_tanh(v[it][e] + bias[e]);
+          const bool valid = rv_ && col + e < p.N_valid;
+          float g = 0.f;
+          if (p.x) {
+            const float d = valid ? rec[e] - xin[it][e] : 0.f;
+            sq += d * d;
+            g = p.scale * d * (1.f - rec[e] * rec[e]);
+            cs[e] += g;
+          }
+          o[e] = (bf16_t)g;
         }
-        o[e] = (bf16_t)g;
-      }
-      if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
-      if (p.recon && rv_) {
-        if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
-          *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
-          *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
-        } else {
+        if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
+        if (p.recon && rv_) {
+          if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
+            *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
+            *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
+          } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (col + e < p.N_valid) p.recon[r * p.ld_recon + col + e] = rec[e];
+            for (int e = 0; e < 8; ++e)
+              if (col + e < p.N_valid) p.recon[r * p.ld_recon + col + e] = rec[e];
+          }
         }
       }
-    }
-  } else {  // EPI_MASK_BF16
-    bf16x8 mk[IT];
+    } else {  // EPI_MASK_BF16
+      bf16x8 mk[CH];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) mk[it] = *(const bf16x8*)(p.mask + (row0 + it * RPP) * p.ld_mask + col);
+      for (int it = 0; it < CH; ++it) mk[it] = *(const bf16x8*)(p.mask + (rowc + it * RPP) * p.ld_mask + col);
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      bf16x8 o;
+      for (int it = 0; it < CH; ++it) {
+        bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float t = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
-        cs[e] += t;
-        o[e] = (bf16_t)t;
+        for (int e = 0; e < 8; ++e) {
+          const float t = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
+          cs[e] += t;
+          o[e] = (bf16_t)t;
+        }
+        *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
       }
-      *(bf16x8*)(p.out_bf16 + (row0 + it * RPP) * p.ld_bf16 + col) = o;
     }
   }
 
@@ -398,13 +424,18 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs p) {
         for (int e = 0; e < 8; ++e) red[wm * BN + wn * WTN + lane * 8 + e] = cs[e];
       }
       __syncthreads();
-      if (tid < BN) p.colsum[(long)tile_m * tiles_n * BN + n0 + tid] = red[tid] + red[BN + tid];
+      if (tid < BN) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) s_ += red[w * BN + tid];
+        p.colsum[(long)tile_m * tiles_n * BN + n0 + tid] = s_;
+      }
     }
     if constexpr (EPI == EPI_TANH_LOSS) {
       if (p.blocksum) {
         __syncthreads();
         float* red = (float*)smem_generic;
-        const float s_ = block_sum_256(sq, red);
+        const float s_ = block_sum<NW>(sq, red);
         if (tid == 0) p.blocksum[tile_m * tiles_n + tile_n] = s_;
       }
     }

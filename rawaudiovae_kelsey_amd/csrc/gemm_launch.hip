@@ -6,12 +6,17 @@ using namespace rv;
 
 namespace {
 
-constexpr int NSTAGE = 4;  // LDS ring depth: 128 KiB for 128x128 tiles (1 block/CU), 64 KiB for 64x64
+// Tile configurations (block tile, wave grid, LDS ring depth):
+//   0:  64x64  2x2 waves of 32x32, 4 stages ( 64 KiB)  latent-sized extents
+//   1: 128x128 2x2 waves of 64x64, 4 stages (128 KiB)
+//   2: 256x128 4x2 waves of 64x64, 3 stages (144 KiB)  two waves per SIMD
+//   3: 256x128 2x2 waves of 128x64, 3 stages (144 KiB) one wave per SIMD, half the LDS reads
+int g_force_tile = -1;
 
-template <int BM, int BN, bool AK, bool BK, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   constexpr int smem = NSTAGE * (BM + BN) * 128;
-  auto kern = gemm_bf16_kernel<BM, BN, AK, BK, EPI, NSTAGE>;
+  auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -21,26 +26,100 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), smem, st, g);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
 
-// Tile choice: 128x128 when both extents allow it, 64x64 otherwise (latent-sized N).
+int splits_for(long tiles, long k_tiles, int max_splits) {
+  int s = 1;
+  while (tiles * s < 256 && 2 * s <= max_splits && k_tiles % (2 * s) == 0 && k_tiles / (2 * s) >= 2) s *= 2;
+  return s;
+}
+
+bool tile_fits(int tile, long Mp, long Np) {
+  switch (tile) {
+    case 0: return Mp % 64 == 0 && Np % 64 == 0;
+    case 1: return Mp % 128 == 0 && Np % 128 == 0;
+    case 2: case 3: return Mp % 256 == 0 && Np % 128 == 0;
+    default: return false;
+  }
+}
+
+void tile_dims(int tile, int* bm, int* bn) {
+  *bm = tile == 0 ? 64 : tile == 1 ? 128 : 256;
+  *bn = tile == 0 ? 64 : 128;
+}
+
 template <bool AK, bool BK, int EPI>
-int launch_auto(const GemmArgs& a, long Mp, long Np, long Kp, int splits, hipStream_t st) {
-  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0, RV_ERR_SHAPE, "gemm: empty extent");
-  RV_REQUIRE(Mp % 64 == 0 && Np % 64 == 0 && Kp % 64 == 0, RV_ERR_SHAPE,
-             "gemm: extents must be multiples of 64 (got %ld %ld %ld)", Mp, Np, Kp);
+int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int splits, hipStream_t st) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Kp % 64 == 0, RV_ERR_SHAPE, "gemm: bad extents %ld %ld %ld", Mp, Np, Kp);
+  RV_REQUIRE(tile_fits(tile, Mp, Np), RV_ERR_SHAPE, "gemm: tile %d does not divide %ld x %ld", tile, Mp, Np);
   RV_REQUIRE(splits >= 1 && (Kp / 64) % splits == 0, RV_ERR_SHAPE,
              "gemm: K tiles %ld not divisible by splits %d", Kp / 64, splits);
   RV_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0, RV_ERR_SHAPE, "gemm: leading dims must be multiples of 8");
   RV_REQUIRE((((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0, RV_ERR_SHAPE, "gemm: operands must be 16-byte aligned");
-  if (Mp % 128 == 0 && Np % 128 == 0) return launch<128, 128, AK, BK, EPI>(a, Mp, Np, splits, st);
-  return launch<64, 64, AK, BK, EPI>(a, Mp, Np, splits, st);
+  switch (tile) {
+    case 0: return launch<64, 64, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 1: return launch<128, 128, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 2: return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
+    default: return launch<256, 128, 2, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
+  }
 }
 
 }  // namespace
+
+// Tile used for a GEMM launched with a given split count (deterministic: callers size their
+// partial-sum buffers from it).
+static int choose_tile(long Mp, long Np, int splits) {
+  if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) return g_force_tile;
+  if (tile_fits(2, Mp, Np) && (Mp / 256) * (Np / 128) * splits >= 192) return 2;
+  return tile_fits(1, Mp, Np) ? 1 : 0;
+}
+
+extern "C" int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Mp % 64 == 0 && Np % 64 == 0 && splits >= 1, RV_ERR_SHAPE,
+             "rv_gemm_tile: extents must be positive multiples of 64 (got %ld %ld)", Mp, Np);
+  int m, n;
+  tile_dims(choose_tile(Mp, Np, splits), &m, &n);
+  if (bm) *bm = m;
+  if (bn) *bn = n;
+  return RV_OK;
+}
+
+extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 64 == 0 && Np % 64 == 0 && Kp % 64 == 0, RV_ERR_SHAPE,
+             "rv_gemm_pick: extents must be positive multiples of 64 (got %ld %ld %ld)", Mp, Np, Kp);
+  if (max_splits < 1) max_splits = 1;
+  const long kt = Kp / 64;
+  int t = -1;
+  if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) {
+    t = g_force_tile;
+  } else if (tile_fits(2, Mp, Np)) {
+    const long tl = (Mp / 256) * (Np / 128);
+    if (tl * splits_for(tl, kt, max_splits) >= 192) t = 2;
+  }
+  if (t < 0) t = tile_fits(1, Mp, Np) ? 1 : 0;
+  int m, n;
+  tile_dims(t, &m, &n);
+  const int s = splits_for((Mp / m) * (Np / n), kt, max_splits);
+  if (bm) *bm = m;
+  if (bn) *bn = n;
+  if (splits) *splits = s;
+  return RV_OK;
+}
+
+extern "C" int rv_gemm_force_tile(int tile) {
+  g_force_tile = tile;
+  return RV_OK;
+}
+
+template <bool AK, bool BK, int EPI>
+static int launch_auto(const GemmArgs& a, long Mp, long Np, long Kp, int splits, hipStream_t st) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Mp % 64 == 0 && Np % 64 == 0 && splits >= 1, RV_ERR_SHAPE,
+             "gemm: extents must be positive multiples of 64 (got %ld %ld)", Mp, Np);
+  return launch_tile<AK, BK, EPI>(choose_tile(Mp, Np, splits), a, Mp, Np, Kp, splits, st);
+}
 
 extern "C" {
 
@@ -72,7 +151,6 @@ int rv_decode_out_loss_fwd(const void* h3, long ldh, const void* w4, long ldw, c
   RV_REQUIRE(h3 && w4, RV_ERR_NULL, "rv_decode_out_loss_fwd: null operand");
   RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_decode_out_loss_fwd: B,S exceed padded extents");
   RV_REQUIRE(!x || dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd: x given without dP4 output");
-  RV_REQUIRE(Bp % 128 == 0 && Sp % 128 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd: Bp,Sp must be multiples of 128");
   GemmArgs a{};
   a.A = (const bf16_t*)h3; a.lda = ldh; a.B = (const bf16_t*)w4; a.ldb = ldw;
   a.k_tiles = (int)(Hp / 64); a.M_valid = (int)B; a.N_valid = (int)S;
@@ -91,8 +169,6 @@ int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp,
   a.M_valid = (int)Mp; a.N_valid = (int)Np;
   if (mask) {
     RV_REQUIRE(dx, RV_ERR_NULL, "rv_linear_dgrad: mask given without bf16 output");
-    RV_REQUIRE(!colsum || (Mp % 128 == 0 && Np % 128 == 0), RV_ERR_SHAPE,
-               "rv_linear_dgrad: colsum needs 128-multiples");
     a.k_tiles = (int)(Kp / 64); a.mask = (const bf16_t*)mask; a.ld_mask = ldmask;
     a.out_bf16 = (bf16_t*)dx; a.ld_bf16 = lddx; a.colsum = colsum;
     return launch_auto<true, false, EPI_MASK_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);

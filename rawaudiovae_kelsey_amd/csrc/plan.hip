@@ -20,10 +20,16 @@ struct Buf {
 
 long align256(long b) { return (b + 255) / 256 * 256; }
 
-int pick_splits(long tiles, long k_tiles) {
+int splits_of(long Mp, long Np, long Kp) {
   int s = 1;
-  while (tiles * s < 256 && s < 16 && k_tiles % (2 * s) == 0 && k_tiles / (2 * s) >= 2) s *= 2;
+  rv_gemm_pick(Mp, Np, Kp, 16, nullptr, nullptr, &s);
   return s;
+}
+
+int row_tiles(long Mp, long Np) {
+  int bm = 128;
+  rv_gemm_tile(Mp, Np, 1, &bm, nullptr);
+  return (int)(Mp / bm);
 }
 
 }  // namespace
@@ -31,7 +37,7 @@ int pick_splits(long tiles, long k_tiles) {
 struct rv_plan {
   long B, S, H, L, Bp, Sp, Hp, Lp, L2p;
   int s_heads, s_dz, s_w4, s_w3, s_wh, s_w1;  // split-K factors
-  int n_mse, n_kl, n_mt;                      // partial counts; n_mt = Bp/128 row tiles
+  int n_mse, n_kl, n_mt4, n_mt3;              // partial counts (row tiles of the producing GEMMs)
   long off[10];                               // element offsets of the 10 params in the flat arenas
   long n_params;
   std::vector<Buf> bufs;
@@ -65,15 +71,20 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   if (rc) { delete p; return rc; }
   p->L2p = 2 * p->Lp;
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
-  const bool lat128 = (Lp % 128 == 0);
-  p->s_heads = pick_splits((Bp / 128) * (L2p / 128), Hp / 64);
-  p->s_dz = lat128 ? pick_splits((Bp / 128) * (Lp / 128), Hp / 64) : pick_splits((Bp / 64) * (Lp / 64), Hp / 64);
-  p->s_w4 = pick_splits((Sp / 128) * (Hp / 128), Bp / 64);
-  p->s_w3 = lat128 ? pick_splits((Hp / 128) * (Lp / 128), Bp / 64) : pick_splits((Hp / 64) * (Lp / 64), Bp / 64);
-  p->s_wh = pick_splits((L2p / 128) * (Hp / 128), Bp / 64);
-  p->s_w1 = pick_splits((Hp / 128) * (Sp / 128), Bp / 64);
-  p->n_mt = (int)(Bp / 128);
-  p->n_mse = (int)((Bp / 128) * (Sp / 128));
+  p->s_heads = splits_of(Bp, L2p, Hp);
+  p->s_dz = splits_of(Bp, Lp, Hp);
+  p->s_w4 = splits_of(Sp, Hp, Bp);
+  p->s_w3 = splits_of(Hp, Lp, Bp);
+  p->s_wh = splits_of(L2p, Hp, Bp);
+  p->s_w1 = splits_of(Hp, Sp, Bp);
+  // per-row-tile partial counts follow the tile each producing GEMM will use
+  p->n_mt4 = row_tiles(Bp, Sp);   // fc4 fwd: dP4 column sums (db4) and MSE partials
+  p->n_mt3 = row_tiles(Bp, Hp);   // fc4 dgrad (db3) and heads dgrad (db1): both Bp x Hp
+  {
+    int bm = 128, bn = 128;
+    rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
+    p->n_mse = (int)((Bp / bm) * (Sp / bn));
+  }
   p->n_kl = (int)(Bp * Lp / 256);
   const long sizes[10] = {H * S, H, L * H, L, L * H, L, H * L, H, S * H, S};
   long o = 0;
@@ -104,10 +115,10 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dWh", (long)p->s_wh * L2p * Hp * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
-  p->add("db1p", (long)p->n_mt * Hp * 4);
+  p->add("db1p", (long)p->n_mt3 * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
-  p->add("db3p", (long)p->n_mt * Hp * 4);
-  p->add("db4p", (long)p->n_mt * Sp * 4);
+  p->add("db3p", (long)p->n_mt3 * Hp * 4);
+  p->add("db4p", (long)p->n_mt4 * Sp * 4);
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
   p->bound = false;
@@ -140,19 +151,19 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   char* W1b = p->ws("W1b"); char* Whb = p->ws("Whb"); char* W3b = p->ws("W3b"); char* W4b = p->ws("W4b");
   float* b1p = (float*)p->ws("b1p"); float* bhp = (float*)p->ws("bhp");
   float* b3p = (float*)p->ws("b3p"); float* b4p = (float*)p->ws("b4p");
-  const int n_mt = p->n_mt, n_b64 = (int)(Bp / 16);  // reparam_bwd: one partial row per 16 batch rows
+  const int n_mt3 = p->n_mt3, n_mt4 = p->n_mt4, n_b64 = (int)(Bp / 16);  // reparam_bwd: one partial row per 16 batch rows
   //                 offset     rows cols slabs        ld   split_stride  splits     bf16 shadow          f32 shadow  ld
   rv_param_desc d[10] = {
       {p->off[0], H, S, dW1, Sp, Hp * Sp, p->s_w1, W1b, nullptr, Sp},
-      {p->off[1], 1, H, db1, Hp, Hp, n_mt, nullptr, b1p, Hp},
+      {p->off[1], 1, H, db1, Hp, Hp, n_mt3, nullptr, b1p, Hp},
       {p->off[2], L, H, dWh, Hp, L2p * Hp, p->s_wh, Whb, nullptr, Hp},
       {p->off[3], 1, L, dbh, L2p, L2p, n_b64, nullptr, bhp, L2p},
       {p->off[4], L, H, dWh + Lp * Hp, Hp, L2p * Hp, p->s_wh, Whb + Lp * Hp * 2, nullptr, Hp},
       {p->off[5], 1, L, dbh + Lp, L2p, L2p, n_b64, nullptr, bhp + Lp, L2p},
       {p->off[6], H, L, dW3, Lp, Hp * Lp, p->s_w3, W3b, nullptr, Lp},
-      {p->off[7], 1, H, db3, Hp, Hp, n_mt, nullptr, b3p, Hp},
+      {p->off[7], 1, H, db3, Hp, Hp, n_mt3, nullptr, b3p, Hp},
       {p->off[8], S, H, dW4, Hp, Sp * Hp, p->s_w4, W4b, nullptr, Hp},
-      {p->off[9], 1, S, db4, Sp, Sp, n_mt, nullptr, b4p, Sp},
+      {p->off[9], 1, S, db4, Sp, Sp, n_mt4, nullptr, b4p, Sp},
   };
   for (int i = 0; i < 10; ++i) {
     p->d_slab[i] = d[i];

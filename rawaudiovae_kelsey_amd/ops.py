@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_RELU, ParamDesc, lib, pad_dims, ptr, stream_ptr
+from ._lib import ACT_RELU, ParamDesc, gemm_pick, gemm_tile, lib, pad_dims, ptr, stream_ptr
 
 
 def _require_cuda(*tensors):
@@ -59,21 +59,9 @@ def _slab_sum(slabs, splits, rows_p, ld, rows, cols, row0=0, col0=0):
     return out
 
 
-def _splits_for(tiles, k_tiles):
-    s = 1
-    while tiles * s < 256 and s < 16 and k_tiles % (2 * s) == 0 and k_tiles // (2 * s) >= 2:
-        s *= 2
-    return s
-
-
-def _tile(m, n):
-    return 128 if (m % 128 == 0 and n % 128 == 0) else 64
-
-
 def _wgrad(dy, x, Mp, Np, Kp):
     """dW slabs for dy [Kp, Mp], x [Kp, Np] (both bf16 padded). Returns (slabs, splits)."""
-    t = _tile(Mp, Np)
-    splits = _splits_for((Mp // t) * (Np // t), Kp // 64)
+    splits = gemm_pick(Mp, Np, Kp)[2]
     slabs = torch.empty((splits, Mp, Np), dtype=torch.float32, device=dy.device)
     lib().rv_linear_wgrad(ptr(dy), Mp, ptr(x), Np, Mp, Np, Kp, splits, ptr(slabs), Np, stream_ptr())
     return slabs, splits
@@ -128,13 +116,14 @@ class EncodeFn(torch.autograd.Function):
         cast_pad(dmu, Bp, Lp, out=dmulv, ld_dst=2 * Lp)
         cast_pad(dlv, Bp, Lp, out=dmulv[:, Lp:], ld_dst=2 * Lp)
         dP1 = _bf16_empty(Bp, Hp, xb.device)
-        cs1 = torch.empty((Bp // 128, Hp), dtype=torch.float32, device=xb.device)
+        n1 = Bp // gemm_tile(Bp, Hp)[0]
+        cs1 = torch.empty((n1, Hp), dtype=torch.float32, device=xb.device)
         L_.rv_linear_dgrad(ptr(dmulv), 2 * Lp, ptr(Whb), Hp, Bp, Hp, 2 * Lp, ptr(h1), Hp, ptr(dP1), Hp,
                            ptr(cs1), None, 0, 1, st)
         sl_h, s_h = _wgrad(dmulv, h1, 2 * Lp, Hp, Bp)
         sl_1, s_1 = _wgrad(dP1, xb, Hp, Sp, Bp)
         dW1 = _slab_sum(sl_1, s_1, Hp, Sp, H, S)
-        db1 = _slab_sum(cs1, Bp // 128, 1, Hp, 1, H).view(H)
+        db1 = _slab_sum(cs1, n1, 1, Hp, 1, H).view(H)
         dW21 = _slab_sum(sl_h, s_h, 2 * Lp, Hp, Ld, H)
         dW22 = _slab_sum(sl_h, s_h, 2 * Lp, Hp, Ld, H, row0=Lp)
         db21 = _colsum(dmu, False, B, Ld, Ld)
@@ -205,18 +194,18 @@ class DecodeFn(torch.autograd.Function):
         L_.rv_tanh_bwd_pack(ptr(d_recon), ptr(recon), B, S, ptr(dP4), Bp, Sp, st)
         db4 = _colsum(dP4, True, Bp, Sp, Sp)[:S].contiguous()
         dP3 = _bf16_empty(Bp, Hp, dev)
-        cs3 = torch.empty((Bp // 128, Hp), dtype=torch.float32, device=dev)
+        n3 = Bp // gemm_tile(Bp, Hp)[0]
+        cs3 = torch.empty((n3, Hp), dtype=torch.float32, device=dev)
         L_.rv_linear_dgrad(ptr(dP4), Sp, ptr(W4b), Hp, Bp, Hp, Sp, ptr(h3), Hp, ptr(dP3), Hp, ptr(cs3),
                            None, 0, 1, st)
         sl_4, s_4 = _wgrad(dP4, h3, Sp, Hp, Bp)
         sl_3, s_3 = _wgrad(dP3, zb, Hp, Lp, Bp)
         dW4 = _slab_sum(sl_4, s_4, Sp, Hp, S, H)
         dW3 = _slab_sum(sl_3, s_3, Hp, Lp, H, Ld)
-        db3 = _slab_sum(cs3, Bp // 128, 1, Hp, 1, H).view(H)
+        db3 = _slab_sum(cs3, n3, 1, Hp, 1, H).view(H)
         dz = None
         if ctx.needs_input_grad[0]:
-            t = _tile(Bp, Lp)
-            s_z = _splits_for((Bp // t) * (Lp // t), Hp // 64)
+            s_z = gemm_pick(Bp, Lp, Hp)[2]
             dzs = torch.empty((s_z, Bp, Lp), dtype=torch.float32, device=dev)
             L_.rv_linear_dgrad(ptr(dP3), Hp, ptr(W3b), Lp, Bp, Lp, Hp, None, 0, None, 0, None, ptr(dzs), Lp, s_z, st)
             dz = _slab_sum(dzs, s_z, Bp, Lp, B, Ld)

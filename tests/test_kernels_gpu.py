@@ -80,6 +80,74 @@ def test_linear_dgrad_f32(L, M, N, K, splits):
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
 
+@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "t64", "t128", "t256w8", "t256w4"])
+def tile(request, L):
+    """Pin each block-tile configuration in turn (256-row tiles only apply when M % 256 == 0)."""
+    L.rv_gemm_force_tile(request.param)
+    yield request.param
+    L.rv_gemm_force_tile(-1)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 128, 256, 1), (512, 256, 192, 1), (256, 256, 512, 4)])
+def test_all_tiles_all_layouts(L, tile, M, N, K, splits):
+    """NT / NN / TN contractions under every tile configuration."""
+    rng = np.random.default_rng(21)
+    a_km, b_km = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K))
+    b_mn, a_mn = rand_bf16(rng, (K, N)), rand_bf16(rng, (K, M))
+    out = torch.empty((splits, M, N), dtype=torch.float32, device="cuda")
+    A, Bk, Bm, Am = (dev(t, torch.bfloat16) for t in (a_km, b_km, b_mn, a_mn))
+    L.rv_linear_fwd_f32(A.data_ptr(), K, Bk.data_ptr(), K, None, M, N, K, splits, out.data_ptr(), N, sp())
+    ref = a_km.astype(np.float64) @ b_km.astype(np.float64).T
+    np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    L.rv_linear_dgrad(A.data_ptr(), K, Bm.data_ptr(), N, M, N, K, None, 0, None, 0, None, out.data_ptr(), N, splits, sp())
+    ref = a_km.astype(np.float64) @ b_mn.astype(np.float64)
+    np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    L.rv_linear_wgrad(Am.data_ptr(), M, Bm.data_ptr(), N, M, N, K, splits, out.data_ptr(), N, sp())
+    ref = a_mn.astype(np.float64).T @ b_mn.astype(np.float64)
+    np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+def test_all_tiles_fused_epilogues(L, tile):
+    """bias+ReLU, mask+colsum and tanh+loss epilogues under every tile configuration."""
+    from rawaudiovae_kelsey_amd._lib import gemm_tile
+    M, N, K = 512, 256, 128
+    rng = np.random.default_rng(22)
+    a, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (N, K), 0.1)
+    wt = rand_bf16(rng, (K, N), 0.1)
+    b = rng.standard_normal(N).astype(np.float32)
+    A, W, WT, Bd = dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(wt, torch.bfloat16), dev(b)
+    bm, bn = gemm_tile(M, N, 1)
+    y = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    L.rv_linear_fwd(A.data_ptr(), K, W.data_ptr(), K, Bd.data_ptr(), M, N, K, 1, y.data_ptr(), N, sp())
+    ref = np.maximum(a.astype(np.float64) @ w.astype(np.float64).T + b, 0)
+    assert np.abs(y.float().cpu().numpy() - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    h = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
+    Hd = dev(h, torch.bfloat16)
+    cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad(A.data_ptr(), K, WT.data_ptr(), N, M, N, K, Hd.data_ptr(), N, y.data_ptr(), N,
+                      cs.data_ptr(), None, 0, 1, sp())
+    ref = (a.astype(np.float64) @ wt.astype(np.float64)) * (h > 0)
+    assert np.abs(y.float().cpu().numpy() - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), ref.sum(0), rtol=1e-4, atol=1e-4 * np.abs(ref.sum(0)).max())
+    Bv, Sv = M - 37, N - 5   # ragged valid extents inside the padded tile grid
+    x = rng.uniform(-1, 1, (Bv, Sv)).astype(np.float32)
+    Xd = dev(x)
+    recon = torch.zeros((Bv, Sv), device="cuda")
+    dp4 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    msep = torch.zeros((M // bm) * (N // bn), device="cuda")
+    cs.zero_()
+    L.rv_decode_out_loss_fwd(A.data_ptr(), K, W.data_ptr(), K, Bd.data_ptr(), M, N, K, Bv, Sv, Xd.data_ptr(), Sv,
+                             recon.data_ptr(), Sv, dp4.data_ptr(), N, msep.data_ptr(), cs.data_ptr(), sp())
+    rec = np.tanh(a.astype(np.float64) @ w.astype(np.float64).T + b)[:Bv, :Sv]
+    np.testing.assert_allclose(recon.cpu().numpy(), rec, atol=2e-6)
+    assert abs(msep.sum().item() - ((rec - x) ** 2).sum()) <= 1e-5 * ((rec - x) ** 2).sum()
+    g = np.zeros((M, N))
+    g[:Bv, :Sv] = 2.0 / (Bv * Sv) * (rec - x) * (1 - rec ** 2)
+    got = dp4.float().cpu().numpy()
+    assert np.abs(got - g).max() <= 2 ** -7 * np.abs(g).max()
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), g.sum(0), rtol=2e-3, atol=2e-3 * np.abs(g.sum(0)).max())
+
+
 def test_linear_dgrad_mask_colsum(L):
     M, N, K = 256, 256, 128
     rng = np.random.default_rng(12)
@@ -87,7 +155,8 @@ def test_linear_dgrad_mask_colsum(L):
     h = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
     dyd, wd, hd = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(h, torch.bfloat16)
     out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
-    cs = torch.zeros((M // 128, N), dtype=torch.float32, device="cuda")
+    from rawaudiovae_kelsey_amd._lib import gemm_tile
+    cs = torch.zeros((M // gemm_tile(M, N, 1)[0], N), dtype=torch.float32, device="cuda")
     L.rv_linear_dgrad(dyd.data_ptr(), K, wd.data_ptr(), N, M, N, K, hd.data_ptr(), N, out.data_ptr(), N,
                       cs.data_ptr(), None, 0, 1, sp())
     ref = (dy.astype(np.float64) @ w.astype(np.float64)) * (h > 0)

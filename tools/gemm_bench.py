@@ -13,11 +13,20 @@ from rawaudiovae_kelsey_amd._lib import lib  # noqa: E402
 B, S, H, L = 4096, 1024, 2048, 64
 L2 = 2 * L
 Lb = lib()
+if os.environ.get('RV_TILE'):
+    Lb.rv_gemm_force_tile(int(os.environ['RV_TILE']))
 st = torch.cuda.current_stream().cuda_stream or None
 
 
-def rnd(*shape):
-    return torch.randn(*shape, device="cuda").to(torch.bfloat16)
+PAD = int(os.environ.get("LDPAD", "0"))  # extra elements per row (breaks power-of-two strides)
+
+
+def rnd(r, c):
+    t = torch.randn(r, c + PAD, device="cuda").to(torch.bfloat16)
+    return t
+
+
+LD = lambda n: n + PAD
 
 
 x, h, dp4, z, dmulv = rnd(B, S), rnd(B, H), rnd(B, S), rnd(B, L), rnd(B, L2)
@@ -32,25 +41,27 @@ SPL = {k: int(os.environ.get("SPL_" + k, v)) for k, v in dict(heads=8, dz=4, w4=
 
 P = lambda t: t.data_ptr()
 cases = {
-    "fc1 fwd   4096x2048x1024 NT": (2 * B * H * S, lambda: Lb.rv_linear_fwd(P(x), S, P(W1), S, P(bH), B, H, S, 1, P(outH), H, st)),
+    "fc1 fwd   4096x2048x1024 NT": (2 * B * H * S, lambda: Lb.rv_linear_fwd(P(x), LD(S), P(W1), LD(S), P(bH), B, H, S, 1, P(outH), H, st)),
     "heads fwd 4096x128x2048  NT": (2 * B * L2 * H, lambda: Lb.rv_linear_fwd_f32(P(h), H, P(Wh), H, P(bL2), B, L2, H, SPL["heads"], P(f32buf), L2, st)),
     "fc3 fwd   4096x2048x64   NT": (2 * B * H * L, lambda: Lb.rv_linear_fwd(P(z), L, P(W3), L, P(bH), B, H, L, 1, P(outH), H, st)),
     "fc4 fwd+loss 4096x1024x2048": (2 * B * S * H, lambda: Lb.rv_decode_out_loss_fwd(P(h), H, P(W4), H, P(bS), B, S, H, B, S, P(xf), S, None, S, P(outS), S, P(msep), P(cs), st)),
     "dgrad fc4 4096x2048x1024 NN": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), S, P(W4), H, B, H, S, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
-    "wgrad fc4 1024x2048x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(dp4), S, P(h), H, S, H, B, SPL["w4"], P(f32buf), H, st)),
+    "wgrad fc4 1024x2048x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(dp4), LD(S), P(h), LD(H), S, H, B, SPL["w4"], P(f32buf), H, st)),
     "dz        4096x64x2048   NN": (2 * B * L * H, lambda: Lb.rv_linear_dgrad(P(h), H, P(W3), L, B, L, H, None, 0, None, 0, None, P(f32buf), L, SPL["dz"], st)),
     "wgrad fc3 2048x64x4096   TN": (2 * B * L * H, lambda: Lb.rv_linear_wgrad(P(h), H, P(z), L, H, L, B, SPL["w3"], P(f32buf), L, st)),
     "dgrad hd  4096x2048x128  NN": (2 * B * H * L2, lambda: Lb.rv_linear_dgrad(P(dmulv), L2, P(Wh), H, B, H, L2, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
     "wgrad hd  128x2048x4096  TN": (2 * B * H * L2, lambda: Lb.rv_linear_wgrad(P(dmulv), L2, P(h), H, L2, H, B, SPL["wh"], P(f32buf), H, st)),
-    "pure NT f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(x), S, P(W1), S, None, B, H, S, 1, P(f32buf), H, st)),
-    "pure NN f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), S, P(W4), H, B, H, S, None, 0, None, 0, None, P(f32buf), H, 1, st)),
-    "pure NT f32 4096x1024x2048": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(h), H, P(W4), H, None, B, S, H, 1, P(f32buf), S, st)),
-    "wgrad fc1 2048x1024x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(h), H, P(x), S, H, S, B, SPL["w1"], P(f32buf), S, st)),
+    "pure NT f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(x), LD(S), P(W1), LD(S), None, B, H, S, 1, P(f32buf), H, st)),
+    "pure NN f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), LD(S), P(W4), LD(H), B, H, S, None, 0, None, 0, None, P(f32buf), H, 1, st)),
+    "pure NT f32 4096x1024x2048": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(h), LD(H), P(W4), LD(H), None, B, S, H, 1, P(f32buf), S, st)),
+    "wgrad fc1 2048x1024x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(h), LD(H), P(x), LD(S), H, S, B, SPL["w1"], P(f32buf), S, st)),
 }
 
 e0, e1 = C.c_void_p(), C.c_void_p()
 Lb.rv_event_create(C.byref(e0))
 Lb.rv_event_create(C.byref(e1))
+if PAD:
+    cases = {k: v for k, v in cases.items() if k.startswith(('pure', 'fc1', 'wgrad fc4', 'wgrad fc1'))}
 res = {k: [] for k in cases}
 REPS, ROUNDS = 20, 5
 for rnd_i in range(ROUNDS + 1):
