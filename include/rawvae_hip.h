@@ -222,6 +222,10 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
 void rv_plan_destroy(rv_plan*);
 long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
+/* The full local step (FWD|BWD_A|BWD_B|ADAM) forks the weight-gradient GEMMs and the
+ * fc3/fc4 half of Adam onto an internal side stream and joins before returning to the
+ * caller's stream order (needs a non-default `stream`).  0 disables (one serial stream). */
+int rv_plan_set_concurrency(rv_plan*, int enable);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);
 /* Enqueue the selected phases of one training step (train.py:184-193) on `stream`.

@@ -79,6 +79,7 @@ _SIGS = {
     "rv_plan_workspace_bytes": (c_long, [c_void_p]),
     "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
+    "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),

@@ -73,7 +73,8 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
 // partial-sum buffers from it).
 static int choose_tile(long Mp, long Np, int splits) {
   if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) return g_force_tile;
-  if (tile_fits(2, Mp, Np) && (Mp / 256) * (Np / 128) * splits >= 192) return 2;
+  // 256x128 only when it fills the chip without slicing K finely (small-N GEMMs do better on 128x128)
+  if (tile_fits(2, Mp, Np) && splits <= 4 && (Mp / 256) * (Np / 128) * splits >= 192) return 2;
   return tile_fits(1, Mp, Np) ? 1 : 0;
 }
 
@@ -97,7 +98,8 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
     t = g_force_tile;
   } else if (tile_fits(2, Mp, Np)) {
     const long tl = (Mp / 256) * (Np / 128);
-    if (tl * splits_for(tl, kt, max_splits) >= 192) t = 2;
+    const int sp = splits_for(tl, kt, max_splits);
+    if (sp <= 4 && tl * sp >= 192) t = 2;
   }
   if (t < 0) t = tile_fits(1, Mp, Np) ? 1 : 0;
   int m, n;

@@ -45,6 +45,11 @@ struct rv_plan {
   rv_plan_buffers b;
   bool bound;
   rv_param_desc d_slab[10], d_flat[10];
+  // fork/join machinery: independent backward GEMMs and the fc3/fc4 half of Adam run on a
+  // side stream, ordered against the caller's stream with events (graph-capture safe)
+  hipStream_t side = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool concurrent = true;
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -126,7 +131,19 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   return RV_OK;
 }
 
-void rv_plan_destroy(rv_plan* p) { delete p; }
+void rv_plan_destroy(rv_plan* p) {
+  if (!p) return;
+  for (hipEvent_t e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (p->side) (void)hipStreamDestroy(p->side);
+  delete p;
+}
+
+int rv_plan_set_concurrency(rv_plan* p, int enable) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
+  p->concurrent = enable != 0;
+  return RV_OK;
+}
 
 long rv_plan_workspace_bytes(const rv_plan* p) { return p ? p->ws_bytes : 0; }
 
@@ -143,6 +160,10 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   RV_REQUIRE(((uintptr_t)b->workspace & 255) == 0, RV_ERR_SHAPE, "rv_plan_bind: workspace must be 256-byte aligned");
   p->b = *b;
   p->bound = true;
+  if (!p->side) {
+    RV_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    for (hipEvent_t& e : p->ev) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   const long H = p->H, S = p->S, L = p->L, Hp = p->Hp, Sp = p->Sp, Lp = p->Lp, L2p = p->L2p, Bp = p->Bp;
   float* dW1 = (float*)p->ws("dW1"); float* dWh = (float*)p->ws("dWh");
   float* dW3 = (float*)p->ws("dW3"); float* dW4 = (float*)p->ws("dW4");
@@ -225,6 +246,42 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
     RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                   recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+  }
+  const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
+                              (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
+                          !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
+  if (full_local && p->concurrent && stream) {
+    // Two-stream backward.  Main stream: the dependent chain dgrad fc4 -> dz -> reparam_bwd ->
+    // dgrad heads -> wgrad fc1 -> Adam(fc1, heads).  Side stream: wgrad fc4 -> wgrad fc3 ->
+    // wgrad heads -> Adam(fc3, fc4), each gated by an event on the tensor it consumes.
+    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
+    void* v1 = (void*)s1;
+    RV_HIP(hipEventRecord(p->ev[0], s0));  // forward done: dP4, h3, z, mulv ready
+    RV_HIP(hipStreamWaitEvent(s1, p->ev[0], 0));
+    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"),
+                           nullptr, 0, 1, stream));
+    RV_HIP(hipEventRecord(p->ev[1], s0));  // dP3, db3 ready; W4b no longer read
+    RV_TRY(rv_linear_wgrad(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, (float*)p->ws("dW4"), Hp, v1));
+    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
+                           p->s_dz, stream));
+    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
+                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
+                          p->b.step_counter, p->b.ring, stream));
+    RV_HIP(hipEventRecord(p->ev[2], s0));  // dmulv ready; W3b no longer read
+    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
+    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, v1));
+    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
+                           nullptr, 0, 1, stream));
+    RV_HIP(hipStreamWaitEvent(s1, p->ev[2], 0));
+    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, v1));
+    RV_TRY(rv_adam_multi(p->d_slab + 6, 4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, v1));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_HIP(hipEventRecord(p->ev[3], s1));
+    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join
+    RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, stream));
+    return RV_OK;
   }
   if (phases & RV_PHASE_BWD_A) {
     RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"),

@@ -96,6 +96,10 @@ class TrainEngine:
                 self.view(self.param, k).copy_(src.to(self.device, torch.float32))
         self.refresh_shadows()
 
+    def set_concurrency(self, enable):
+        """Fork independent backward GEMMs / half of Adam onto a side stream (default on)."""
+        lib().rv_plan_set_concurrency(self._plan, int(bool(enable)))
+
     def refresh_shadows(self, stream=None):
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
 

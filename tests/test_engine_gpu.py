@@ -161,3 +161,21 @@ def test_graph_replay_matches_eager():
     torch.cuda.synchronize()
     assert torch.equal(a.param, b.param)
     assert a.losses(4) == b.losses(4)
+
+
+def test_two_stream_backward_equals_serial():
+    """The forked schedule (side stream + events) must give bit-identical steps."""
+    S, H, L, B = 256, 384, 16, 256
+    a, b = _engine(S, H, L, B, seed=5), _engine(S, H, L, B, seed=5)
+    a.set_concurrency(False)
+    b.set_concurrency(True)
+    st = torch.cuda.Stream()
+    xs = [torch.from_numpy(make_frames(B, S, 40 + i)).cuda() for i in range(3)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for i in range(6):
+            a.step(xs[i % 3], stream=st)
+            b.step(xs[i % 3], stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(a.param, b.param) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    assert a.losses(6) == b.losses(6)
