@@ -50,12 +50,12 @@ def time_dominant_kernel(eng, reps=50):
     """Average duration of the TN wgrad GEMM (dW4 = dP4^T h3: M=S, N=H, K=B) with HIP
     events on the launching stream.  Returns (ms_per_launch, flops_per_launch)."""
     import torch
-    from rawaudiovae_kelsey_amd._lib import lib, stream_ptr
+    from rawaudiovae_kelsey_amd._lib import gemm_pick, lib, stream_ptr
     Lb = lib()
     Bp, Sp, Hp, Lp = eng.padded()
     dP4 = eng.buffer("dP4", torch.bfloat16, (Bp, Sp))
     h3 = eng.buffer("h3", torch.bfloat16, (Bp, Hp))
-    splits = 2
+    bm, bn, splits = gemm_pick(Sp, Hp, Bp)  # the tile / split-K the training step itself uses
     out = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
     st = stream_ptr()
     e0, e1 = C.c_void_p(), C.c_void_p()
@@ -74,7 +74,7 @@ def time_dominant_kernel(eng, reps=50):
     Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
     Lb.rv_event_destroy(e0)
     Lb.rv_event_destroy(e1)
-    return ms.value / reps, 2.0 * S * H * B
+    return ms.value / reps, 2.0 * S * H * B, (bm, bn, splits)
 
 
 def main():
@@ -104,17 +104,13 @@ def main():
     eng.set_concurrency(not args.serial)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
     comp = torch.cuda.Stream(device=dev)
-    use_graph = world == 1 and not args.no_graph
-    off_a = eng.offsets["fc3.weight"]  # grad arena: [fc1, fc21, fc22 | fc3, fc4]
+    use_graph = world == 1 and not args.no_graph and os.environ.get("RV_FORCE_DDP") != "1"
+    from rawaudiovae_kelsey_amd import ddp
+    force_ddp = os.environ.get("RV_FORCE_DDP") == "1"  # exercise the phased DDP step on one rank
+    sync = ddp.GradSync(eng.grad, ddp.engine_buckets(eng)) if (world > 1 or force_ddp) else None
 
     def ddp_step(x):
-        eng.step(x, phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_FINALIZE_A, stream=comp)
-        wa = dist.all_reduce(eng.grad[off_a:], async_op=True)  # overlaps with BWD_B
-        eng.step(x, phases=E.PHASE_BWD_B | E.PHASE_FINALIZE_B, stream=comp)
-        wb = dist.all_reduce(eng.grad[:off_a], async_op=True)
-        wa.wait()
-        wb.wait()
-        eng.step(x, phases=E.PHASE_ADAM, grad_scale=1.0 / world, adam_from_flat=True, stream=comp)
+        ddp.ddp_step(eng, sync, x, stream=comp)
 
     graphs = []
     with torch.cuda.stream(comp):
@@ -128,7 +124,7 @@ def main():
                 graphs.append(g)
 
         def one_step(i):
-            if world > 1:
+            if sync is not None:
                 ddp_step(pool[i % POOL])
             elif use_graph:
                 graphs[i % POOL].launch()
@@ -156,7 +152,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         last = eng.losses(min(8, args.steps))
-        kern_ms, kern_flops = time_dominant_kernel(eng) if rank == 0 else (None, None)
+        kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
         print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)
@@ -178,8 +174,8 @@ def main():
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "final_loss": last[-1],
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,TN,EPI_F32> (weight-gradient GEMM "
-                                                    "dW=dY^T X, M=1024 N=2048 K=4096, split-K 2)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel TN/EPI_F32, %dx%d tile, split-K %d (weight-gradient "
+                                                    "GEMM dW=dY^T X, M=1024 N=2048 K=4096; 2 launches/step)" % kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                          "us_per_launch": kern_ms * 1e3},

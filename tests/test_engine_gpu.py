@@ -179,3 +179,18 @@ def test_two_stream_backward_equals_serial():
     torch.cuda.synchronize()
     assert torch.equal(a.param, b.param) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
     assert a.losses(6) == b.losses(6)
+
+
+def test_ddp_phased_step_equals_local_step_single_rank():
+    """FWD|BWD_A|FINALIZE_A -> (all-reduce) -> BWD_B|FINALIZE_B -> (all-reduce) -> Adam-from-flat
+    is the same arithmetic as the fused local step when world == 1."""
+    from rawaudiovae_kelsey_amd import ddp
+    S, H, L, B = 256, 384, 16, 256
+    a, b = _engine(S, H, L, B, seed=9), _engine(S, H, L, B, seed=9)
+    sync = ddp.GradSync(b.grad, ddp.engine_buckets(b))
+    xs = [torch.from_numpy(make_frames(B, S, 70 + i)).cuda() for i in range(3)]
+    for i in range(4):
+        a.step(xs[i % 3])
+        ddp.ddp_step(b, sync, xs[i % 3])
+    torch.cuda.synchronize()
+    assert torch.equal(a.param, b.param) and a.losses(4) == b.losses(4)
