@@ -111,7 +111,7 @@ int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx
  *      kl_partial[block] = sum over valid (b,l) of 1 + logvar - mu^2 - exp(logvar).
  * eps: explicit [B,L] fp32 when eps_in != NULL (parity runs), otherwise generated
  * on-device (Philox4x32-10 + Box-Muller, keyed by seed and *step_counter) and
- * written to eps_out [B,L].  n_kl_partials = ceil(Bp*Lp/256). */
+ * written to eps_out [B,L].  n_kl_partials = Bp*Lp/1024. */
 int rv_reparam_fwd(const float* mulv_slabs, int splits, long Bp, long Lp, long B, long L,
                    const float* eps_in, float* eps_out, unsigned long long seed,
                    const long long* step_counter, float* mulv, void* z_bf16, float* kl_partial,

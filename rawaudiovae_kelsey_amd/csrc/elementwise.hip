@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ reparam forward + KL
-// One thread per (b, l) of the padded [Bp, Lp] latent grid.
+// One thread per 4 consecutive latent columns of the padded [Bp, Lp] grid (float4 slab reads,
+// four slabs in flight).
 __global__ void __launch_bounds__(256)
 k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, long B, long L,
               const float* __restrict__ eps_in, float* __restrict__ eps_out, uint64_t seed,
@@ -121,34 +122,66 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
               bf16_t* __restrict__ z, float* __restrict__ kl_partial) {
   __shared__ float red[4];
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long b = i / Lp, l = i % Lp;
+  const long lq = Lp / 4;
+  const long b = i / lq, l = (i % lq) * 4;
   const long L2p = 2 * Lp;
   float kl = 0.f;
   if (b < Bp) {
-    float mu = 0.f, lv = 0.f, zz = 0.f;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), lv = mu;
+    float zz[4] = {0.f, 0.f, 0.f, 0.f};
     if (b < B && l < L) {
-      for (int s = 0; s < splits; ++s) {
-        const float* sl = slabs + (long)s * Bp * L2p + b * L2p;
-        mu += sl[l];
-        lv += sl[Lp + l];
+      const float* base = slabs + b * L2p + l;
+      const long ss = Bp * L2p;
+      int s = 0;
+      for (; s + 4 <= splits; s += 4) {
+        float4 m[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          m[u] = *reinterpret_cast<const float4*>(base + (s + u) * ss);
+          v[u] = *reinterpret_cast<const float4*>(base + (s + u) * ss + Lp);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          mu.x += m[u].x; mu.y += m[u].y; mu.z += m[u].z; mu.w += m[u].w;
+          lv.x += v[u].x; lv.y += v[u].y; lv.z += v[u].z; lv.w += v[u].w;
+        }
       }
-      float e;
-      if (eps_in) {
-        e = eps_in[b * L + l];
-      } else {
-        e = normal1(seed, (uint64_t)(b * L + l), step_counter ? (uint64_t)*step_counter : 0);
-        eps_out[b * L + l] = e;
+      for (; s < splits; ++s) {
+        const float4 m = *reinterpret_cast<const float4*>(base + s * ss);
+        const float4 v = *reinterpret_cast<const float4*>(base + s * ss + Lp);
+        mu.x += m.x; mu.y += m.y; mu.z += m.z; mu.w += m.w;
+        lv.x += v.x; lv.y += v.y; lv.z += v.z; lv.w += v.w;
       }
-      const float sd = __expf(0.5f * lv);
-      zz = mu + e * sd;
-      kl = 1.f + lv - mu * mu - sd * sd;
+      float mua[4] = {mu.x, mu.y, mu.z, mu.w}, lva[4] = {lv.x, lv.y, lv.z, lv.w};
+      const uint64_t off = step_counter ? (uint64_t)*step_counter : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (l + j < L) {
+          float e;
+          if (eps_in) {
+            e = eps_in[b * L + l + j];
+          } else {
+            e = normal1(seed, (uint64_t)(b * L + l + j), off);
+            eps_out[b * L + l + j] = e;
+          }
+          const float sd = __expf(0.5f * lva[j]);
+          zz[j] = mua[j] + e * sd;
+          kl += 1.f + lva[j] - mua[j] * mua[j] - sd * sd;
+        } else {
+          mua[j] = 0.f;
+          lva[j] = 0.f;
+        }
+      }
+      mu = make_float4(mua[0], mua[1], mua[2], mua[3]);
+      lv = make_float4(lva[0], lva[1], lva[2], lva[3]);
     }
-    mulv[b * L2p + l] = mu;
-    mulv[b * L2p + Lp + l] = lv;
-    z[b * Lp + l] = (bf16_t)zz;
+    *reinterpret_cast<float4*>(mulv + b * L2p + l) = mu;
+    *reinterpret_cast<float4*>(mulv + b * L2p + Lp + l) = lv;
+    const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
+    *reinterpret_cast<bf16x4*>(z + b * Lp + l) = zb;
   }
-  const float s = block_sum_256(kl, red);
-  if (threadIdx.x == 0) kl_partial[blockIdx.x] = s;
+  const float s_ = block_sum_256(kl, red);
+  if (threadIdx.x == 0) kl_partial[blockIdx.x] = s_;
 }
 
 // ------------------------------------------------------------------ reparam backward (+ loss finish)
@@ -587,8 +620,8 @@ int rv_reparam_fwd(const float* slabs, int splits, long Bp, long Lp, long B, lon
                    void* stream) {
   RV_REQUIRE(slabs && mulv && z && kl_partial, RV_ERR_NULL, "rv_reparam_fwd: null pointer");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_reparam_fwd: need eps_in or eps_out");
-  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && (Bp * Lp) % 256 == 0, RV_ERR_SHAPE, "rv_reparam_fwd: bad extents");
-  hipLaunchKernelGGL(k_reparam_fwd, dim3((unsigned)(Bp * Lp / 256)), dim3(256), 0, (hipStream_t)stream,
+  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && (Bp * Lp) % 1024 == 0, RV_ERR_SHAPE, "rv_reparam_fwd: bad extents");
+  hipLaunchKernelGGL(k_reparam_fwd, dim3((unsigned)(Bp * Lp / 1024)), dim3(256), 0, (hipStream_t)stream,
                      slabs, splits, Bp, Lp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv,
                      (bf16_t*)z, kl_partial);
   RV_CHECK_LAUNCH();

@@ -90,7 +90,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
     p->n_mse = (int)((Bp / bm) * (Sp / bn));
   }
-  p->n_kl = (int)(Bp * Lp / 256);
+  p->n_kl = (int)(Bp * Lp / 1024);
   const long sizes[10] = {H * S, H, L * H, L, L * H, L, H * L, H, S * H, S};
   long o = 0;
   for (int i = 0; i < 10; ++i) { p->off[i] = o; o += sizes[i]; }
