@@ -167,6 +167,13 @@ int rv_colsum_partial(const void* src, int is_bf16, long rows, long cols, long l
  * loss tensor to the gradients rv_loss_fused saved. */
 int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* stream);
 
+/* Hop-strided framing on the device (AudioDataset, rawvae/dataset.py:99-121): the padded
+ * waveform stays in HBM and out[i, :] = audio[f*hop : f*hop + S] with f = frame_index[i]
+ * (int64, e.g. one slice of the epoch's shuffle) or first_frame + i when frame_index is NULL
+ * (TestDataset, dataset.py:147-157, is hop == S).  Samples past n_samples read as 0. */
+int rv_gather_frames(const float* audio, long n_samples, const long long* frame_index,
+                     long first_frame, long n_frames, long S, long hop, float* out, void* stream);
+
 /* Standard normal draws (replaces torch.randn_like, model.py:25). */
 int rv_randn(float* out, long n, unsigned long long seed, unsigned long long offset,
              void* stream);

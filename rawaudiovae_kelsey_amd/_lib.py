@@ -71,6 +71,7 @@ _SIGS = {
     "rv_reparameterize": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_u64, c_u64,
                                   c_void_p, c_void_p]),
     "rv_randn": (c_int, [c_void_p, c_long, c_u64, c_u64, c_void_p]),
+    "rv_gather_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_float, c_float, c_void_p, c_void_p]),
     "rv_grad_finalize": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),

@@ -43,6 +43,20 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, u
   return {c0, c1, c2, c3};
 }
 
+// Same draw with the hardware transcendental units (v_log/v_sin/v_cos; abs error ~1e-6):
+// used where eps is consumed immediately and only its distribution matters.
+__device__ __forceinline__ void normal4_fast(uint64_t seed, uint64_t idx4, uint64_t offset, float* o) {
+  const u32x4 r = philox4x32_10(seed, idx4, offset);
+  const float inv32 = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)r.x + 0.5f) * inv32, u1 = ((float)r.y + 0.5f) * inv32;
+  const float u2 = ((float)r.z + 0.5f) * inv32, u3 = ((float)r.w + 0.5f) * inv32;
+  const float ra = sqrtf(-2.0f * __logf(fminf(u0, 0.99999994f)));
+  const float rb = sqrtf(-2.0f * __logf(fminf(u2, 0.99999994f)));
+  const float t1 = 6.283185307179586f * u1, t3 = 6.283185307179586f * u3;
+  o[0] = ra * __cosf(t1); o[1] = ra * __sinf(t1);
+  o[2] = rb * __cosf(t3); o[3] = rb * __sinf(t3);
+}
+
 // Four N(0,1) draws for counter (idx4, offset): Box-Muller on two uniform pairs.
 __device__ __forceinline__ void normal4(uint64_t seed, uint64_t idx4, uint64_t offset, float* o) {
   const u32x4 r = philox4x32_10(seed, idx4, offset);
@@ -153,7 +167,8 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
         lv.x += v.x; lv.y += v.y; lv.z += v.z; lv.w += v.w;
       }
       float mua[4] = {mu.x, mu.y, mu.z, mu.w}, lva[4] = {lv.x, lv.y, lv.z, lv.w};
-      const uint64_t off = step_counter ? (uint64_t)*step_counter : 0;
+      float ev[4];
+      if (!eps_in) normal4_fast(seed, (uint64_t)i, step_counter ? (uint64_t)*step_counter : 0, ev);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (l + j < L) {
@@ -161,7 +176,7 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
           if (eps_in) {
             e = eps_in[b * L + l + j];
           } else {
-            e = normal1(seed, (uint64_t)(b * L + l + j), off);
+            e = ev[j];
             eps_out[b * L + l + j] = e;
           }
           const float sd = __expf(0.5f * lva[j]);
@@ -401,6 +416,31 @@ __global__ void __launch_bounds__(256)
 k_scale_by(const float* __restrict__ a, const float* __restrict__ scalar, long n, float* __restrict__ out) {
   const float g = scalar[0];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * g;
+}
+
+// ------------------------------------------------------------------ hop-strided framing (N1)
+// frame i = audio[idx[i]*hop : idx[i]*hop + S]  (AudioDataset.__getitem__, dataset.py:108-118;
+// idx == NULL -> consecutive frames first_frame + i).  The waveform stays resident in HBM;
+// frames overlap S/hop-fold, so the gather is served from L2.
+__global__ void __launch_bounds__(256)
+k_gather_frames(const float* __restrict__ audio, long n_samples, const long long* __restrict__ idx,
+                long first_frame, long n_frames, long S, long hop, float* __restrict__ out) {
+  const long per = (S + 3) / 4;
+  const long total = n_frames * per;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const long f = t / per, c = (t % per) * 4;
+    const long start = (idx ? (long)idx[f] : first_frame + f) * hop + c;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long a = start + j;
+      v[j] = (c + j < S && a >= 0 && a < n_samples) ? audio[a] : 0.f;
+    }
+    float* o = out + f * S + c;
+    if (c + 4 <= S && ((S & 3) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+      for (int j = 0; j < 4 && c + j < S; ++j) o[j] = v[j];
+  }
 }
 
 // ------------------------------------------------------------------ Adam / gradient finaliser
@@ -666,6 +706,18 @@ int rv_reparameterize(const float* mu, const float* logvar, long n, const float*
   if (n == 0) return RV_OK;
   hipLaunchKernelGGL(k_reparameterize, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar,
                      n, eps_in, eps_out, (uint64_t)seed, (uint64_t)offset, z);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_gather_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
+                     long n_frames, long S, long hop, float* out, void* stream) {
+  RV_REQUIRE(audio && out, RV_ERR_NULL, "rv_gather_frames: null pointer");
+  RV_REQUIRE(n_samples > 0 && n_frames >= 0 && S > 0 && hop > 0, RV_ERR_SHAPE, "rv_gather_frames: bad extents");
+  RV_REQUIRE(((uintptr_t)out & 15) == 0, RV_ERR_SHAPE, "rv_gather_frames: output must be 16-byte aligned");
+  if (n_frames == 0) return RV_OK;
+  hipLaunchKernelGGL(k_gather_frames, dim3(grid_for(n_frames * ((S + 3) / 4), 4096)), dim3(256), 0,
+                     (hipStream_t)stream, audio, n_samples, frame_index, first_frame, n_frames, S, hop, out);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -1,0 +1,187 @@
+"""Audio framing for the training path, device-resident.
+
+Semantics follow the reference's datasets (`rawvae/dataset.py`):
+  * `AudioDataset` (dataset.py:86-121): concatenate all training wavs, zero-pad to a multiple
+    of `hop`, frame i = audio[i*hop : i*hop + S], len = N/hop - S/hop + 1, `ValueError` when
+    S is not a multiple of hop; `DataLoader(shuffle=True)` draws a fresh permutation per epoch
+    and keeps the ragged last batch (train.py:134).
+  * `TestDataset` (dataset.py:129-160): non-overlapping frames, tail zero-padded to S.
+  * `IterableAudioDataset` (dataset.py:11-84): shuffle the FILE list once per iterator, cycle
+    it forever, per file take channel 0, pad to `hop`, emit hop-strided frames in order.
+
+A Python DataLoader delivers ~0.1 M frames/s; the step consumes >15 M frames/s, so
+the waveform is uploaded once and frames are gathered on the GPU (`rv_gather_frames`): frames
+overlap S/hop-fold, so the unique bytes are 1/8 of the framed batch at hop 128.
+
+wav I/O uses scipy (librosa / soundfile / torchaudio are not available here): PCM is scaled to
+[-1, 1] float32; `librosa.load(sr=...)`'s mono mix-down (mean of channels) and resampling
+(polyphase here, not librosa's soxr) are restated.
+"""
+import itertools
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, stream_ptr
+
+
+def _to_float32(a):
+    if a.dtype == np.float32:
+        return a
+    if a.dtype == np.float64:
+        return a.astype(np.float32)
+    if a.dtype == np.uint8:
+        return (a.astype(np.float32) - 128.0) / 128.0
+    if np.issubdtype(a.dtype, np.integer):
+        return a.astype(np.float32) / float(2 ** (8 * a.dtype.itemsize - 1))
+    raise ValueError("unsupported wav sample type %s" % a.dtype)
+
+
+def read_wav(path):
+    """-> (float32 [n] or [n, channels], sample_rate)."""
+    from scipy.io import wavfile
+    sr, a = wavfile.read(str(path))
+    return _to_float32(a), int(sr)
+
+
+def _resample(a, sr_in, sr_out):
+    if sr_in == sr_out:
+        return a
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(int(sr_in), int(sr_out))
+    return resample_poly(a, sr_out // g, sr_in // g).astype(np.float32)
+
+
+def load_audio_mono(path, sampling_rate):
+    """`librosa.load(path, sr=sampling_rate)` (train.py:120): mono float32 at `sampling_rate`."""
+    a, sr = read_wav(path)
+    if a.ndim == 2:
+        a = a.mean(axis=1).astype(np.float32)
+    return _resample(a, sr, sampling_rate)
+
+
+def load_audio_ch0(path, sampling_rate):
+    """`torchaudio.load` + first channel only (dataset.py:47-58)."""
+    a, sr = read_wav(path)
+    if a.ndim == 2:
+        a = np.ascontiguousarray(a[:, 0])
+    return _resample(a, sr, sampling_rate)
+
+
+def write_wav(path, samples, sampling_rate):
+    """`soundfile.write(path, samples, sr)` stand-in: float32 wav."""
+    from scipy.io import wavfile
+    wavfile.write(str(path), int(sampling_rate), np.asarray(samples, dtype=np.float32))
+
+
+def frame_count(n_samples, segment_length, hop):
+    """(number of frames, padded length) of AudioDataset (dataset.py:99-104,121)."""
+    if segment_length % hop != 0:
+        raise ValueError("segment_length {} is not a multiple of hop_size {}".format(segment_length, hop))
+    padded = n_samples if n_samples % hop == 0 else n_samples + hop - n_samples % hop
+    return padded // hop - segment_length // hop + 1, padded
+
+
+class DeviceAudio:
+    """AudioDataset with the waveform resident in HBM and frames gathered on the device."""
+
+    def __init__(self, audio_np, segment_length, hop_size, device="cuda"):
+        self.segment_length, self.hop_size = int(segment_length), int(hop_size)
+        self.n_frames, self.padded = frame_count(len(audio_np), self.segment_length, self.hop_size)
+        self.device = torch.device(device)
+        buf = np.zeros(self.padded, dtype=np.float32)
+        buf[:len(audio_np)] = audio_np
+        self.audio = torch.from_numpy(buf).to(self.device)
+
+    def __len__(self):
+        return max(self.n_frames, 0)
+
+    def num_batches(self, batch_size):
+        return (len(self) + batch_size - 1) // batch_size
+
+    def gather(self, index, out=None, stream=None):
+        """index: int64 device tensor of frame numbers -> fp32 [len(index), S]."""
+        n = index.numel()
+        if out is None:
+            out = torch.empty((n, self.segment_length), dtype=torch.float32, device=self.device)
+        lib().rv_gather_frames(ptr(self.audio), self.padded, ptr(index), 0, n, self.segment_length,
+                               self.hop_size, ptr(out), stream_ptr(stream))
+        return out
+
+    def frames(self, first, n, out=None, stream=None):
+        """n consecutive frames starting at frame `first`."""
+        if out is None:
+            out = torch.empty((n, self.segment_length), dtype=torch.float32, device=self.device)
+        lib().rv_gather_frames(ptr(self.audio), self.padded, None, first, n, self.segment_length,
+                               self.hop_size, ptr(out), stream_ptr(stream))
+        return out
+
+    def batches(self, batch_size, shuffle=True, generator=None):
+        """One epoch: DataLoader(dataset, batch_size, shuffle) -- fresh permutation, ragged last batch kept."""
+        n = len(self)
+        if shuffle:
+            perm = torch.randperm(n, generator=generator).to(self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        for lo in range(0, n, batch_size):
+            yield self.gather(perm[lo:lo + batch_size])
+
+
+class DeviceEvalAudio(DeviceAudio):
+    """TestDataset: non-overlapping frames, tail zero-padded to a whole frame."""
+
+    def __init__(self, audio_np, segment_length, device="cuda"):
+        n = len(audio_np)
+        pad = n if n % segment_length == 0 else n + segment_length - n % segment_length
+        a = np.zeros(pad, dtype=np.float32)
+        a[:n] = audio_np
+        super().__init__(a, segment_length, segment_length, device)
+
+    def batches(self, batch_size, shuffle=False, generator=None):
+        return super().batches(batch_size, shuffle=False)
+
+
+class StreamingFrames:
+    """IterableAudioDataset + DataLoader(batch_size, shuffle=False) + islice: an endless stream of
+    fixed-size batches of hop-strided 1024-sample... `segment_length`-sample frames, file order
+    shuffled once per iterator (dataset.py:38-42,77-84).  Each file's waveform is uploaded once
+    and cached on the device; a batch that straddles a file boundary is gathered in two pieces."""
+
+    def __init__(self, files, sampling_rate, hop_size, segment_length, device="cuda", shuffle=True, seed=None):
+        self.files = list(files)
+        if not self.files:
+            raise FileNotFoundError("no .wav files to stream")
+        self.sampling_rate, self.hop_size, self.segment_length = int(sampling_rate), int(hop_size), int(segment_length)
+        self.device = torch.device(device)
+        self.shuffle = shuffle
+        self._rng = random.Random(seed)
+        self._cache = {}
+
+    def _dataset(self, f):
+        d = self._cache.get(f)
+        if d is None:
+            d = DeviceAudio(load_audio_ch0(f, self.sampling_rate), self.segment_length, self.hop_size, self.device)
+            self._cache[f] = d
+        return d
+
+    def batches(self, batch_size, n_batches):
+        order = self._rng.sample(self.files, len(self.files)) if self.shuffle else list(self.files)
+        stream = itertools.cycle(order)
+        cur, pos = None, 0
+        for _ in range(n_batches):
+            out = torch.empty((batch_size, self.segment_length), dtype=torch.float32, device=self.device)
+            filled = 0
+            while filled < batch_size:
+                if cur is None or pos >= len(cur):
+                    cur, pos = self._dataset(next(stream)), 0
+                    if len(cur) <= 0:
+                        cur = None
+                        continue
+                take = min(batch_size - filled, len(cur) - pos)
+                cur.frames(pos, take, out=out[filled:filled + take])
+                filled += take
+                pos += take
+            yield out

@@ -30,7 +30,10 @@ class TrainEngine:
     """Owns the arenas + workspace of one (S, H, L, B) training configuration."""
 
     def __init__(self, segment_length, n_units, latent_dim, batch_size, device="cuda",
-                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True):
+                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None):
+        """share: another TrainEngine of the same (S, H, L) whose parameter / Adam / gradient
+        arenas, step counter and loss ring this one uses (a second batch size, e.g. the ragged
+        last batch of an epoch -- DataLoader keeps it, train.py:134)."""
         self.S, self.H, self.L, self.B = int(segment_length), int(n_units), int(latent_dim), int(batch_size)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -49,15 +52,24 @@ class TrainEngine:
             o += n
         self.n_params = o
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.param = torch.zeros(o, **f32)
-        self.exp_avg = torch.zeros(o, **f32)
-        self.exp_avg_sq = torch.zeros(o, **f32)
-        self.grad = torch.zeros(o, **f32) if grad_arena else None
+        if share is not None:
+            if (share.S, share.H, share.L) != (self.S, self.H, self.L):
+                raise _lib.RvError("share: engines must have the same (S, H, L)")
+            self.param, self.exp_avg, self.exp_avg_sq, self.grad = share.param, share.exp_avg, share.exp_avg_sq, share.grad
+            self.step_counter, self.loss_ring, self.ring = share.step_counter, share.loss_ring, share.ring
+            self._shared = share._shared
+        else:
+            self.param = torch.zeros(o, **f32)
+            self.exp_avg = torch.zeros(o, **f32)
+            self.exp_avg_sq = torch.zeros(o, **f32)
+            self.grad = torch.zeros(o, **f32) if grad_arena else None
+            self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.loss_ring = torch.zeros(self.ring, 4, **f32)
+            self._shared = {"version": 0, "drained": 0}   # parameter version, losses already drained
+        self._shadow_version = -1
         ws_bytes = L_.rv_plan_workspace_bytes(self._plan)
         self.workspace = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=self.device)
         ws_ptr = (self.workspace.data_ptr() + 255) // 256 * 256
-        self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.loss_ring = torch.zeros(self.ring, 4, **f32)
         self._bufs = PlanBuffers(ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                  ptr(self.grad), ws_ptr, ptr(self.step_counter),
                                  ptr(self.loss_ring), self.ring)
@@ -94,6 +106,7 @@ class TrainEngine:
                 if not torch.is_tensor(src):
                     src = torch.as_tensor(src)
                 self.view(self.param, k).copy_(src.to(self.device, torch.float32))
+        self.params_changed()
         self.refresh_shadows()
 
     def set_concurrency(self, enable):
@@ -101,7 +114,13 @@ class TrainEngine:
         lib().rv_plan_set_concurrency(self._plan, int(bool(enable)))
 
     def refresh_shadows(self, stream=None):
+        """Rebuild this engine's bf16/padded weight shadows from the fp32 arena."""
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
+        self._shadow_version = self._shared["version"]
+
+    def params_changed(self):
+        """Call after writing the fp32 arena from outside (load_state_dict, optimizer.step ...)."""
+        self._shared["version"] += 1
 
     def adopt(self, module):
         """Copy a VAE module's parameters into the arena and re-point the module's
@@ -112,6 +131,7 @@ class TrainEngine:
                 v = self.view(self.param, k)
                 v.copy_(sd[k].detach().to(self.device, torch.float32))
                 sd[k].data = v
+        self.params_changed()
         self.refresh_shadows()
 
     # ---- stepping -------------------------------------------------------
@@ -123,11 +143,16 @@ class TrainEngine:
         if eps is not None and (eps.dtype != torch.float32 or not eps.is_contiguous()
                                 or eps.numel() != self.B * self.L):
             raise _lib.RvError("step: eps must be contiguous fp32 [B, L]")
+        if (phases & PHASE_FWD) and self._shadow_version != self._shared["version"]:
+            self.refresh_shadows(stream)   # another engine sharing the arena stepped since
         lib().rv_plan_step(self._plan, int(phases), ptr(x), ptr(eps), ptr(recon_out), self.kl_beta,
                            self.lr, float(grad_scale), int(bool(adam_from_flat)), self.seed,
                            stream_ptr(stream))
         if phases & PHASE_FWD:
             self.host_steps += 1
+        if phases & PHASE_ADAM:
+            self._shared["version"] += 1
+            self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
 
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""
@@ -163,6 +188,41 @@ class TrainEngine:
         n = min(n, self.ring, done)
         idx = [(done - n + i) % self.ring for i in range(n)]
         return self.loss_ring[idx, 0].tolist()
+
+
+    def drain_losses(self):
+        """Per-step total losses recorded since the previous drain, oldest first (one device
+        sync).  Must be called at least every `ring` steps or older entries are overwritten."""
+        done = self.steps_done()
+        n = done - self._shared["drained"]
+        if n > self.ring:
+            raise _lib.RvError("drain_losses: %d steps since the last drain exceed the ring of %d" % (n, self.ring))
+        idx = [(self._shared["drained"] + i) % self.ring for i in range(n)]
+        self._shared["drained"] = done
+        return self.loss_ring[idx, 0].tolist() if n else []
+
+    # ---- optimizer state in torch.optim.Adam form (checkpoints, train.py:208-212) ----
+    def optimizer_state_dict(self):
+        t = float(self.steps_done())
+        state = {i: {"step": torch.tensor(t), "exp_avg": self.view(self.exp_avg, k).clone(),
+                     "exp_avg_sq": self.view(self.exp_avg_sq, k).clone()} for i, k in enumerate(PARAM_NAMES)}
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(PARAM_NAMES)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        st = sd["state"]
+        with torch.no_grad():
+            for i, k in enumerate(PARAM_NAMES):
+                if i in st:
+                    self.view(self.exp_avg, k).copy_(st[i]["exp_avg"].to(self.device))
+                    self.view(self.exp_avg_sq, k).copy_(st[i]["exp_avg_sq"].to(self.device))
+            steps = [int(v["step"]) for v in st.values()] if st else [0]
+            self.step_counter.fill_(max(steps))
+        self._shared["drained"] = int(self.step_counter.item())
+        if sd.get("param_groups"):
+            self.lr = float(sd["param_groups"][0].get("lr", self.lr))
 
 
 class Graph:

@@ -310,3 +310,30 @@ def test_adam_multi_and_finalize(L):
         np.testing.assert_array_equal(got[:r, :c], O.bf16_round(pd.cpu().numpy()[o:o + r * c].reshape(r, c)))
         assert np.all(got[r:] == 0) and np.all(got[:, c:] == 0)
         o += r * c
+
+
+def test_gather_frames_matches_audio_dataset_semantics(L):
+    """rv_gather_frames == AudioDataset.__getitem__ (rawvae/dataset.py:108-118) for a shuffled index,
+    and == TestDataset for hop == S."""
+    rng = np.random.default_rng(31)
+    audio = rng.uniform(-1, 1, 5003).astype(np.float32)
+    S, hop = 256, 64
+    ref = O.hop_frames(audio, S, hop)
+    n, padded = O.frame_count(len(audio), S, hop)
+    buf = np.zeros(padded, np.float32)
+    buf[:len(audio)] = audio
+    ad = dev(buf)
+    idx = rng.permutation(n).astype(np.int64)
+    idd = dev(idx)
+    out = torch.zeros((n, S), device="cuda")
+    L.rv_gather_frames(ad.data_ptr(), padded, idd.data_ptr(), 0, n, S, hop, out.data_ptr(), sp())
+    np.testing.assert_array_equal(out.cpu().numpy(), ref[idx])
+    L.rv_gather_frames(ad.data_ptr(), padded, None, 3, n - 3, S, hop, out.data_ptr(), sp())
+    np.testing.assert_array_equal(out.cpu().numpy()[:n - 3], ref[3:])
+    ev = O.eval_frames(audio, 100)   # S not a multiple of 4: scalar tail path
+    e = np.zeros(ev.size, np.float32)
+    e[:len(audio)] = audio
+    ed = dev(e)
+    out2 = torch.zeros(ev.shape, device="cuda")
+    L.rv_gather_frames(ed.data_ptr(), ev.size, None, 0, ev.shape[0], 100, 100, out2.data_ptr(), sp())
+    np.testing.assert_array_equal(out2.cpu().numpy(), ev)

@@ -1,0 +1,175 @@
+"""Entry points `train.py --config` / `train_iterable.py --config`: host logic on CPU, and an
+end-to-end run on the GPU with synthetic wav files (workspace tree, checkpoint keys, console
+lines and artefacts of the reference, train.py:94-109,136-151,198-250,254-307)."""
+import configparser
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from conftest import GOLDEN, REPO  # noqa: E402
+
+
+def _sine_wav(path, seconds, sr, f0, stereo=False):
+    from scipy.io import wavfile
+    t = np.arange(int(seconds * sr)) / sr
+    a = (0.5 * np.sin(2 * np.pi * f0 * t) + 0.2 * np.sin(2 * np.pi * 2.7 * f0 * t)).astype(np.float32)
+    pcm = (a * 32767).astype(np.int16)
+    if stereo:
+        pcm = np.stack([pcm, -pcm], axis=1)
+    wavfile.write(str(path), sr, pcm)
+    return a
+
+
+def _dataset(tmp_path, sr=8000):
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    (tmp_path / "audio").mkdir()
+    (tmp_path / "test_audio").mkdir()
+    _sine_wav(tmp_path / "audio" / "a.wav", 1.3, sr, 220.0)
+    _sine_wav(tmp_path / "audio" / "b.wav", 0.9, sr, 330.0, stereo=True)
+    _sine_wav(tmp_path / "test_audio" / "t.wav", 0.5, sr, 440.0)
+    return tmp_path
+
+
+def _ini(tmp_path, iterable=False, **over):
+    cfg = configparser.ConfigParser(allow_no_value=True)
+    cfg.read(os.path.join(REPO, "default_iterable.ini" if iterable else "default.ini"))
+    cfg["audio"].update(sampling_rate="8000", hop_length="64", segment_length="256")
+    cfg["dataset"]["datapath"] = str(tmp_path)
+    cfg["VAE"].update(latent_dim="8", n_units="128")
+    cfg["training"].update(batch_size="64", checkpoint_interval="2", learning_rate="0.001")
+    if iterable:
+        cfg["training"]["total_num_frames"] = str(64 * 7)
+        cfg["training"]["checkpoint_interval"] = "3"
+    else:
+        cfg["training"].update(epochs="4", save_best_model_after="1")
+    cfg["extra"]["description"] = "unit"
+    cfg["mi355x"].update(tensorboard="False", loss_ring="4")
+    for k, v in over.items():
+        sec, key = k.split("__")
+        cfg[sec][key] = v
+    p = tmp_path / "run.ini"
+    with open(p, "w") as f:
+        cfg.write(f)
+    return p
+
+
+def test_wav_io_and_frame_count_host_logic(tmp_path):
+    from rawaudiovae_kelsey_amd import data as D
+    a = _sine_wav(tmp_path / "m.wav", 0.25, 8000, 200.0)
+    got = D.load_audio_mono(tmp_path / "m.wav", 8000)
+    assert got.dtype == np.float32 and len(got) == len(a) and np.abs(got - a).max() < 1e-4
+    _sine_wav(tmp_path / "s.wav", 0.25, 8000, 200.0, stereo=True)
+    assert np.abs(D.load_audio_mono(tmp_path / "s.wav", 8000)).max() < 1e-4      # L + (-L) averages to 0
+    assert np.abs(D.load_audio_ch0(tmp_path / "s.wav", 8000) - a).max() < 1e-4   # streaming path: channel 0
+    assert len(D.load_audio_mono(tmp_path / "m.wav", 4000)) == len(a) // 2        # resampled
+    D.write_wav(tmp_path / "o.wav", a, 8000)
+    assert np.array_equal(D.read_wav(tmp_path / "o.wav")[0], a)
+    with open(os.path.join(GOLDEN, "summary.json")) as f:
+        d = json.load(f)["dataset"]
+    assert D.frame_count(d["n_samples"], d["segment_length"], d["hop"]) == (d["len"], d["padded"])
+    with pytest.raises(ValueError):
+        D.frame_count(d["n_samples"], d["bad_segment_length"], d["hop"])
+
+
+def test_workspace_numbering_and_missing_paths(tmp_path):
+    sys.path.insert(0, REPO)
+    import train as T
+    w0 = T.make_workspace(tmp_path, "desc", 0)
+    w1 = T.make_workspace(tmp_path, "desc", 0)
+    assert w0.name == "run-000" and w1.name == "run-001" and w1.parent.name == "desc"
+    ini = _ini(_dataset(tmp_path / "d1"), dataset__datapath=str(tmp_path / "nope"))
+    with pytest.raises(FileNotFoundError):
+        T.main(["--config", str(ini)])
+    with pytest.raises(SystemExit):
+        T.main(["--config", str(tmp_path / "missing.ini")])
+
+
+@pytest.mark.gpu
+def test_train_py_end_to_end(tmp_path, capsys):
+    sys.path.insert(0, REPO)
+    import train as T
+    from rawaudiovae_kelsey_amd import data as D
+    ds = _dataset(tmp_path)
+    workdir = T.main(["--config", str(_ini(ds))])
+    out = capsys.readouterr().out
+    assert workdir.name == "run-000" and workdir.parent.name == "unit"
+    for rel in ("config.ini", "model/checkpoints/ckpt_00002", "model/checkpoints/ckpt_00004", "model/last_model.pt",
+                "model/best_model.pt", "audio_logs/test_audio.txt", "audio_logs/test_original.wav",
+                "audio_logs/test_reconst_00002.wav", "audio_logs/test_reconst_00004.wav", "logs"):
+        assert (workdir / rel).exists(), rel
+    assert "Epoch 0/3" in out and "----------" in out and "Checkpoint - Epoch 2" in out
+    assert "Total number of audio frames:" in out and "Training Finished: Saved the last model" in out
+    losses = [float(l.split("Total loss: ")[1].split(" - ")[0]) for l in out.splitlines() if l.startswith("====> Epoch")]
+    assert len(losses) == 4 and losses[-1] < losses[0]
+    ck = torch.load(workdir / "model/checkpoints/ckpt_00004", weights_only=False)
+    assert set(ck) == {"epoch", "state_dict", "optimizer"} and ck["epoch"] == 3
+    assert list(ck["state_dict"]) == ["fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight",
+                                      "fc22.bias", "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias"]
+    n_frames, _ = D.frame_count(int(1.3 * 8000) + int(0.9 * 8000), 256, 64)
+    steps = 4 * ((n_frames + 63) // 64)
+    assert int(ck["optimizer"]["state"][0]["step"]) == steps
+    opt = torch.optim.Adam([torch.nn.Parameter(v.clone()) for v in ck["state_dict"].values()], lr=1e-3)
+    opt.load_state_dict(ck["optimizer"])          # the optimizer dict is in torch.optim.Adam's own format
+    m = torch.load(workdir / "model/last_model.pt", weights_only=False)
+    assert type(m).__module__ == "rawvae.model"
+    rec, sr = D.read_wav(workdir / "audio_logs/test_reconst_00004.wav")
+    orig, _ = D.read_wav(workdir / "audio_logs/test_original.wav")
+    assert sr == 8000 and len(rec) == ((len(orig) + 255) // 256) * 256 and np.isfinite(rec).all()
+    cfg = configparser.ConfigParser(allow_no_value=True)
+    cfg.read(workdir / "config.ini")
+    assert cfg["dataset"]["workspace"] == str(workdir.resolve()) and cfg["VAE"]["device_name"]
+    assert cfg["dataset"]["total_frames"] == str((int(1.3 * 8000) + int(0.9 * 8000)) // 256)
+
+
+@pytest.mark.gpu
+def test_train_iterable_end_to_end(tmp_path, capsys):
+    sys.path.insert(0, REPO)
+    import train_iterable as TI
+    ds = _dataset(tmp_path)
+    workdir = TI.main(["--config", str(_ini(ds, iterable=True))])
+    out = capsys.readouterr().out
+    batch_lines = [l for l in out.splitlines() if l.startswith("====> Batch:")]
+    assert len(batch_lines) == 7 and batch_lines[0].startswith("====> Batch: 0 - Loss: ")
+    for rel in ("console_log", "model/checkpoints/ckpt_00003", "model/checkpoints/ckpt_00006",
+                "model/checkpoints/ckpt_00007", "model/last_model.pt", "audio_logs/test_reconst_00003.wav"):
+        assert (workdir / rel).exists(), rel
+    ck = torch.load(workdir / "model/checkpoints/ckpt_00006", weights_only=False)
+    assert set(ck) == {"batch_id", "state_dict", "optimizer"} and ck["batch_id"] == 6
+    assert "====> Batch: 6" in open(workdir / "console_log").read()
+
+
+@pytest.mark.gpu
+def test_streaming_frames_order_and_file_boundaries(tmp_path):
+    """Unshuffled stream == hop frames of file a (ch0), then file b, cycled (dataset.py:53-84)."""
+    from oracle import vae_oracle as O
+    from rawaudiovae_kelsey_amd import data as D
+    ds = _dataset(tmp_path)
+    files = sorted((ds / "audio").glob("*.wav"))
+    ref = np.concatenate([O.hop_frames(D.load_audio_ch0(f, 8000), 256, 64) for f in files] * 2)
+    st = D.StreamingFrames(files, 8000, 64, 256, "cuda", shuffle=False)
+    got = torch.cat(list(st.batches(50, 9))).cpu().numpy()
+    np.testing.assert_array_equal(got, ref[:450])
+
+
+@pytest.mark.gpu
+def test_device_audio_epoch_is_a_permutation_with_ragged_tail():
+    from oracle import vae_oracle as O
+    from rawaudiovae_kelsey_amd import data as D
+    rng = np.random.default_rng(2)
+    audio = rng.uniform(-1, 1, 64 * 37 + 11).astype(np.float32)
+    d = D.DeviceAudio(audio, 256, 64)
+    ref = O.hop_frames(audio, 256, 64)
+    assert len(d) == len(ref)
+    bs = [b.cpu().numpy() for b in d.batches(16, shuffle=True, generator=torch.Generator().manual_seed(1))]
+    assert [len(b) for b in bs] == [16] * (len(ref) // 16) + [len(ref) % 16]
+    got = np.concatenate(bs)
+    key = lambda a: sorted(map(bytes, a))
+    assert key(got) == key(ref)       # every frame exactly once
+    assert not np.array_equal(got, ref)  # and shuffled
+    with pytest.raises(ValueError):
+        D.DeviceAudio(audio, 250, 64)
