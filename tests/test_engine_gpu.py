@@ -194,3 +194,40 @@ def test_ddp_phased_step_equals_local_step_single_rank():
         ddp.ddp_step(b, sync, xs[i % 3])
     torch.cuda.synchronize()
     assert torch.equal(a.param, b.param) and a.losses(4) == b.losses(4)
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 1, 1), (1000, 130, 256, 3), (64, 64, 129, 300), (1024, 2048, 64, 2137)])
+def test_edge_shapes_single_frame_wide_latent_ragged_batch(shape):
+    """B=1, L=1, L=256 (widest supported latent), S not a multiple of 8, and the ragged last batch
+    of the reference's 30 s example (2137 frames) -- each a full step against the oracle."""
+    from rawaudiovae_kelsey_amd import engine as E
+    S, H, L, B = shape
+    e = _engine(S, H, L, B)
+    x, eps = make_frames(B, S, 11), make_eps(B, L, 12)
+    recon = torch.zeros(B, S, device="cuda")
+    e.step(torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda(), recon,
+           phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B)
+    p = O.cast_params(make_params(S, H, L, 0), np.float32)
+    c = O.forward(p, x, eps, quant="bf16")
+    loss, _, _ = O.loss_function(c["recon"].astype(np.float64), x.astype(np.float64), c["mu"].astype(np.float64),
+                                 c["logvar"].astype(np.float64), KL)
+    g = O.backward(p, c, KL, quant="bf16")
+    assert abs(e.last_loss()[0] - loss) <= 5e-5 * abs(loss)
+    # a bf16-ulp flip of one hidden unit (different fp32 summation order) moves a few outputs by ~2e-3
+    np.testing.assert_allclose(recon.cpu().numpy(), c["recon"], atol=4e-3)
+    assert (np.abs(recon.cpu().numpy() - c["recon"]) > 1e-3).mean() < 1e-3
+    gv = e.grad_views()
+    for k in PARAM_NAMES:
+        assert _rel_l2(gv[k].cpu().numpy(), g[k]) < 1e-2, k
+
+
+def test_unsupported_latent_is_rejected_loudly():
+    from rawaudiovae_kelsey_amd._lib import RvError
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    with pytest.raises(RvError, match="latent_dim"):
+        TrainEngine(64, 64, 300, 8)
+    e = _engine(64, 64, 8, 8)
+    with pytest.raises(RvError):
+        e.step(torch.zeros(7, 64, device="cuda"))          # wrong batch size
+    with pytest.raises(RvError):
+        e.step(torch.zeros(8, 64, device="cuda", dtype=torch.float64))
