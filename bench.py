@@ -162,6 +162,12 @@ def main():
         frames = float(B) * world * args.steps
         value = frames / dt
         achieved = kern_flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        try:  # HBM bytes per launch of the same kernel from the committed PMC passes (profiles/r01_traffic.json)
+            with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["traffic_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "audio frames/sec (fwd+bwd+step), 1024-sample frames",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -177,7 +183,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel TN/EPI_F32, %dx%d tile, split-K %d (weight-gradient "
                                                     "GEMM dW=dY^T X, M=1024 N=2048 K=4096; 2 launches/step)" % kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "us_per_launch": kern_ms * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:
