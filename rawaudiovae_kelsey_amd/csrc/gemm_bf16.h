@@ -38,8 +38,9 @@ struct GemmArgs {
   const bf16_t* A;
   const bf16_t* B;
   long lda, ldb;
-  int k_tiles;           // 64-deep K tiles per split (grid.z = splits)
-  int tiles_m, tiles_n;  // output tiles (grid.x = tiles_m * tiles_n)
+  int k_tiles;           // 64-deep K tiles per split
+  int tiles_m, tiles_n;  // output tiles
+  int splits;            // K splits (grid.x = tiles_m * tiles_n * splits)
   int M_valid, N_valid;  // unpadded extents (row/col masks in epilogues)
   int relu;              // EPI_BIAS_ACT_BF16: apply ReLU
   float* out_f32;
@@ -163,14 +164,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and
-  // b+8 share an L2), so give each XCD a contiguous run of tile ids: its tiles then share
-  // A row panels through that XCD's L2 instead of every XCD streaming every panel.
-  // Bijective for any grid size; a different placement only changes speed.
-  const int tiles_n = p.tiles_n, nwg = p.tiles_n * p.tiles_m;
+  // XCD-aware work order over the 1-D grid of (split, tile_m, tile_n) items: workgroups are
+  // dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so give each XCD a
+  // contiguous run of items -- one K split and a few tile rows -- whose A and B panels it then
+  // shares through its own L2 instead of every XCD streaming every panel.  Bijective for any
+  // grid size; a different placement only changes speed.
+  const int tiles_n = p.tiles_n, nt = p.tiles_n * p.tiles_m, nwg = nt * p.splits;
   const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  const int tid_lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int tile_m = tid_lin / tiles_n, tile_n = tid_lin - tile_m * tiles_n, split = blockIdx.z;
+  const int item = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int split = item / nt, tid_lin = item - split * nt;
+  const int tile_m = tid_lin / tiles_n, tile_n = tid_lin - tile_m * tiles_n;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const long k0 = (long)split * p.k_tiles * 64;
 

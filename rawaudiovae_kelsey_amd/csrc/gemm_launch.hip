@@ -33,7 +33,8 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   GemmArgs g = a;
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
+  g.splits = splits;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), smem, st, g);
   RV_CHECK_LAUNCH();
   return RV_OK;
