@@ -222,7 +222,9 @@ typedef struct rv_plan_buffers {
 #define RV_PHASE_BWD_B 4    /* heads dgrad/wgrad, fc1 wgrad                           */
 #define RV_PHASE_FINALIZE_A 8  /* fc3,fc4 slabs -> flat fp32 grad arena (bucket A: ready after BWD_A) */
 #define RV_PHASE_FINALIZE_B 32 /* fc1,fc21,fc22 slabs -> flat grad arena (bucket B)                  */
-#define RV_PHASE_ADAM 16       /* optimizer + bf16 shadow refresh                                    */
+#define RV_PHASE_ADAM 16       /* optimizer + bf16 shadow refresh (all ten tensors)                  */
+#define RV_PHASE_ADAM_A 64     /* ... only fc3, fc4 (bucket A)                                       */
+#define RV_PHASE_ADAM_B 128    /* ... only fc1, fc21, fc22 (bucket B)                                */
 #define RV_PHASE_ALL_LOCAL (1 | 2 | 4 | 16)
 
 int rv_plan_create(rv_plan** out, long B, long S, long H, long L);

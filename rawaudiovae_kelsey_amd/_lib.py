@@ -32,6 +32,7 @@ class PlanBuffers(C.Structure):
 
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
 PHASE_FINALIZE_A, PHASE_ADAM, PHASE_FINALIZE_B = 8, 16, 32
+PHASE_ADAM_A, PHASE_ADAM_B = 64, 128
 PHASE_ALL_LOCAL = PHASE_FWD | PHASE_BWD_A | PHASE_BWD_B | PHASE_ADAM
 ACT_NONE, ACT_RELU = 0, 1
 

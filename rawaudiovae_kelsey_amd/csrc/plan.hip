@@ -308,10 +308,16 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
     RV_TRY(rv_grad_finalize(p->d_slab, 6, p->b.grad, stream));
   }
-  if (phases & RV_PHASE_ADAM) {
+  if (phases & (RV_PHASE_ADAM | RV_PHASE_ADAM_A | RV_PHASE_ADAM_B)) {
     RV_REQUIRE(!adam_from_flat || p->b.grad, RV_ERR_STATE, "rv_plan_step: adam_from_flat needs a grad arena");
-    RV_TRY(rv_adam_multi(adam_from_flat ? p->d_flat : p->d_slab, 10, p->b.param, p->b.exp_avg, p->b.exp_avg_sq,
-                         nullptr, lr, grad_scale, p->b.step_counter, stream));
+    const rv_param_desc* d = adam_from_flat ? p->d_flat : p->d_slab;
+    const bool all = phases & RV_PHASE_ADAM;
+    if (all || (phases & RV_PHASE_ADAM_A))
+      RV_TRY(rv_adam_multi(d + 6, 4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                           p->b.step_counter, stream));
+    if (all || (phases & RV_PHASE_ADAM_B))
+      RV_TRY(rv_adam_multi(d, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                           p->b.step_counter, stream));
   }
 #undef RV_TRY
   return RV_OK;

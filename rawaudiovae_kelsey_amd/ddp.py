@@ -37,6 +37,11 @@ class GradSync:
         self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
                                              group=self.group, async_op=True))
 
+    def wait_one(self):
+        """Wait for the oldest launched bucket only."""
+        if self._pending:
+            self._pending.pop(0).wait()
+
     def wait(self):
         """Make the current stream (GPU) or the host (CPU/gloo) wait for all launched buckets."""
         for w in self._pending:
@@ -55,12 +60,21 @@ def engine_buckets(engine):
 
 
 def ddp_step(engine, sync, x, eps=None, stream=None):
-    """One data-parallel training step (train.py:184-193 across ranks)."""
-    from ._lib import (PHASE_ADAM, PHASE_BWD_A, PHASE_BWD_B, PHASE_FINALIZE_A, PHASE_FINALIZE_B,
-                       PHASE_FWD)
+    """One data-parallel training step (train.py:184-193 across ranks).
+
+    Timeline on the compute stream (RCCL runs on its own stream, ordered by events):
+        FWD, BWD_A, finalize A        -> all-reduce A (fc3, fc4) starts
+        BWD_B, finalize B             -> all-reduce B (fc1, heads) starts   [A overlaps this compute]
+        wait A, Adam(fc3, fc4)                                             [overlaps all-reduce B]
+        wait B, Adam(fc1, heads)
+    """
+    from ._lib import (PHASE_ADAM_A, PHASE_ADAM_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_FINALIZE_A,
+                       PHASE_FINALIZE_B, PHASE_FWD)
     engine.step(x, eps, phases=PHASE_FWD | PHASE_BWD_A | PHASE_FINALIZE_A, stream=stream)
-    sync.start(0)   # overlaps with the second half of backward
+    sync.start(0)
     engine.step(x, eps, phases=PHASE_BWD_B | PHASE_FINALIZE_B, stream=stream)
     sync.start(1)
+    sync.wait_one()
+    engine.step(x, eps, phases=PHASE_ADAM_A, grad_scale=sync.grad_scale, adam_from_flat=True, stream=stream)
     sync.wait()
-    engine.step(x, eps, phases=PHASE_ADAM, grad_scale=sync.grad_scale, adam_from_flat=True, stream=stream)
+    engine.step(x, eps, phases=PHASE_ADAM_B, grad_scale=sync.grad_scale, adam_from_flat=True, stream=stream)
