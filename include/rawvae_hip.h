@@ -49,7 +49,8 @@ int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, lo
  * GEMM is launched with a given split count; per-row-tile outputs (column-sum partials,
  * MSE partials) then have Mp/bm row tiles and Np/bn column tiles.
  * rv_gemm_force_tile: test hook, pins the tile configuration (0: 64x64, 1: 128x128,
- * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves) wherever it divides the extents; -1 = auto. */
+ * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves, 4: 128x128 with 8 waves, 5: 256x256)
+ * wherever it divides the extents; -1 = auto. */
 int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
 int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
 int rv_gemm_force_tile(int tile);
@@ -97,6 +98,19 @@ int rv_linear_dgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw
                     long Np, long Kp, const void* mask_bf16, long ldmask, void* dx_bf16,
                     long lddx, float* colsum_partial, float* dx_f32, long lddx32, int splits,
                     void* stream);
+
+/* Both halves of a Linear layer's backward in ONE launch when the extents allow 256x256 tiles
+ * (neither GEMM alone has enough such tiles to fill 256 CUs; together they do):
+ *   dx_bf16 [Mp,Np] = (x > 0) ? dY W : 0     with column-sum partials [Mp/bm][Np] (bias grads)
+ *   dw_slabs [splits][Kp][Np] = dY^T x        (split over the batch)
+ * dy [Mp(batch), Kp(out)], w [Kp, Np] ([out,in]), x [Mp, Np] = the layer's ReLU output (mask AND
+ * wgrad operand).  `splits` and `bm` must come from rv_dgrad_wgrad_pick(Mp, Np, Kp); when the
+ * pairing does not apply the call falls back to rv_linear_dgrad + rv_linear_wgrad. */
+int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits);
+int rv_linear_dgrad_wgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw,
+                          const void* x_bf16, long ldx, long Mp, long Np, long Kp, void* dx_bf16,
+                          long lddx, float* colsum_partial, float* dw_slabs, long lddw, int splits,
+                          void* stream);
 
 /* dW = dY^T X as `splits` fp32 partial slabs [Mp(out), Np(in)] (split over the batch).
  * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS

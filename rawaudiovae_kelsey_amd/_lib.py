@@ -44,6 +44,9 @@ _SIGS = {
     "rv_gemm_pick": (c_int, [c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 3),
     "rv_gemm_tile": (c_int, [c_long, c_long, c_int] + [C.POINTER(c_int)] * 2),
     "rv_gemm_force_tile": (c_int, [c_int]),
+    "rv_dgrad_wgrad_pick": (c_int, [c_long, c_long, c_long] + [C.POINTER(c_int)] * 3),
+    "rv_linear_dgrad_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
+                                      c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
@@ -156,6 +159,13 @@ def gemm_tile(Mp, Np, splits=1):
     """(bm, bn) block tile used for a GEMM launched with `splits` K splits."""
     o = [c_int() for _ in range(2)]
     lib().rv_gemm_tile(Mp, Np, splits, *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)
+
+
+def dgrad_wgrad_pick(Mp, Np, Kp):
+    """(paired, bm_dgrad, splits) for the fused backward of one Linear layer."""
+    o = [c_int() for _ in range(3)]
+    lib().rv_dgrad_wgrad_pick(Mp, Np, Kp, *[C.byref(v) for v in o])
     return tuple(v.value for v in o)
 
 

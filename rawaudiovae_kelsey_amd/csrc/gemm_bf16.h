@@ -67,32 +67,46 @@ __device__ __forceinline__ int swz_mn(int k) {
     return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);  // 4 x 32-B chunks per 128-B k-row
 }
 
-// Stage one ROWS x 64 operand tile into LDS with NW waves.  `g` is the tile origin.
+// Per-lane element offsets (from the tile origin) of the 16-byte pieces this lane stages for one
+// ROWS x 64 operand tile: computed once, so the K loop only adds a wave-uniform tile base
+// (scalar) to a 32-bit per-lane offset -- global_load_lds then uses its saddr+voffset form and
+// the loop carries one VGPR per piece instead of a 64-bit pointer.
 template <int ROWS, bool KMAJ, int NW>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, lds_char* lds,
-                                           int wave, int lane) {
-  constexpr int NINSTR = ROWS * 128 / 1024;  // 1-KiB wave-instructions per tile
+struct StageOffsets {
+  static constexpr int NINSTR = ROWS * 128 / 1024;  // 1-KiB wave-instructions per tile
+  static constexpr int PER_WAVE = NINSTR / NW;
   static_assert(NINSTR % NW == 0, "tile must split evenly over the waves");
+  unsigned off[PER_WAVE];
+
+  __device__ __forceinline__ void init(long ld, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < NINSTR / NW; ++i) {
-    const int t = wave + NW * i;
-    const bf16_t* src;
-    if constexpr (KMAJ) {
-      const int r = 8 * t + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      src = g + (long)r * ld + c * 8;
-    } else {
-      constexpr int LPR = ROWS * 2 / 16;  // lanes per k-row
-      const int kr = LPR >= 64 ? t / (LPR / 64) : t * (64 / LPR) + lane / LPR;
-      const int p16 = LPR >= 64 ? (t % (LPR / 64)) * 64 + lane : lane % LPR;
-      const int c32 = (p16 >> 1) ^ swz_mn<ROWS>(kr);
-      src = g + (long)kr * ld + (c32 * 2 + (p16 & 1)) * 8;
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int t = wave + NW * i;
+      if constexpr (KMAJ) {
+        const int r = 8 * t + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        off[i] = (unsigned)(r * (int)ld + c * 8);
+      } else {
+        constexpr int LPR = ROWS * 2 / 16;  // lanes per k-row
+        const int kr = LPR >= 64 ? t / (LPR / 64) : t * (64 / LPR) + lane / LPR;
+        const int p16 = LPR >= 64 ? (t % (LPR / 64)) * 64 + lane : lane % LPR;
+        const int c32 = (p16 >> 1) ^ swz_mn<ROWS>(kr);
+        off[i] = (unsigned)(kr * (int)ld + (c32 * 2 + (p16 & 1)) * 8);
+      }
     }
-    __builtin_amdgcn_global_load_lds((glb_cptr)src,
-                                     (__attribute__((address_space(3))) void*)(lds + t * 1024), 16,
-                                     0, 0);
   }
-}
+
+  // Stage the tile whose origin is the wave-uniform pointer `g` into the LDS slot `lds`.
+  __device__ __forceinline__ void stage(const bf16_t* __restrict__ g, lds_char* lds, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int t = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((glb_cptr)(g + (size_t)off[i]),
+                                       (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0,
+                                       0);
+    }
+  }
+};
 
 // One 16(rows) x 32(k) MFMA operand fragment: lane l holds rows row0+(l&15),
 // k = 32*kk + 8*(l>>4) + j, j = 0..7.
@@ -152,8 +166,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // The barrier publishes every wave's share of tile kt+1 and orders the refill after all
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
 template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
-__global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -170,7 +183,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
   // shares through its own L2 instead of every XCD streaming every panel.  Bijective for any
   // grid size; a different placement only changes speed.
   const int tiles_n = p.tiles_n, nt = p.tiles_n * p.tiles_m, nwg = nt * p.splits;
-  const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   const int item = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   const int split = item / nt, tid_lin = item - split * nt;
   const int tile_m = tid_lin / tiles_n, tile_n = tid_lin - tile_m * tiles_n;
@@ -188,12 +201,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  StageOffsets<BM, A_KMAJ, NW> sa;
+  StageOffsets<BN, B_KMAJ, NW> sb;
+  sa.init(p.lda, wave, lane);
+  sb.init(p.ldb, wave, lane);
+
   const int nk = p.k_tiles;
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < nk) {
-      stage_tile<BM, A_KMAJ, NW>(Ag + s * a_step, p.lda, smem + s * STAGE, wave, lane);
-      stage_tile<BN, B_KMAJ, NW>(Bg + s * b_step, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
+      sa.stage(Ag + s * a_step, smem + s * STAGE, wave);
+      sb.stage(Bg + s * b_step, smem + s * STAGE + A_BYTES, wave);
     }
   // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
   wait_tiles_in_flight<GL>(nk - 1 < NSTAGE - 1 ? nk - 1 : NSTAGE - 1);
@@ -239,8 +257,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
       __builtin_amdgcn_s_barrier();
       if (kt + NSTAGE < nk) {
         lds_char* rf = smem + slot * STAGE;
-        stage_tile<BM, A_KMAJ, NW>(Ag + (long)(kt + NSTAGE) * a_step, p.lda, rf, wave, lane);
-        stage_tile<BN, B_KMAJ, NW>(Bg + (long)(kt + NSTAGE) * b_step, p.ldb, rf + A_BYTES, wave, lane);
+        sa.stage(Ag + (long)(kt + NSTAGE) * a_step, rf, wave);
+        sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + A_BYTES, wave);
       }
       const lds_char* nxt = smem + nslot * STAGE;
 #pragma unroll
@@ -269,18 +287,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
   constexpr int LDW = WTN + 4;    // padded row: fragment writes 2-way conflict at most
   constexpr int LPRW = WTN / 8;   // lanes per row of the wave tile (8 columns each)
   constexpr int RPP = 64 / LPRW;  // rows per pass
-  constexpr int IT = WTM / RPP;   // passes
+  constexpr int ER = WTM < 64 ? WTM : 64;  // wave-tile rows staged per round (bounds the LDS area)
+  constexpr int IT = ER / RPP;    // passes per round
   constexpr int CH = IT < 8 ? IT : 8;  // passes per chunk (bounds live registers)
-  static_assert(NW * WTM * LDW * 4 <= NSTAGE * STAGE, "epilogue staging must fit in the ring");
-  float* ep = (float*)smem_generic + wave * (WTM * LDW);
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ep[(mi * 16 + (lane >> 4) * 4 + j) * LDW + ni * 16 + (lane & 15)] = acc[mi][ni][j];
-  // same-wave LDS hand-off: the hardware keeps a wave's DS ops in order.
+  float* ep = (float*)smem_generic + wave * (ER * LDW);
 
   const int er = lane / LPRW, ec = (lane % LPRW) * 8;  // row within the pass, first of 8 columns
   const long col = n0 + wn * WTN + ec;
@@ -304,6 +314,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
   const bool vec_x = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && col + 8 <= p.N_valid &&
                      ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
+#pragma unroll
+  for (int rd = 0; rd < WTM / ER; ++rd) {
+  // stage this round's ER rows of the wave tile (same-wave LDS hand-off: a wave's DS ops
+  // execute in order, so the previous round's reads are done before these writes land)
+#pragma unroll
+  for (int mi = 0; mi < ER / 16; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ep[(mi * 16 + (lane >> 4) * 4 + j) * LDW + ni * 16 + (lane & 15)] = acc[rd * (ER / 16) + mi][ni][j];
 #pragma unroll 1
   for (int c0 = 0; c0 < IT; c0 += CH) {
     float v[CH][8];
@@ -314,7 +335,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
     }
-    const long rowc = row0 + (long)c0 * RPP;
+    const long rowc = row0 + (long)rd * ER + (long)c0 * RPP;
 
     if constexpr (EPI == EPI_BIAS_ACT_BF16) {
 #pragma unroll
@@ -410,6 +431,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
     }
   }
 
+  }  // rounds
+
   if constexpr (EPI == EPI_TANH_LOSS || EPI == EPI_MASK_BF16) {
     if (p.colsum) {
       // lanes with equal (lane % LPRW) own the same 8 columns: butterfly over the row bits
@@ -443,6 +466,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
       }
     }
   }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  gemm_body<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI, NSTAGE>(p, blockIdx.x, smem_dyn);
+}
+
+// Two independent GEMMs in ONE launch (blocks [0, n_first) run the first): neither of the
+// paired problems has enough 256x256 output tiles to fill 256 CUs on its own, together they do.
+// Used for the backward of a Linear layer: dX = relu'(dY W) (NN) and dW = dY^T X (TN).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+__global__ void __launch_bounds__(64 * WGM * WGN)
+gemm_dgrad_wgrad_kernel(const GemmArgs dgrad, const GemmArgs wgrad, const int n_first) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  if ((int)blockIdx.x < n_first)
+    gemm_body<BM, BN, WGM, WGN, true, false, EPI_MASK_BF16, NSTAGE>(dgrad, blockIdx.x, smem_dyn);
+  else
+    gemm_body<BM, BN, WGM, WGN, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x - n_first, smem_dyn);
 }
 
 }  // namespace rv

@@ -13,6 +13,8 @@ namespace {
 //   3: 256x128 2x2 waves of 128x64, 3 stages (144 KiB) one wave per SIMD, half the LDS reads
 //   4: 128x128 2x4 waves of 64x32, 4 stages (128 KiB)  two waves per SIMD; default 128x128
 //      (measured 4-10 % faster than config 1 on every 128-tile GEMM of the step)
+//   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring, 136 KiB with epilogue staging); only
+//      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
 int g_force_tile = -1;
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI>
@@ -21,7 +23,8 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
   constexpr int stage_bytes = (BM + BN) * 128;
-  constexpr int epi_bytes = WGM * WGN * (BM / WGM) * (BN / WGN + 4) * 4;
+  constexpr int epi_rows = (BM / WGM) < 64 ? (BM / WGM) : 64;  // rows staged per epilogue round
+  constexpr int epi_bytes = WGM * WGN * epi_rows * (BN / WGN + 4) * 4;
   const int used = (a.k_tiles < NSTAGE ? a.k_tiles : NSTAGE) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE>;
@@ -52,13 +55,14 @@ bool tile_fits(int tile, long Mp, long Np) {
     case 1: return Mp % 128 == 0 && Np % 128 == 0;
     case 2: case 3: return Mp % 256 == 0 && Np % 128 == 0;
     case 4: return Mp % 128 == 0 && Np % 128 == 0;
+    case 5: return Mp % 256 == 0 && Np % 256 == 0;
     default: return false;
   }
 }
 
 void tile_dims(int tile, int* bm, int* bn) {
   *bm = tile == 0 ? 64 : (tile == 1 || tile == 4) ? 128 : 256;
-  *bn = tile == 0 ? 64 : 128;
+  *bn = tile == 0 ? 64 : tile == 5 ? 256 : 128;
 }
 
 template <bool AK, bool BK, int EPI>
@@ -74,6 +78,7 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
     case 1: return launch<128, 128, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 2: return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 4: return launch<128, 128, 2, 4, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 5: return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
     default: return launch<256, 128, 2, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
   }
 }
@@ -200,6 +205,72 @@ int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp,
   a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.out_f32 = dw; a.ld_f32 = lddw; a.split_stride_f32 = Mp * lddw;
   return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+
+// ---- paired backward of one Linear layer: dX = relu'(dY W) and dW = dY^T X in one launch ----
+// dy [Mp(batch), Kp(out features)], w [Kp, Np] ([out,in]), x [Mp, Np] is BOTH the ReLU output that
+// masks dX and the right operand of dW.  dW[Kp, Np] leaves as `splits` slabs over the batch.
+int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 64 == 0 && Np % 64 == 0 && Kp % 64 == 0, RV_ERR_SHAPE,
+             "rv_dgrad_wgrad_pick: extents must be positive multiples of 64");
+  const bool fits = Mp % 256 == 0 && Np % 256 == 0 && Kp % 256 == 0;
+  int pr = 0, bm = 0, sp = 1;
+  if (fits && (g_force_tile == 5 || g_force_tile < 0)) {
+    const long t_d = (Mp / 256) * (Np / 256), t_w = (Kp / 256) * (Np / 256);
+    // wgrad splits: even out the K work per block (dgrad blocks loop over Kp, wgrad blocks over Mp/sp)
+    while (2 * sp <= 16 && (Mp / 64) % (2 * sp) == 0 && Mp / (2 * sp) >= Kp && Mp / (2 * sp) >= 128) sp *= 2;
+    if (g_force_tile == 5 || (t_d + t_w * sp >= 192 && t_d + t_w * sp <= 320)) { pr = 1; bm = 256; }
+  }
+  if (!pr) {
+    int bn;
+    tile_dims(choose_tile(Mp, Np, 1), &bm, &bn);
+    rv_gemm_pick(Kp, Np, Mp, 16, nullptr, nullptr, &sp);
+  }
+  if (paired) *paired = pr;
+  if (bm_dgrad) *bm_dgrad = bm;
+  if (splits) *splits = sp;
+  return RV_OK;
+}
+
+int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
+                          long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
+                          float* dw_slabs, long lddw, int splits, void* stream) {
+  RV_REQUIRE(dy && w && x && dx_bf16 && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad: null operand");
+  int paired, bm, sp;
+  int rc = rv_dgrad_wgrad_pick(Mp, Np, Kp, &paired, &bm, &sp);
+  if (rc) return rc;
+  RV_REQUIRE(sp == splits, RV_ERR_STATE, "rv_linear_dgrad_wgrad: caller passed %d splits, rv_dgrad_wgrad_pick says %d",
+             splits, sp);
+  if (!paired) {
+    rc = rv_linear_dgrad(dy, lddy, w, ldw, Mp, Np, Kp, x, ldx, dx_bf16, lddx, colsum_partial, nullptr, 0, 1, stream);
+    if (rc) return rc;
+    return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, splits, dw_slabs, lddw, stream);
+  }
+  RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: leading dims must be multiples of 8");
+  RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: operands must be 16-byte aligned");
+  constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, NSTAGE = 2;
+  GemmArgs d{}, g{};
+  d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
+  d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
+  d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+  d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1;
+  g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
+  g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
+  g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
+  g.tiles_m = (int)(Kp / BM); g.tiles_n = (int)(Np / BN); g.splits = splits;
+  const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * splits;
+  constexpr int ring = NSTAGE * (BM + BN) * 128, epi = WGM * WGN * 64 * (BN / WGN + 4) * 4;
+  constexpr int smem = ring > epi ? ring : epi;
+  auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_d + n_w)), dim3(64 * WGM * WGN), smem, (hipStream_t)stream, d, g, n_d);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
 }
 
 }  // extern "C"

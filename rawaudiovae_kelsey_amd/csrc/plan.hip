@@ -37,7 +37,7 @@ int row_tiles(long Mp, long Np) {
 struct rv_plan {
   long B, S, H, L, Bp, Sp, Hp, Lp, L2p;
   int s_heads, s_dz, s_w4, s_w3, s_wh, s_w1;  // split-K factors
-  int n_mse, n_kl, n_mt4, n_mt3;              // partial counts (row tiles of the producing GEMMs)
+  int n_mse, n_kl, n_mt4, n_mt3, n_mt1;       // partial counts (row tiles of the producing GEMMs)
   long off[10];                               // element offsets of the 10 params in the flat arenas
   long n_params;
   std::vector<Buf> bufs;
@@ -78,13 +78,19 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   p->s_heads = splits_of(Bp, L2p, Hp);
   p->s_dz = splits_of(Bp, Lp, Hp);
-  p->s_w4 = splits_of(Sp, Hp, Bp);
+  {
+    // fc4 backward runs as one paired launch (dgrad + wgrad) when 256x256 tiles apply
+    int paired = 0, bm = 128, sp = 1;
+    rv_dgrad_wgrad_pick(Bp, Hp, Sp, &paired, &bm, &sp);
+    p->s_w4 = sp;
+    p->n_mt3 = (int)(Bp / bm);
+  }
   p->s_w3 = splits_of(Hp, Lp, Bp);
   p->s_wh = splits_of(L2p, Hp, Bp);
   p->s_w1 = splits_of(Hp, Sp, Bp);
   // per-row-tile partial counts follow the tile each producing GEMM will use
   p->n_mt4 = row_tiles(Bp, Sp);   // fc4 fwd: dP4 column sums (db4) and MSE partials
-  p->n_mt3 = row_tiles(Bp, Hp);   // fc4 dgrad (db3) and heads dgrad (db1): both Bp x Hp
+  p->n_mt1 = row_tiles(Bp, Hp);   // heads dgrad: dP1 column sums (db1)
   {
     int bm = 128, bn = 128;
     rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
@@ -120,7 +126,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dWh", (long)p->s_wh * L2p * Hp * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
-  p->add("db1p", (long)p->n_mt3 * Hp * 4);
+  p->add("db1p", (long)p->n_mt1 * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
   p->add("db4p", (long)p->n_mt4 * Sp * 4);
@@ -172,11 +178,11 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   char* W1b = p->ws("W1b"); char* Whb = p->ws("Whb"); char* W3b = p->ws("W3b"); char* W4b = p->ws("W4b");
   float* b1p = (float*)p->ws("b1p"); float* bhp = (float*)p->ws("bhp");
   float* b3p = (float*)p->ws("b3p"); float* b4p = (float*)p->ws("b4p");
-  const int n_mt3 = p->n_mt3, n_mt4 = p->n_mt4, n_b64 = (int)(Bp / 16);  // reparam_bwd: one partial row per 16 batch rows
+  const int n_mt3 = p->n_mt3, n_mt1 = p->n_mt1, n_mt4 = p->n_mt4, n_b64 = (int)(Bp / 16);  // reparam_bwd: one partial row per 16 batch rows
   //                 offset     rows cols slabs        ld   split_stride  splits     bf16 shadow          f32 shadow  ld
   rv_param_desc d[10] = {
       {p->off[0], H, S, dW1, Sp, Hp * Sp, p->s_w1, W1b, nullptr, Sp},
-      {p->off[1], 1, H, db1, Hp, Hp, n_mt3, nullptr, b1p, Hp},
+      {p->off[1], 1, H, db1, Hp, Hp, n_mt1, nullptr, b1p, Hp},
       {p->off[2], L, H, dWh, Hp, L2p * Hp, p->s_wh, Whb, nullptr, Hp},
       {p->off[3], 1, L, dbh, L2p, L2p, n_b64, nullptr, bhp, L2p},
       {p->off[4], L, H, dWh + Lp * Hp, Hp, L2p * Hp, p->s_wh, Whb + Lp * Hp * 2, nullptr, Hp},
@@ -251,17 +257,15 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                               (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
                           !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
   if (full_local && p->concurrent && stream) {
-    // Two-stream backward.  Main stream: the dependent chain dgrad fc4 -> dz -> reparam_bwd ->
-    // dgrad heads -> wgrad fc1 -> Adam(fc1, heads).  Side stream: wgrad fc4 -> wgrad fc3 ->
+    // Two-stream backward.  Main stream: the dependent chain fc4 backward (paired dgrad+wgrad) ->
+    // dz -> reparam_bwd -> dgrad heads -> wgrad fc1 -> Adam(fc1, heads).  Side stream: wgrad fc3 ->
     // wgrad heads -> Adam(fc3, fc4), each gated by an event on the tensor it consumes.
     hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
     void* v1 = (void*)s1;
-    RV_HIP(hipEventRecord(p->ev[0], s0));  // forward done: dP4, h3, z, mulv ready
-    RV_HIP(hipStreamWaitEvent(s1, p->ev[0], 0));
-    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"),
-                           nullptr, 0, 1, stream));
-    RV_HIP(hipEventRecord(p->ev[1], s0));  // dP3, db3 ready; W4b no longer read
-    RV_TRY(rv_linear_wgrad(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, (float*)p->ws("dW4"), Hp, v1));
+    (void)p->ev[0];
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_HIP(hipEventRecord(p->ev[1], s0));  // dP3, db3, dW4 ready; W4b no longer read
     RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
                            p->s_dz, stream));
     RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
@@ -284,9 +288,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     return RV_OK;
   }
   if (phases & RV_PHASE_BWD_A) {
-    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"),
-                           nullptr, 0, 1, stream));
-    RV_TRY(rv_linear_wgrad(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, (float*)p->ws("dW4"), Hp, stream));
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
     RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
                            p->s_dz, stream));
     RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));

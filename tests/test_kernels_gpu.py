@@ -80,7 +80,7 @@ def test_linear_dgrad_f32(L, M, N, K, splits):
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "t64", "t128", "t256w8", "t256w4"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5], ids=["auto", "t64", "t128w4", "t256x128w8", "t256x128w4", "t128w8", "t256x256"])
 def tile(request, L):
     """Pin each block-tile configuration in turn (256-row tiles only apply when M % 256 == 0)."""
     L.rv_gemm_force_tile(request.param)
@@ -337,3 +337,31 @@ def test_gather_frames_matches_audio_dataset_semantics(L):
     out2 = torch.zeros(ev.shape, device="cuda")
     L.rv_gather_frames(ed.data_ptr(), ev.size, None, 0, ev.shape[0], 100, 100, out2.data_ptr(), sp())
     np.testing.assert_array_equal(out2.cpu().numpy(), ev)
+
+
+@pytest.mark.parametrize("force", [5, -1])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (1024, 512, 256), (768, 256, 512)])
+def test_paired_dgrad_wgrad(L, force, M, N, K):
+    """rv_linear_dgrad_wgrad: dX = relu'(dY W) and dW = dY^T X from ONE launch (256x256 tiles, forced)
+    and through its unpaired fallback; M = batch, K = out features, N = in features."""
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
+    L.rv_gemm_force_tile(force)
+    try:
+        rng = np.random.default_rng(41)
+        dy, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N), 0.1)
+        x = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
+        paired, bm, splits = dgrad_wgrad_pick(M, N, K)
+        assert paired == (1 if force == 5 else 0)
+        DY, W, X = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+        dx = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
+        dw = torch.full((splits, K, N), 7.0, dtype=torch.float32, device="cuda")
+        L.rv_linear_dgrad_wgrad(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N,
+                                cs.data_ptr(), dw.data_ptr(), N, splits, sp())
+        ref_dx = (dy.astype(np.float64) @ w.astype(np.float64)) * (x > 0)
+        ref_dw = dy.astype(np.float64).T @ x.astype(np.float64)
+        assert np.abs(dx.float().cpu().numpy() - ref_dx).max() <= 2 ** -7 * np.abs(ref_dx).max()
+        np.testing.assert_allclose(cs.sum(0).cpu().numpy(), ref_dx.sum(0), rtol=1e-4, atol=1e-4 * np.abs(ref_dx.sum(0)).max())
+        np.testing.assert_allclose(dw.sum(0).cpu().numpy(), ref_dw, rtol=1e-5, atol=1e-5 * np.abs(ref_dw).max())
+    finally:
+        L.rv_gemm_force_tile(-1)

@@ -40,6 +40,8 @@ msep = torch.empty(1024, dtype=torch.float32, device="cuda")
 SPL = {k: int(os.environ.get("SPL_" + k, v)) for k, v in dict(heads=8, dz=4, w4=2, w3=8, wh=16, w1=2).items()}
 
 P = lambda t: t.data_ptr()
+from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick  # noqa: E402
+PAIR_S = dgrad_wgrad_pick(B, H, S)[2]
 cases = {
     "fc1 fwd   4096x2048x1024 NT": (2 * B * H * S, lambda: Lb.rv_linear_fwd(P(x), LD(S), P(W1), LD(S), P(bH), B, H, S, 1, P(outH), H, st)),
     "heads fwd 4096x128x2048  NT": (2 * B * L2 * H, lambda: Lb.rv_linear_fwd_f32(P(h), H, P(Wh), H, P(bL2), B, L2, H, SPL["heads"], P(f32buf), L2, st)),
@@ -47,6 +49,7 @@ cases = {
     "fc4 fwd+loss 4096x1024x2048": (2 * B * S * H, lambda: Lb.rv_decode_out_loss_fwd(P(h), H, P(W4), H, P(bS), B, S, H, B, S, P(xf), S, None, S, P(outS), S, P(msep), P(cs), st)),
     "dgrad fc4 4096x2048x1024 NN": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), S, P(W4), H, B, H, S, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
     "wgrad fc4 1024x2048x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(dp4), LD(S), P(h), LD(H), S, H, B, SPL["w4"], P(f32buf), H, st)),
+    "PAIR dgrad+wgrad fc4 (34.4GF)": (4 * B * H * S, lambda: Lb.rv_linear_dgrad_wgrad(P(dp4), LD(S), P(W4), LD(H), P(h), LD(H), B, H, S, P(outH), H, P(cs), P(f32buf), H, PAIR_S, st)),
     "dz        4096x64x2048   NN": (2 * B * L * H, lambda: Lb.rv_linear_dgrad(P(h), H, P(W3), L, B, L, H, None, 0, None, 0, None, P(f32buf), L, SPL["dz"], st)),
     "wgrad fc3 2048x64x4096   TN": (2 * B * L * H, lambda: Lb.rv_linear_wgrad(P(h), H, P(z), L, H, L, B, SPL["w3"], P(f32buf), L, st)),
     "dgrad hd  4096x2048x128  NN": (2 * B * H * L2, lambda: Lb.rv_linear_dgrad(P(dmulv), L2, P(Wh), H, B, H, L2, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
