@@ -13,8 +13,8 @@ device-resident batches is cycled); eps is drawn on-device.  One process per GPU
 with N > 1 the fp32 gradients are all-reduced over RCCL in two buckets, the first
 overlapped with the rest of backward (weak scaling: per-GPU batch fixed).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the TN weight-
-gradient GEMM, launched twice per step), timed live with HIP events; `cpu_baseline`
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the paired fc4
+backward GEMM launch, the longest kernel of the step), timed live with HIP events; `cpu_baseline`
 is the stock-PyTorch CPU port of the same step (oracle/torch_port.py) timed on this
 node's host cores (N=1 only).
 """
@@ -47,23 +47,29 @@ def parse():
 
 
 def time_dominant_kernel(eng, reps=50):
-    """Average duration of the TN wgrad GEMM (dW4 = dP4^T h3: M=S, N=H, K=B) with HIP
-    events on the launching stream.  Returns (ms_per_launch, flops_per_launch)."""
+    """Average duration of the step's longest kernel -- the paired fc4 backward
+    (`gemm_dgrad_wgrad_kernel`: dP3 = relu'(dP4 W4) and dW4 = dP4^T h3 in one launch, 256x256 tiles)
+    -- with HIP events on the launching stream, on the step's own operands.
+    Returns (ms_per_launch, algorithmic flops per launch, description)."""
     import torch
-    from rawaudiovae_kelsey_amd._lib import gemm_pick, lib, stream_ptr
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick, lib, stream_ptr
     Lb = lib()
     Bp, Sp, Hp, Lp = eng.padded()
     dP4 = eng.buffer("dP4", torch.bfloat16, (Bp, Sp))
     h3 = eng.buffer("h3", torch.bfloat16, (Bp, Hp))
-    bm, bn, splits = gemm_pick(Sp, Hp, Bp)  # the tile / split-K the training step itself uses
-    out = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
+    W4b = eng.buffer("W4b", torch.bfloat16, (Sp, Hp))
+    paired, bm, splits = dgrad_wgrad_pick(Bp, Hp, Sp)   # what the training step itself uses
+    dP3 = torch.empty((Bp, Hp), dtype=torch.bfloat16, device="cuda")
+    cs = torch.empty((Bp // bm) * Hp, dtype=torch.float32, device="cuda")
+    dW4 = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
     st = stream_ptr()
     e0, e1 = C.c_void_p(), C.c_void_p()
     Lb.rv_event_create(C.byref(e0))
     Lb.rv_event_create(C.byref(e1))
 
     def launch():
-        Lb.rv_linear_wgrad(dP4.data_ptr(), Sp, h3.data_ptr(), Hp, Sp, Hp, Bp, splits, out.data_ptr(), Hp, st)
+        Lb.rv_linear_dgrad_wgrad(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, Bp, Hp, Sp,
+                                 dP3.data_ptr(), Hp, cs.data_ptr(), dW4.data_ptr(), Hp, splits, st)
     for _ in range(5):
         launch()
     Lb.rv_event_record(e0, st)
@@ -74,7 +80,10 @@ def time_dominant_kernel(eng, reps=50):
     Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
     Lb.rv_event_destroy(e0)
     Lb.rv_event_destroy(e1)
-    return ms.value / reps, 2.0 * S * H * B, (bm, bn, splits)
+    desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
+            "dW=dY^T X 1024x2048x4096 split-K %d)" % splits) if paired else \
+        "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
+    return ms.value / reps, 4.0 * S * H * B, desc
 
 
 def main():
@@ -180,8 +189,7 @@ def main():
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "final_loss": last[-1],
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel TN/EPI_F32, %dx%d tile, split-K %d (weight-gradient "
-                                                    "GEMM dW=dY^T X, M=1024 N=2048 K=4096; 2 launches/step)" % kern_cfg,
+            "roofline": {"bound": "mfma", "kernel": kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "us_per_launch": kern_ms * 1e3},
