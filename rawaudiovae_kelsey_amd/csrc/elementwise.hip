@@ -512,6 +512,26 @@ k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_are
   const long o = d.offset + r * d.cols + c;
   const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
+  // issue the optimizer-state loads first so they are in flight under the slab sums
+  float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (UPDATE) {
+    if (!coop || (threadIdx.x & 63) == 0) {
+      if (vec) {
+        const float4 m4 = *reinterpret_cast<const float4*>(m_arena + o);
+        const float4 v4 = *reinterpret_cast<const float4*>(v_arena + o);
+        const float4 w4 = *reinterpret_cast<const float4*>(param + o);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+      } else {
+        for (int j = 0; j < nvalid; ++j) {
+          mv[j] = m_arena[o + j];
+          vv[j] = v_arena[o + j];
+          wv[j] = param[o + j];
+        }
+      }
+    }
+  }
   float4 g;
   if (coop) {
     // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
@@ -536,25 +556,11 @@ k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_are
       for (int j = 0; j < nvalid; ++j) grad_out[o + j] = gv[j];
   }
   if constexpr (UPDATE) {
+    // bias corrections 1-b^t through the hardware exp2 (b^t = 2^(t log2 b)); relative error ~1e-6
     const float tt = (float)(*step_counter);
-    const float bc1 = 1.0f - powf(0.9f, tt);
-    const float bc2s = sqrtf(1.0f - powf(0.999f, tt));
+    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);      // log2(0.9)
+    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));  // log2(0.999)
     const float step_size = lr / bc1;
-    float mv[4], vv[4], wv[4];
-    if (vec) {
-      const float4 m4 = *reinterpret_cast<const float4*>(m_arena + o);
-      const float4 v4 = *reinterpret_cast<const float4*>(v_arena + o);
-      const float4 w4 = *reinterpret_cast<const float4*>(param + o);
-      mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-      vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
-      wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
-    } else {
-      for (int j = 0; j < 4; ++j) {
-        mv[j] = j < nvalid ? m_arena[o + j] : 0.f;
-        vv[j] = j < nvalid ? v_arena[o + j] : 0.f;
-        wv[j] = j < nvalid ? param[o + j] : 0.f;
-      }
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
