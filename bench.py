@@ -10,8 +10,8 @@ Workload (BASELINE.json configs[1] / configs[2]): S=1024, H=2048, L=64, per-GPU 
 4096, bf16 MFMA inputs with fp32 accumulation, fp32 master weights and Adam state.
 A step is one pass of the hot path over one resident batch (a pool of 8 distinct
 device-resident batches is cycled); eps is drawn on-device.  One process per GPU;
-with N > 1 the fp32 gradients are all-reduced over RCCL in two buckets, the first
-overlapped with the rest of backward (weak scaling: per-GPU batch fixed).
+with N > 1 the fp32 gradients are all-reduced over RCCL in three buckets (fc4, fc1, rest)
+issued as they become available in backward (weak scaling: per-GPU batch fixed).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the paired fc4
 backward GEMM launch, the longest kernel of the step), timed live with HIP events; `cpu_baseline`
@@ -185,7 +185,7 @@ def main():
             "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
-                       "grad_allreduce": "fp32, 2 buckets" if world > 1 else None},
+                       "grad_allreduce": "fp32, 3 buckets (fc4 | fc1 | rest) overlapped with backward" if world > 1 else None},
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "final_loss": last[-1],

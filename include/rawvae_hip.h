@@ -232,13 +232,23 @@ typedef struct rv_plan_buffers {
 } rv_plan_buffers;
 
 #define RV_PHASE_FWD 1      /* cast, fc1, heads, reparam, fc3, fc4+loss              */
-#define RV_PHASE_BWD_A 2    /* fc4 dgrad/wgrad, fc3 wgrad/dgrad, reparam bwd          */
+#define RV_PHASE_BWD_A 2    /* fc4 backward (paired dgrad+wgrad), dz, reparam bwd, fc3 wgrad */
 #define RV_PHASE_BWD_B 4    /* heads dgrad/wgrad, fc1 wgrad                           */
-#define RV_PHASE_FINALIZE_A 8  /* fc3,fc4 slabs -> flat fp32 grad arena (bucket A: ready after BWD_A) */
-#define RV_PHASE_FINALIZE_B 32 /* fc1,fc21,fc22 slabs -> flat grad arena (bucket B)                  */
-#define RV_PHASE_ADAM 16       /* optimizer + bf16 shadow refresh (all ten tensors)                  */
-#define RV_PHASE_ADAM_A 64     /* ... only fc3, fc4 (bucket A)                                       */
-#define RV_PHASE_ADAM_B 128    /* ... only fc1, fc21, fc22 (bucket B)                                */
+#define RV_PHASE_FINALIZE_A 8  /* fc3,fc4 slabs -> flat fp32 grad arena                */
+#define RV_PHASE_FINALIZE_B 32 /* fc1,fc21,fc22 slabs -> flat grad arena               */
+#define RV_PHASE_ADAM 16       /* optimizer + bf16 shadow refresh (all ten tensors)    */
+#define RV_PHASE_ADAM_A 64     /* ... only fc3, fc4                                    */
+#define RV_PHASE_ADAM_B 128    /* ... only fc1, fc21, fc22                             */
+/* finer split, in gradient-availability order (data-parallel buckets: fc4 | fc1 | the rest):  */
+#define RV_PHASE_BWD_FC4 0x0100   /* fc4 backward: fc4.w, fc4.b, fc3.b gradients ready         */
+#define RV_PHASE_BWD_CHAIN 0x0200 /* dz, reparam bwd, heads dgrad, fc1 wgrad: fc1.*, head biases */
+#define RV_PHASE_BWD_REST 0x0400  /* fc3 wgrad, heads wgrad                                    */
+#define RV_PHASE_FIN_FC4 0x0800
+#define RV_PHASE_FIN_FC1 0x1000
+#define RV_PHASE_FIN_MID 0x2000   /* fc21, fc22, fc3                                           */
+#define RV_PHASE_ADAM_FC4 0x4000
+#define RV_PHASE_ADAM_FC1 0x8000
+#define RV_PHASE_ADAM_MID 0x10000
 #define RV_PHASE_ALL_LOCAL (1 | 2 | 4 | 16)
 
 int rv_plan_create(rv_plan** out, long B, long S, long H, long L);

@@ -33,6 +33,10 @@ class PlanBuffers(C.Structure):
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
 PHASE_FINALIZE_A, PHASE_ADAM, PHASE_FINALIZE_B = 8, 16, 32
 PHASE_ADAM_A, PHASE_ADAM_B = 64, 128
+PHASE_BWD_FC4, PHASE_BWD_CHAIN, PHASE_BWD_REST = 0x100, 0x200, 0x400
+PHASE_FIN_FC4, PHASE_FIN_FC1, PHASE_FIN_MID = 0x800, 0x1000, 0x2000
+PHASE_ADAM_FC4, PHASE_ADAM_FC1, PHASE_ADAM_MID = 0x4000, 0x8000, 0x10000
+PHASE_ANY_ADAM = PHASE_ADAM | PHASE_ADAM_A | PHASE_ADAM_B | PHASE_ADAM_FC4 | PHASE_ADAM_FC1 | PHASE_ADAM_MID
 PHASE_ALL_LOCAL = PHASE_FWD | PHASE_BWD_A | PHASE_BWD_B | PHASE_ADAM
 ACT_NONE, ACT_RELU = 0, 1
 

@@ -287,40 +287,61 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                          p->b.step_counter, stream));
     return RV_OK;
   }
-  if (phases & RV_PHASE_BWD_A) {
+  // ---- backward / finalize / Adam as an ordered list of steps, each enabled by the phase mask ----
+  const bool old_a = phases & RV_PHASE_BWD_A, old_b = phases & RV_PHASE_BWD_B;
+  const bool do_pair = old_a || (phases & RV_PHASE_BWD_FC4);
+  const bool do_chain_a = old_a || (phases & RV_PHASE_BWD_CHAIN);   // dz, reparam_bwd
+  const bool do_chain_b = old_b || (phases & RV_PHASE_BWD_CHAIN);   // heads dgrad, fc1 wgrad
+  const bool do_w3 = old_a || (phases & RV_PHASE_BWD_REST);
+  const bool do_wh = old_b || (phases & RV_PHASE_BWD_REST);
+  if (do_pair)
     RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                  (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+  if (do_chain_a) {
     RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
                            p->s_dz, stream));
-    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
     RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
                           (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
                           p->b.step_counter, p->b.ring, stream));
   }
-  if (phases & RV_PHASE_FINALIZE_A) {
-    RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
-    RV_TRY(rv_grad_finalize(p->d_slab + 6, 4, p->b.grad, stream));
-  }
-  if (phases & RV_PHASE_BWD_B) {
+  if (do_chain_b) {
     RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
                            nullptr, 0, 1, stream));
-    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
     RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
   }
-  if (phases & RV_PHASE_FINALIZE_B) {
-    RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
-    RV_TRY(rv_grad_finalize(p->d_slab, 6, p->b.grad, stream));
+  if (do_w3) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
+  if (do_wh) RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+
+  // tensor masks (bit i = parameter i in state_dict order)
+  unsigned fin = 0, adam = 0;
+  if (phases & RV_PHASE_FINALIZE_A) fin |= 0x3C0;  // fc3, fc4
+  if (phases & RV_PHASE_FINALIZE_B) fin |= 0x03F;  // fc1, fc21, fc22
+  if (phases & RV_PHASE_FIN_FC4) fin |= 0x300;
+  if (phases & RV_PHASE_FIN_FC1) fin |= 0x003;
+  if (phases & RV_PHASE_FIN_MID) fin |= 0x0FC;
+  if (phases & RV_PHASE_ADAM) adam |= 0x3FF;
+  if (phases & RV_PHASE_ADAM_A) adam |= 0x3C0;
+  if (phases & RV_PHASE_ADAM_B) adam |= 0x03F;
+  if (phases & RV_PHASE_ADAM_FC4) adam |= 0x300;
+  if (phases & RV_PHASE_ADAM_FC1) adam |= 0x003;
+  if (phases & RV_PHASE_ADAM_MID) adam |= 0x0FC;
+  if (fin) RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
+  if (adam) RV_REQUIRE(!adam_from_flat || p->b.grad, RV_ERR_STATE, "rv_plan_step: adam_from_flat needs a grad arena");
+  const rv_param_desc* ad = adam_from_flat ? p->d_flat : p->d_slab;
+  for (int i = 0; i < 10;) {   // contiguous runs of selected tensors -> one launch each
+    if (!((fin >> i) & 1)) { ++i; continue; }
+    int j = i;
+    while (j < 10 && ((fin >> j) & 1)) ++j;
+    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, p->b.grad, stream));
+    i = j;
   }
-  if (phases & (RV_PHASE_ADAM | RV_PHASE_ADAM_A | RV_PHASE_ADAM_B)) {
-    RV_REQUIRE(!adam_from_flat || p->b.grad, RV_ERR_STATE, "rv_plan_step: adam_from_flat needs a grad arena");
-    const rv_param_desc* d = adam_from_flat ? p->d_flat : p->d_slab;
-    const bool all = phases & RV_PHASE_ADAM;
-    if (all || (phases & RV_PHASE_ADAM_A))
-      RV_TRY(rv_adam_multi(d + 6, 4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                           p->b.step_counter, stream));
-    if (all || (phases & RV_PHASE_ADAM_B))
-      RV_TRY(rv_adam_multi(d, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                           p->b.step_counter, stream));
+  for (int i = 0; i < 10;) {
+    if (!((adam >> i) & 1)) { ++i; continue; }
+    int j = i;
+    while (j < 10 && ((adam >> j) & 1)) ++j;
+    RV_TRY(rv_adam_multi(ad + i, j - i, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, stream));
+    i = j;
   }
 #undef RV_TRY
   return RV_OK;

@@ -2,9 +2,9 @@
 `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
 
 The reference has no distributed code; frames are independent, so the
-exchange is one SUM all-reduce of the flat fp32 gradient arena per step, issued in two
-buckets so that the first (fc3, fc4 -- ready after the first half of backward) overlaps the
-rest of backward.  Every rank holds the same per-rank batch size, so mean-of-rank-gradients
+exchange is one SUM all-reduce of the flat fp32 gradient arena per step, issued in three
+buckets in the order the gradients become available (fc4, fc1, the rest) so that the two
+large exchanges overlap the remaining backward GEMMs and the first optimizer launch.  Every rank holds the same per-rank batch size, so mean-of-rank-gradients
 equals the gradient of the global-batch mean loss (the reference's loss is a mean,
 rawvae/model.py:39,45); Adam then applies `grad_scale = 1/world`.
 """
@@ -54,27 +54,37 @@ class GradSync:
 
 
 def engine_buckets(engine):
-    """[fc3, fc4] first (ready after PHASE_BWD_A), then [fc1, fc21, fc22]."""
-    cut = engine.offsets["fc3.weight"]
-    return [(cut, engine.n_params), (0, cut)]
+    """Buckets in the order their gradients become available in backward:
+    fc4 (after the paired fc4 backward), fc1 (end of the dependent chain), then fc21/fc22/fc3."""
+    o = engine.offsets
+    return [(o["fc4.weight"], engine.n_params), (0, o["fc21.weight"]), (o["fc21.weight"], o["fc4.weight"])]
 
 
 def ddp_step(engine, sync, x, eps=None, stream=None):
     """One data-parallel training step (train.py:184-193 across ranks).
 
     Timeline on the compute stream (RCCL runs on its own stream, ordered by events):
-        FWD, BWD_A, finalize A        -> all-reduce A (fc3, fc4) starts
-        BWD_B, finalize B             -> all-reduce B (fc1, heads) starts   [A overlaps this compute]
-        wait A, Adam(fc3, fc4)                                             [overlaps all-reduce B]
-        wait B, Adam(fc1, heads)
+        FWD, fc4 backward, finalize fc4            -> all-reduce fc4 (8.4 MB) starts
+        dz, reparam bwd, heads dgrad, fc1 wgrad,
+        finalize fc1                               -> all-reduce fc1 (8.4 MB) starts
+        fc3 wgrad, heads wgrad, finalize rest      -> all-reduce rest (1.6 MB) starts
+        wait fc4,  Adam(fc4)                       [overlaps the fc1 / rest all-reduces]
+        wait fc1,  Adam(fc1)
+        wait rest, Adam(fc21, fc22, fc3)
+    so the fc4 exchange hides behind ~80 us of backward and the fc1 exchange behind the remaining
+    weight-gradient GEMMs and the fc4 optimizer step.
     """
-    from ._lib import (PHASE_ADAM_A, PHASE_ADAM_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_FINALIZE_A,
-                       PHASE_FINALIZE_B, PHASE_FWD)
-    engine.step(x, eps, phases=PHASE_FWD | PHASE_BWD_A | PHASE_FINALIZE_A, stream=stream)
+    from . import _lib as P
+    engine.step(x, eps, phases=P.PHASE_FWD | P.PHASE_BWD_FC4 | P.PHASE_FIN_FC4, stream=stream)
     sync.start(0)
-    engine.step(x, eps, phases=PHASE_BWD_B | PHASE_FINALIZE_B, stream=stream)
+    engine.step(x, eps, phases=P.PHASE_BWD_CHAIN | P.PHASE_FIN_FC1, stream=stream)
     sync.start(1)
+    engine.step(x, eps, phases=P.PHASE_BWD_REST | P.PHASE_FIN_MID, stream=stream)
+    sync.start(2)
+    g = sync.grad_scale
     sync.wait_one()
-    engine.step(x, eps, phases=PHASE_ADAM_A, grad_scale=sync.grad_scale, adam_from_flat=True, stream=stream)
+    engine.step(x, eps, phases=P.PHASE_ADAM_FC4, grad_scale=g, adam_from_flat=True, stream=stream)
+    sync.wait_one()
+    engine.step(x, eps, phases=P.PHASE_ADAM_FC1, grad_scale=g, adam_from_flat=True, stream=stream)
     sync.wait()
-    engine.step(x, eps, phases=PHASE_ADAM_B, grad_scale=sync.grad_scale, adam_from_flat=True, stream=stream)
+    engine.step(x, eps, phases=P.PHASE_ADAM_MID, grad_scale=g, adam_from_flat=True, stream=stream)

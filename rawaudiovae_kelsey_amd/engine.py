@@ -13,8 +13,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (PHASE_ADAM, PHASE_ADAM_A, PHASE_ADAM_B, PHASE_ALL_LOCAL, PHASE_BWD_A, PHASE_BWD_B,
-                   PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr, stream_ptr)
+from ._lib import (PHASE_ADAM, PHASE_ADAM_A, PHASE_ADAM_B, PHASE_ALL_LOCAL, PHASE_ANY_ADAM, PHASE_BWD_A,
+                   PHASE_BWD_B, PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr,
+                   stream_ptr)
 
 PARAM_NAMES = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias",
                "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias")
@@ -150,7 +151,7 @@ class TrainEngine:
                            stream_ptr(stream))
         if phases & PHASE_FWD:
             self.host_steps += 1
-        if phases & (PHASE_ADAM | PHASE_ADAM_B):   # a split Adam ends with its B half
+        if phases & PHASE_ANY_ADAM:
             self._shared["version"] += 1
             self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
 

@@ -40,10 +40,12 @@ def _worker(rank, world, port, q):
         g = O.backward(p, c, 1e-4)
         flat = torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in PARAM_NAMES]))
         sizes = [g[k].size for k in PARAM_NAMES]
-        cut = sum(sizes[:6])
-        sync = GradSync(flat, [(cut, flat.numel()), (0, cut)])
+        c1, c4 = sum(sizes[:2]), sum(sizes[:8])   # engine_buckets(): fc4 | fc1 | the rest
+        sync = GradSync(flat, [(c4, flat.numel()), (0, c1), (c1, c4)])
         sync.start(0)
         sync.start(1)
+        sync.start(2)
+        sync.wait_one()
         sync.wait()
         mean = flat.numpy() * sync.grad_scale
         cf = O.forward(p, x, eps)
