@@ -118,8 +118,12 @@ def main():
     force_ddp = os.environ.get("RV_FORCE_DDP") == "1"  # exercise the phased DDP step on one rank
     sync = ddp.GradSync(eng.grad, ddp.engine_buckets(eng)) if (world > 1 or force_ddp) else None
 
+    # eager launches for the phased data-parallel step: six hipGraph segments per step measured slower
+    # (292 vs 263 us on one rank) because each replay's fixed cost is not hidden behind short segments
+    runner = ddp.DdpRunner(eng, sync, comp, use_graphs=False) if sync is not None else None
+
     def ddp_step(x):
-        ddp.ddp_step(eng, sync, x, stream=comp)
+        runner.step(x)
 
     graphs = []
     with torch.cuda.stream(comp):
@@ -184,7 +188,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": "dp%d" % world,
+                       "launch": "hipGraph" if use_graph else "eager",
                        "grad_allreduce": "fp32, 3 buckets (fc4 | fc1 | rest) overlapped with backward" if world > 1 else None},
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),

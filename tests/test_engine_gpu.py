@@ -231,3 +231,22 @@ def test_unsupported_latent_is_rejected_loudly():
         e.step(torch.zeros(7, 64, device="cuda"))          # wrong batch size
     with pytest.raises(RvError):
         e.step(torch.zeros(8, 64, device="cuda", dtype=torch.float64))
+
+
+def test_ddp_runner_graph_segments_equal_eager():
+    from rawaudiovae_kelsey_amd import ddp
+    S, H, L, B = 256, 384, 16, 256
+    a, b = _engine(S, H, L, B, seed=4), _engine(S, H, L, B, seed=4)
+    st = torch.cuda.Stream()
+    xs = [torch.from_numpy(make_frames(B, S, 90 + i)).cuda() for i in range(2)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        a.step(xs[0], stream=st)   # warm-up outside capture (kernel attributes)
+        b.step(xs[0], stream=st)
+        ra = ddp.DdpRunner(a, ddp.GradSync(a.grad, ddp.engine_buckets(a)), st, use_graphs=False)
+        rb = ddp.DdpRunner(b, ddp.GradSync(b.grad, ddp.engine_buckets(b)), st, use_graphs=True)
+        for i in range(5):
+            ra.step(xs[i % 2])
+            rb.step(xs[i % 2])
+    torch.cuda.synchronize()
+    assert torch.equal(a.param, b.param) and a.losses(5) == b.losses(5)
