@@ -23,6 +23,8 @@
 // partial sums + d(pre-tanh) emission, ReLU-mask application and the bias-grad
 // column sums.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace rv {
@@ -223,58 +225,110 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(smem + A_BYTES, wn * WTN + ni * 16, 0, lane);
 
-  int slot = 0;  // ring slot of tile kt
-  for (int kt = 0; kt < nk; ++kt) {
-    const lds_char* cur = smem + slot * STAGE;
-    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    // The first MFMA of the tile goes BEFORE the second-half fragment reads: the compiler
-    // waits lgkmcnt(0) at the first use of a0/b0 (loaded across the loop back-edge), which
-    // is free here and would otherwise also drain the reads issued just above it.
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b0[0], acc[0][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+  // ds_read instructions per half-tile of fragments, MFMAs per half-tile
+  constexpr int NRD = MI * (A_KMAJ ? 1 : 2) + NI * (B_KMAJ ? 1 : 2);
+  constexpr int NMF = MI * NI;
+
+  // First half of tile kt: MFMAs on (a0, b0) with the reads of (a1, b1) slotted between them
+  // (one MFMA first: its operands were loaded across the loop back-edge, and the lgkmcnt(0) the
+  // compiler puts in front of it must not also drain the reads issued in this half).
+  auto first_half = [&](const lds_char* cur) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a1[mi] = load_frag<BM, A_KMAJ>(cur, wm * WTM + mi * 16, 1, lane);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b1[ni] = load_frag<BN, B_KMAJ>(cur + A_BYTES, wn * WTN + ni * 16, 1, lane);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        if (mi + ni > 0)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+    // issue order: MFMA, then {k ds_reads, MFMA} ...
+    constexpr int K1 = (NRD + NMF - 2) / (NMF - 1);  // reads per MFMA gap
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int i = 0; i < NRD; i += K1) {
+      __builtin_amdgcn_sched_group_barrier(0x100, K1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      // tiles issued so far: 0 .. min(kt+NSTAGE-1, nk-1); newer than kt+1:
-      const int newer = nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2;
-      // This wave must be done reading slot `slot` before the barrier lets anyone refill it:
-      // a register USE of the second-half fragments makes the compiler place the wait here.
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a1[mi]));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(b1[ni]));
-      wait_tiles_in_flight<GL>(newer);
-      __builtin_amdgcn_s_barrier();
-      if (kt + NSTAGE < nk) {
-        lds_char* rf = smem + slot * STAGE;
-        sa.stage(Ag + (long)(kt + NSTAGE) * a_step, rf, wave);
-        sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + A_BYTES, wave);
-      }
+  };
+
+  // Second half of tile kt, entered right after the mid-tile barrier: the LDS-DMA refill of the
+  // vacated slot and the first-half fragment reads of tile kt+1 are slotted between the MFMAs on
+  // (a1, b1), so the matrix pipe restarts immediately after the barrier.
+  auto second_half = [&](auto refill_c, auto next_c, int kt, int slot, int nslot) {
+    constexpr bool REFILL = decltype(refill_c)::value, NEXT = decltype(next_c)::value;
+    if constexpr (REFILL) {
+      lds_char* rf = smem + slot * STAGE;
+      sa.stage(Ag + (long)(kt + NSTAGE) * a_step, rf, wave);
+      sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + A_BYTES, wave);
+    }
+    if constexpr (NEXT) {
       const lds_char* nxt = smem + nslot * STAGE;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(nxt, wm * WTM + mi * 16, 0, lane);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(nxt + A_BYTES, wn * WTN + ni * 16, 0, lane);
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+    if constexpr (NEXT) {
+      constexpr int NV = REFILL ? GL : 0;
+      constexpr int K2 = (NV + NRD + NMF - 2) / (NMF - 1);  // memory instructions per MFMA gap
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+      for (int i = 0; i < NV; i += K2) {
+        __builtin_amdgcn_sched_group_barrier(0x020, K2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NRD; i += K2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, K2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // Mid-tile hand-off: this wave is done reading slot `slot` (register USE of the second-half
+  // fragments makes the compiler place the lgkmcnt wait here), tile kt+1 has landed for this wave's
+  // share (counted vmcnt), then the barrier publishes both facts to the block.
+  auto hand_off = [&](int newer) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a1[mi]));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(b1[ni]));
+    wait_tiles_in_flight<GL>(newer);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  int slot = 0;  // ring slot of tile kt
+  int kt = 0;
+  // steady state: a refill is issued every tile
+  for (; kt + NSTAGE < nk; ++kt) {
+    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    first_half(smem + slot * STAGE);
+    hand_off(NSTAGE - 2);
+    second_half(T_{}, T_{}, kt, slot, nslot);
     slot = nslot;
   }
+  // drain: tiles already staged, nothing left to prefetch
+  for (; kt + 1 < nk; ++kt) {
+    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    first_half(smem + slot * STAGE);
+    hand_off(nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2);
+    second_half(F_{}, T_{}, kt, slot, nslot);
+    slot = nslot;
+  }
+  // last tile
+  first_half(smem + slot * STAGE);
+  second_half(F_{}, F_{}, kt, slot, slot);
   __syncthreads();  // every wave is done with the ring before the epilogue reuses LDS
 
   // ------------------------------ epilogue ------------------------------
