@@ -101,4 +101,6 @@ def test_api_path_and_engine_agree_on_one_step():
     g_api = torch.cat([p.grad.reshape(-1) for _, p in m.named_parameters()])
     g_eng, l_eng = _grads(_engine(b), x, eps)
     assert abs(loss.item() - l_eng[0]) < 2e-6 * l_eng[0]
-    assert float((g_api - g_eng).norm() / g_eng.norm()) < 2e-5
+    # the API path rounds d(pre-tanh) to bf16 from (2/N d)(1-r^2), the engine from 2/N (d (1-r^2)):
+    # one-ulp fp32 differences that occasionally flip a bf16 rounding
+    assert float((g_api - g_eng).norm() / g_eng.norm()) < 2e-4
