@@ -127,7 +127,12 @@ def main():
 
     graphs = []
     with torch.cuda.stream(comp):
-        eng.step(pool[0], stream=comp)  # eager warm-up (sets kernel attributes before capture)
+        # eager warm-up step (sets kernel attributes before any capture); with several ranks it must
+        # already be a data-parallel step, or the replicas would start from different weights
+        if sync is not None:
+            runner.step(pool[0])
+        else:
+            eng.step(pool[0], stream=comp)
         torch.cuda.synchronize()
         if use_graph:
             for x in pool:
@@ -165,6 +170,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         last = eng.losses(min(8, args.steps))
+        if world > 1:  # replicas must hold identical weights after identical averaged updates
+            chk = torch.stack([eng.param.double().sum(), eng.param.double().abs().sum()])
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if rank == 0 and not torch.equal(lo, hi):
+                print("bench.py: WARNING replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
         kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
