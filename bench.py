@@ -211,6 +211,8 @@ def main():
                        "grad_allreduce": "fp32, 3 buckets (fc4 | fc1 | rest) overlapped with backward" if world > 1 else None},
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
+            # algorithmic HBM bytes per step: 54,784 B/frame of activations + 38 B/param
+            "step_hbm_frac": (value * 54784.0 + (value / B / world) * 38.0 * 4592768 * world) / (8.0e12 * world),
             "final_loss": last[-1],
             "roofline": {"bound": "mfma", "kernel": kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
