@@ -228,6 +228,7 @@ def main():
                                              "host, median %.1f ms/step" % (n, ms)}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # rank 0 did extra timing work; leave together
         dist.destroy_process_group()
 
 
