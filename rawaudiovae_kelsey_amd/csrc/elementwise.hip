@@ -200,9 +200,10 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
 }
 
 // ------------------------------------------------------------------ reparam backward (+ loss finish)
-// Block = RB_ROWS batch rows x all Lp columns; thread -> (l = tid % Lp, r0 = tid / Lp), rows
-// r0, r0 + 256/Lp, ...  Column sums (bias grads of fc21|fc22) are reduced through LDS into
-// one partial row per block.  The last grid block also finishes the loss scalar.
+// Block = RB_ROWS batch rows x all Lp columns, one thread per 4 consecutive columns of one row
+// (float4 loads, all slabs in flight); rows of the block are covered in 256*4/Lp-row passes.
+// Column sums (bias grads of fc21|fc22) are reduced through LDS into one partial row per block.
+// The last grid block also finishes the loss scalar.
 constexpr int RB_ROWS = 16;
 
 __global__ void __launch_bounds__(256)
@@ -212,38 +213,59 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
               const float* __restrict__ mse_partial, int n_mse,
               const float* __restrict__ kl_partial, int n_kl, float* __restrict__ loss_out,
               const long long* __restrict__ step_counter, int ring) {
-  __shared__ float sh[512];
+  __shared__ float sh[2 * 256 * 4];
   const int tid = threadIdx.x;
   const long L2p = 2 * Lp;
-  const int rows_par = (int)(256 / Lp);  // Lp in {64,128,256}
-  const int l = (int)(tid % Lp), r0 = (int)(tid / Lp);
+  const int lq = (int)(Lp / 4);             // column groups per row (16, 32 or 64)
+  const int rows_par = 256 / lq;            // rows covered per pass (16, 8 or 4)
+  const int cg = tid % lq, r0 = tid / lq;
+  const long l = (long)cg * 4;
   const float inv_nk = 1.0f / ((float)B * (float)L);
-  float cs_mu = 0.f, cs_lv = 0.f;
+  float cs_mu[4] = {0.f, 0.f, 0.f, 0.f}, cs_lv[4] = {0.f, 0.f, 0.f, 0.f};
   for (int r = r0; r < RB_ROWS; r += rows_par) {
     const long b = (long)blockIdx.x * RB_ROWS + r;
-    float dmu = 0.f, dlv = 0.f;
+    float dmu[4] = {0.f, 0.f, 0.f, 0.f}, dlv[4] = {0.f, 0.f, 0.f, 0.f};
     if (b < B && l < L) {
-      float dz = 0.f;
-      for (int s = 0; s < splits; ++s) dz += dz_slabs[(long)s * Bp * Lp + b * Lp + l];
-      const float mu = mulv[b * L2p + l], lv = mulv[b * L2p + Lp + l];
-      const float e = eps[b * L + l];
-      const float sd = __expf(0.5f * lv);
-      dmu = dz + kl_beta * mu * inv_nk;
-      dlv = dz * e * 0.5f * sd + kl_beta * 0.5f * (sd * sd - 1.f) * inv_nk;
+      float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* zb = dz_slabs + b * Lp + l;
+      for (int s = 0; s < splits; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(zb + (long)s * Bp * Lp);
+        dz.x += t.x; dz.y += t.y; dz.z += t.z; dz.w += t.w;
+      }
+      const float4 mu4 = *reinterpret_cast<const float4*>(mulv + b * L2p + l);
+      const float4 lv4 = *reinterpret_cast<const float4*>(mulv + b * L2p + Lp + l);
+      const float dza[4] = {dz.x, dz.y, dz.z, dz.w}, mua[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+      const float lva[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (l + j < L) {
+          const float e = eps[b * L + l + j];
+          const float sd = __expf(0.5f * lva[j]);
+          dmu[j] = dza[j] + kl_beta * mua[j] * inv_nk;
+          dlv[j] = dza[j] * e * 0.5f * sd + kl_beta * 0.5f * (sd * sd - 1.f) * inv_nk;
+        }
+      }
     }
-    dmulv[b * L2p + l] = (bf16_t)dmu;
-    dmulv[b * L2p + Lp + l] = (bf16_t)dlv;
-    cs_mu += dmu;
-    cs_lv += dlv;
+    const bf16x4 m4 = {(bf16_t)dmu[0], (bf16_t)dmu[1], (bf16_t)dmu[2], (bf16_t)dmu[3]};
+    const bf16x4 v4 = {(bf16_t)dlv[0], (bf16_t)dlv[1], (bf16_t)dlv[2], (bf16_t)dlv[3]};
+    *reinterpret_cast<bf16x4*>(dmulv + b * L2p + l) = m4;
+    *reinterpret_cast<bf16x4*>(dmulv + b * L2p + Lp + l) = v4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cs_mu[j] += dmu[j]; cs_lv[j] += dlv[j]; }
   }
-  sh[tid] = cs_mu;
-  sh[256 + tid] = cs_lv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[tid * 4 + j] = cs_mu[j];
+    sh[1024 + tid * 4 + j] = cs_lv[j];
+  }
   __syncthreads();
   if (dbh_partial && tid < Lp) {
+    // column tid = group (tid/4), element (tid%4); sum over the rows_par row-lanes in a fixed order
+    const int g = tid / 4, j = tid % 4;
     float a = 0.f, c = 0.f;
     for (int q = 0; q < rows_par; ++q) {
-      a += sh[q * Lp + tid];
-      c += sh[256 + q * Lp + tid];
+      a += sh[(q * lq + g) * 4 + j];
+      c += sh[1024 + (q * lq + g) * 4 + j];
     }
     dbh_partial[(long)blockIdx.x * L2p + tid] = a;
     dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
