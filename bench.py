@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     ap.add_argument("--serial", action="store_true", help="disable the two-stream backward")
+    ap.add_argument("--sched", type=int, default=1, help="backward schedule: 1 two-stream, 2 only the optimizer forked")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -116,7 +117,7 @@ def main():
 
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
     eng.load_params(make_params(S, H, L, 0))
-    eng.set_concurrency(not args.serial)
+    eng.set_concurrency(0 if args.serial else args.sched)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
     comp = torch.cuda.Stream(device=dev)
     use_graph = world == 1 and not args.no_graph and os.environ.get("RV_FORCE_DDP") != "1"

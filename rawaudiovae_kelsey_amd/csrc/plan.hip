@@ -49,7 +49,7 @@ struct rv_plan {
   // side stream, ordered against the caller's stream with events (graph-capture safe)
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool concurrent = true;
+  int concurrent = 1;  // 0 serial, 1 two-stream backward, 2 only the fc3/fc4 optimizer forked
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -147,7 +147,7 @@ void rv_plan_destroy(rv_plan* p) {
 
 int rv_plan_set_concurrency(rv_plan* p, int enable) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
-  p->concurrent = enable != 0;
+  p->concurrent = enable;
   return RV_OK;
 }
 
@@ -256,7 +256,33 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
                               (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
                           !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
-  if (full_local && p->concurrent && stream) {
+  if (full_local && p->concurrent == 2 && stream) {
+    // Variant: one fork only -- every GEMM stays on the main stream, the fc3/fc4 optimizer launch
+    // overlaps the last weight-gradient GEMM.
+    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
+                           p->s_dz, stream));
+    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
+    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
+                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
+                          p->b.step_counter, p->b.ring, stream));
+    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
+                           nullptr, 0, 1, stream));
+    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+    RV_HIP(hipEventRecord(p->ev[1], s0));
+    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
+    RV_TRY(rv_adam_multi(p->d_slab + 2, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, (void*)s1));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_HIP(hipEventRecord(p->ev[3], s1));
+    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));
+    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, stream));
+    return RV_OK;
+  }
+  if (full_local && p->concurrent == 1 && stream) {
     // Two-stream backward.  Main stream: the dependent chain fc4 backward (paired dgrad+wgrad) ->
     // dz -> reparam_bwd -> dgrad heads -> wgrad fc1 -> Adam(fc1, heads).  Side stream: wgrad fc3 ->
     // wgrad heads -> Adam(fc3, fc4), each gated by an event on the tensor it consumes.

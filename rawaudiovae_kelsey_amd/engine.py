@@ -112,7 +112,7 @@ class TrainEngine:
 
     def set_concurrency(self, enable):
         """Fork independent backward GEMMs / half of Adam onto a side stream (default on)."""
-        lib().rv_plan_set_concurrency(self._plan, int(bool(enable)))
+        lib().rv_plan_set_concurrency(self._plan, int(enable))
 
     def refresh_shadows(self, stream=None):
         """Rebuild this engine's bf16/padded weight shadows from the fp32 arena."""
