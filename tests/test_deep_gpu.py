@@ -1,0 +1,146 @@
+"""Deep variant (BASELINE configs[3]) on the GPU against oracle/deep_oracle.py.
+
+Tolerances as in test_engine_gpu.py: vs the bf16-quantised oracle loss 2e-5 rel, gradients 5e-3 x depth
+rel-L2 (each extra quantised layer on the way back adds its own bf16 rounding-boundary and ReLU-mask
+flips between the fp32-accumulating MFMA path and numpy's sums); vs the fp32 oracle at the C4 shape
+loss 1e-4 rel.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import deep_oracle as DO  # noqa: E402
+from oracle import vae_oracle as O  # noqa: E402
+from oracle.inputs import make_eps, make_frames, make_params  # noqa: E402
+
+KL, LR = 1e-4, 1e-4
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def _engine(S, H, L, depth, B, params):
+    from rawaudiovae_kelsey_amd.deep import DeepTrainEngine
+    e = DeepTrainEngine(S, H, L, depth, B, kl_beta=KL, lr=LR)
+    e.load_params(params)
+    return e
+
+
+@pytest.mark.parametrize("shape", [(64, 96, 8, 2, 16), (256, 512, 32, 3, 256), (100, 200, 5, 3, 37),
+                                   (512, 256, 100, 4, 130)])
+def test_deep_fwd_bwd_vs_quantised_oracle(shape):
+    S, H, L, depth, B = shape
+    p = DO.make_params(S, H, L, depth, 0)
+    e = _engine(S, H, L, depth, B, p)
+    x, eps = make_frames(B, S, 1234), make_eps(B, L, 4321)
+    recon = torch.zeros(B, S, device="cuda")
+    e.step(torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda(), recon, adam=False)
+    torch.cuda.synchronize()
+    c = DO.forward(p, x, eps, depth, quant="bf16")
+    loss, mse, kld = O.loss_function(c["recon"].astype(np.float64), x.astype(np.float64),
+                                     c["mu"].astype(np.float64), c["logvar"].astype(np.float64), KL)
+    g = DO.backward(p, c, KL, depth, quant="bf16")
+    got = e.last_loss()
+    assert abs(got[0] - loss) <= 2e-5 * abs(loss), (got, loss)
+    assert abs(got[1] - mse) <= 2e-5 * abs(mse) and abs(got[2] - kld) <= 1e-4 * abs(kld)
+    mu, lv = e.outputs()
+    np.testing.assert_allclose(mu.cpu().numpy(), c["mu"], atol=2e-4 * max(1, np.abs(c["mu"]).max()))
+    np.testing.assert_allclose(lv.cpu().numpy(), c["logvar"], atol=2e-4 * max(1, np.abs(c["logvar"]).max()))
+    np.testing.assert_allclose(recon.cpu().numpy(), c["recon"], atol=5e-4)
+    gv = e.gradients()
+    for k in DO.param_names(depth):
+        assert _rel_l2(gv[k].cpu().numpy(), g[k]) < 5e-3 * depth, k
+
+
+def test_depth1_is_the_reference_topology():
+    """DeepTrainEngine(depth=1) and the fused TrainEngine give the same step, bit for bit in the loss and
+    to fp32 rounding in the updated parameters (same kernels, same split choices)."""
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    S, H, L, B = 512, 1024, 16, 256
+    p = make_params(S, H, L, 0)
+    ren = {"fc1": "enc.0", "fc3": "dec.0"}
+    pd = {(ren.get(k.split(".")[0], k.split(".")[0]) + "." + k.split(".")[1]): v for k, v in p.items()}
+    d = _engine(S, H, L, 1, B, pd)
+    e = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR)
+    e.load_params(p)
+    x = torch.from_numpy(make_frames(B, S, 5)).cuda()
+    eps = torch.from_numpy(make_eps(B, L, 6)).cuda()
+    for _ in range(3):
+        d.step(x, eps)
+        e.step(x, eps)
+    torch.cuda.synchronize()
+    assert d.last_loss() == e.last_loss()
+    ev = e.param_views()
+    for k, kd in (("fc1.weight", "enc.0.weight"), ("fc22.bias", "fc22.bias"), ("fc3.weight", "dec.0.weight"),
+                  ("fc4.weight", "fc4.weight"), ("fc4.bias", "fc4.bias")):
+        assert torch.equal(ev[k], d.param_views()[kd]), k
+
+
+def test_deep_training_descends_and_matches_oracle_adam():
+    """Three full steps (Adam included) against the fp32 oracle stepped with the same Adam."""
+    S, H, L, depth, B = 128, 256, 16, 3, 128
+    p = DO.make_params(S, H, L, depth, 3)
+    e = _engine(S, H, L, depth, B, p)
+    names = DO.param_names(depth)
+    po = {k: v.astype(np.float64) for k, v in p.items()}
+    m = {k: np.zeros_like(v) for k, v in po.items()}
+    v2 = {k: np.zeros_like(v) for k, v in po.items()}
+    x, eps = make_frames(B, S, 11), make_eps(B, L, 12)
+    xd, ed = torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda()
+    for t in range(1, 4):
+        e.step(xd, ed)
+        c = DO.forward(po, x.astype(np.float64), eps.astype(np.float64), depth)
+        g = DO.backward(po, c, KL, depth)
+        for k in names:
+            m[k] = 0.9 * m[k] + 0.1 * g[k]
+            v2[k] = 0.999 * v2[k] + 0.001 * g[k] * g[k]
+            po[k] -= (LR / (1 - 0.9 ** t)) * m[k] / (np.sqrt(v2[k]) / np.sqrt(1 - 0.999 ** t) + 1e-8)
+    torch.cuda.synchronize()
+    pv = e.param_views()
+    for k in names:
+        # Adam's first steps move every weight by ~lr; bf16 gradient noise can flip the sign of tiny
+        # gradients, so the bound is a few lr per step, not a relative one (as test_engine_gpu.py).
+        assert np.abs(pv[k].cpu().numpy() - po[k]).max() <= 3.2 * LR * 3, k
+    ls = e.losses(3)
+    assert ls[2] < ls[0]
+
+
+def test_c4_shape_loss_vs_fp32_oracle():
+    """BASELINE configs[3]: S=2048, H=2048, L=256, depth 3 hidden layers per side, B=4096."""
+    S, H, L, depth, B = 2048, 2048, 256, 3, 4096
+    p = DO.make_params(S, H, L, depth, 0)
+    e = _engine(S, H, L, depth, B, p)
+    x, eps = make_frames(B, S, 1), make_eps(B, L, 2)
+    e.step(torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda())
+    torch.cuda.synchronize()
+    c = DO.forward(p, x, eps, depth)
+    loss, _, _ = O.loss_function(c["recon"].astype(np.float64), x.astype(np.float64), c["mu"].astype(np.float64),
+                                 c["logvar"].astype(np.float64), KL)
+    assert abs(e.last_loss()[0] - loss) <= 1e-4 * abs(loss), (e.last_loss(), loss)
+
+
+def test_deep_module_adopt_and_graph_replay():
+    from rawaudiovae_kelsey_amd.deep import DeepVAE
+    from rawaudiovae_kelsey_amd.engine import Graph
+    torch.manual_seed(0)
+    m = DeepVAE(256, 512, 32, depth=3).cuda()
+    eng = m.engine(256, kl_beta=KL, lr=1e-3, seed=1)
+    x = torch.from_numpy(make_frames(256, 256, 9)).cuda()
+    before = m.enc[1].weight.detach().clone()
+    eng.step(x)                                   # eager warm-up
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = Graph(side)
+        with g:
+            eng.step(x, stream=side)
+        for _ in range(20):
+            g.launch()
+    side.synchronize()
+    assert int(eng.step_counter.item()) == 21     # warm-up + 20 replays (the capture itself does not execute)
+    assert not torch.equal(before, m.enc[1].weight)  # the module's Parameters alias the arena
+    ls = eng.losses(20)
+    assert ls[-1] < ls[0]
