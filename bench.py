@@ -109,7 +109,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("RV_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for rehearsals
-    if world > 1:
+    if world > 1 or (os.environ.get("RV_FORCE_DDP") == "1" and "MASTER_ADDR" in os.environ and "RANK" in os.environ):
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -228,7 +228,7 @@ def main():
                                    "sample": "%d steps of the same C2 step (B=4096) in stock PyTorch fp32 on the "
                                              "host, median %.1f ms/step" % (n, ms)}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()   # rank 0 did extra timing work; leave together
         dist.destroy_process_group()
 

@@ -8,6 +8,8 @@ large exchanges overlap the remaining backward GEMMs and the first optimizer lau
 equals the gradient of the global-batch mean loss (the reference's loss is a mean,
 rawvae/model.py:39,45); Adam then applies `grad_scale = 1/world`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,11 +29,13 @@ class GradSync:
                                  % (lo, hi, flat.numel()))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank group still goes through the backend when asked to (RCCL rehearsal on a one-GPU box)
+        self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("RV_FORCE_DDP") == "1")
         self._pending = []
 
     def start(self, i):
-        """Launch the all-reduce of bucket i (no-op for a single rank)."""
-        if self.world == 1:
+        """Launch the all-reduce of bucket i (no-op without a process group)."""
+        if not self.active:
             return
         lo, hi = self.buckets[i]
         self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
