@@ -137,3 +137,42 @@ def test_default_ini_shape_max_batch_matches_sub_batches():
     assert abs(l_big[0] - lsum / n) < 2e-6 * l_big[0]
     rel = float(((acc / n).float() - g_big).norm() / g_big.norm())
     assert rel < 5e-5, rel
+
+
+def test_reference_default_ini_batch_131072():
+    """The reference's own default.ini (default.ini:18-28): S=1024, H=2048, L=256, batch 131072 -- the
+    largest size the path is configured for.  Checked through the data-parallel identity: the loss of
+    the 131072-frame batch is the mean of the losses of its 32 chunks of 4096 frames, and its gradient
+    is the mean of theirs (fp32 summation order only), all on the same weights and eps."""
+    from rawaudiovae_kelsey_amd import engine as E
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    Sd, Hd, Ld, Bd, chunk = 1024, 2048, 256, 131072, 4096
+    p = make_params(Sd, Hd, Ld, 0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(Bd, Sd, device="cuda", generator=g) * 2 - 1
+    eps = torch.randn(Bd, Ld, device="cuda", generator=g)
+    ph = E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B
+    big = TrainEngine(Sd, Hd, Ld, Bd, kl_beta=KL, lr=LR)
+    big.load_params(p)
+    big.step(x, eps, phases=ph)
+    torch.cuda.synchronize()
+    g_big, l_big = big.grad.clone(), big.last_loss()
+    mu_big = big.outputs()[0][-3:].clone()
+    del big
+    torch.cuda.empty_cache()
+    small = TrainEngine(Sd, Hd, Ld, chunk, kl_beta=KL, lr=LR)
+    small.load_params(p)
+    g_sum = torch.zeros_like(g_big, dtype=torch.float64)
+    l_sum = np.zeros(3)
+    for i in range(Bd // chunk):
+        small.step(x[i * chunk:(i + 1) * chunk], eps[i * chunk:(i + 1) * chunk], phases=ph)
+        torch.cuda.synchronize()
+        g_sum += small.grad.double()
+        l_sum += np.array(small.last_loss())
+    n = Bd // chunk
+    for a, b in zip(l_big, l_sum / n):
+        assert abs(a - b) <= 2e-6 * abs(b), (l_big, l_sum / n)
+    rel = float((g_big.double() - g_sum / n).norm() / (g_sum / n).norm())
+    assert rel < 5e-5, rel
+    # last rows of the last chunk: same GEMM inputs, only the split-K count (fp32 summation order) differs
+    assert torch.allclose(mu_big, small.outputs()[0][-3:], rtol=0, atol=2e-6)
