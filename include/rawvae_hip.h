@@ -75,6 +75,15 @@ int rv_linear_fwd_f32(const void* x_bf16, long ldx, const void* w_bf16, long ldw
                       const float* bias, long Mp, long Np, long Kp, int splits, float* y_f32,
                       long ldy, void* stream);
 
+/* Exact-fp32 y = act(x W^T + b) for the inference surface: `model(test_sample)[0]` under
+ * torch.no_grad() (train.py:218-232) and the notebooks' encode / decode calls
+ * (tutorial.ipynb:461,505-506,922-923).  F.linear + F.relu / F.tanh, model.py:20-21,29-30, in the
+ * reference's own precision: f32-input MFMA (a k-ordered fmaf chain), so outputs match the
+ * reference to f32 summation order.  Exact shapes (no padding), x [M,K], w [N,K] ([out,in]),
+ * bias [N] or NULL, y [M,N]; act: 0 none, 1 relu, 2 tanh. */
+int rv_linear_fp32(const float* x, long ldx, const float* w, long ldw, const float* bias, long M,
+                   long N, long K, int act, float* y, long ldy, void* stream);
+
 /* recon = tanh(h3 W4^T + b4), model.py:30, fused with the reconstruction half of
  * loss_function (model.py:39) and its derivative:
  *   recon   (optional) exact [B,S] fp32

@@ -38,7 +38,7 @@ PHASE_FIN_FC4, PHASE_FIN_FC1, PHASE_FIN_MID = 0x800, 0x1000, 0x2000
 PHASE_ADAM_FC4, PHASE_ADAM_FC1, PHASE_ADAM_MID = 0x4000, 0x8000, 0x10000
 PHASE_ANY_ADAM = PHASE_ADAM | PHASE_ADAM_A | PHASE_ADAM_B | PHASE_ADAM_FC4 | PHASE_ADAM_FC1 | PHASE_ADAM_MID
 PHASE_ALL_LOCAL = PHASE_FWD | PHASE_BWD_A | PHASE_BWD_B | PHASE_ADAM
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2   # ACT_TANH: rv_linear_fp32 only
 
 # name -> (restype, argtypes); every int-returning entry is error-checked by _wrap.
 _SIGS = {
@@ -59,6 +59,8 @@ _SIGS = {
     "rv_scale_by": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                               c_int, c_void_p, c_long, c_void_p]),
+    "rv_linear_fp32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int,
+                               c_void_p, c_long, c_void_p]),
     "rv_linear_fwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
                                   c_long, c_int, c_void_p, c_long, c_void_p]),
     "rv_decode_out_loss_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,

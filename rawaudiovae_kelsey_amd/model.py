@@ -9,6 +9,12 @@ initialisation are identical -- reference checkpoints load both ways), methods
 `encode / reparameterize / decode / forward`, and
 `loss_function(recon_x, x, mu, logvar, kl_beta, segment_length)`.
 
+Precision: calls that record an autograd graph (training) run the bf16-MFMA kernels with fp32
+accumulation; calls under `torch.no_grad()` -- the reference's eval reconstruction
+(train.py:218-232) and the notebooks' encode/decode (tutorial.ipynb:461,505-506,922-923) -- run
+exact-fp32 kernels (`rv_linear_fp32`), so inference outputs match the reference to fp32 summation
+order.  Set `model.inference_precision = "bf16"` to use the bf16 kernels there too.
+
 Added (optional, keyword-only): an explicit `eps` for `reparameterize`/`forward`
 (parity runs: the reference draws it from torch's global generator, model.py:25),
 and `VAE.engine(batch_size, ...)`, which returns the fused whole-step
@@ -36,10 +42,18 @@ class VAE(nn.Module):
         self.fc4 = nn.Linear(n_units, segment_length)
         self._rng_seed = 0x5EED
         self._rng_calls = 0
+        self.inference_precision = "fp32"
+
+    def _exact(self):
+        return not torch.is_grad_enabled() and getattr(self, "inference_precision", "fp32") == "fp32"
 
     # -- reference methods -------------------------------------------------
     def encode(self, x):
         x2 = x.reshape(-1, self.segment_length)
+        if self._exact():
+            h1 = ops.linear_fp32(x2, self.fc1.weight, self.fc1.bias, ops.ACT_RELU)
+            return (ops.linear_fp32(h1, self.fc21.weight, self.fc21.bias),
+                    ops.linear_fp32(h1, self.fc22.weight, self.fc22.bias))
         return ops.EncodeFn.apply(x2, self.fc1.weight, self.fc1.bias, self.fc21.weight, self.fc21.bias,
                                   self.fc22.weight, self.fc22.bias)
 
@@ -49,6 +63,9 @@ class VAE(nn.Module):
 
     def decode(self, z):
         z2 = z.reshape(-1, self.latent_dim)
+        if self._exact():
+            h3 = ops.linear_fp32(z2, self.fc3.weight, self.fc3.bias, ops.ACT_RELU)
+            return ops.linear_fp32(h3, self.fc4.weight, self.fc4.bias, ops.ACT_TANH)
         return ops.DecodeFn.apply(z2, self.fc3.weight, self.fc3.bias, self.fc4.weight, self.fc4.bias)
 
     def forward(self, x, eps=None):

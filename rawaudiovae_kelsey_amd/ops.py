@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_RELU, ParamDesc, gemm_pick, gemm_tile, lib, pad_dims, ptr, stream_ptr
+from ._lib import ACT_RELU, ACT_TANH, ParamDesc, gemm_pick, gemm_tile, lib, pad_dims, ptr, stream_ptr
 
 
 def _require_cuda(*tensors):
@@ -72,6 +72,21 @@ def _colsum(src, is_bf16, rows, cols, ld):
     part = torch.empty((nb, cols), dtype=torch.float32, device=src.device)
     lib().rv_colsum_partial(ptr(src), int(is_bf16), rows, cols, ld, ptr(part), cols, stream_ptr())
     return _slab_sum(part, nb, 1, cols, 1, cols).view(cols)
+
+
+def linear_fp32(x, W, b, act=0):
+    """Exact-fp32 act(x W^T + b) (rv_linear_fp32): the inference surface's Linear, no autograd."""
+    _require_cuda(x, W)
+    x, W = _f32c(x.detach()), _f32c(W.detach())
+    b = None if b is None else _f32c(b.detach())
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise _lib.RvError("linear_fp32: x is [%d, %d] but weight is [%d, %d]" % (M, K, N, W.shape[1]))
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if M:
+        lib().rv_linear_fp32(ptr(x), K, ptr(W), K, ptr(b), M, N, K, int(act), ptr(y), N, stream_ptr())
+    return y
 
 
 class EncodeFn(torch.autograd.Function):
