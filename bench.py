@@ -125,9 +125,32 @@ def main():
     force_ddp = os.environ.get("RV_FORCE_DDP") == "1"  # exercise the phased DDP step on one rank
     sync = ddp.GradSync(eng.grad, ddp.engine_buckets(eng)) if (world > 1 or force_ddp) else None
 
-    # eager launches for the phased data-parallel step: six hipGraph segments per step measured slower
-    # (292 vs 263 us on one rank) because each replay's fixed cost is not hidden behind short segments
-    runner = ddp.DdpRunner(eng, sync, comp, use_graphs=False) if sync is not None else None
+    # Data-parallel step.  Default: the library issues the RCCL all-reduces itself (one host call per
+    # step, collectives on their own stream between the kernels: ddp.NativeDdpRunner / rv_plan_step_ddp).
+    # RV_DDP=torch (or a non-RCCL rehearsal backend, or a failed RCCL self-test) selects the
+    # torch.distributed path: six host calls + three dist.all_reduce per step (ddp.ddp_step).
+    runner, ddp_mode, comm = None, None, None
+    if sync is not None:
+        want_native = dist.is_initialized() and backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch"
+        ok = 0
+        if want_native:
+            try:
+                comm = ddp.RcclComm()
+                comm.self_test(dev)
+                ok = 1
+            except Exception as exc:  # fall back together, below
+                print("bench.py: rank %d: native RCCL path unavailable (%s)" % (rank, exc), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1")
+            ddp_mode = "fp32, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its own stream, " \
+                       "overlapped with backward" + (", hipGraph" if runner.use_graph else "")
+        else:
+            # eager launches: six hipGraph segments per step measured slower (292 vs 263 us on one rank)
+            runner = ddp.DdpRunner(eng, sync, comp, use_graphs=False)
+            ddp_mode = "fp32, 3 buckets (fc4 | fc1 | rest) via torch.distributed, overlapped with backward"
 
     def ddp_step(x):
         runner.step(x)
@@ -208,8 +231,8 @@ def main():
             "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
                        "parallelism": "dp%d" % world,
-                       "launch": "hipGraph" if use_graph else "eager",
-                       "grad_allreduce": "fp32, 3 buckets (fc4 | fc1 | rest) overlapped with backward" if world > 1 else None},
+                       "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
+                       "grad_allreduce": ddp_mode},
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             # algorithmic HBM bytes per step: 54,784 B/frame of activations + 38 B/param
@@ -230,6 +253,9 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()   # rank 0 did extra timing work; leave together
+        if comm is not None:
+            torch.cuda.synchronize()
+            comm.destroy()
         dist.destroy_process_group()
 
 

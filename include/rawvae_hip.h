@@ -23,6 +23,8 @@
 #ifndef RAWVAE_HIP_H
 #define RAWVAE_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -277,6 +279,20 @@ int rv_plan_refresh_shadows(rv_plan*, void* stream);
 int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* recon_out,
                  float kl_beta, float lr, float grad_scale, int adam_from_flat,
                  unsigned long long seed, void* stream);
+/* ---- data-parallel step with the collective driven from here (no reference code:
+ * the reference is single-process).  `allreduce` is the collective library's in-place-capable
+ * all-reduce with RCCL's ncclAllReduce signature -- (sendbuf, recvbuf, count, dtype, op, comm, stream),
+ * returning 0 on success -- and `comm` its communicator; the caller creates both (see
+ * rawaudiovae_kelsey_amd/ddp.py: RCCL loaded with ctypes, unique id shared over torch.distributed).
+ * rv_plan_step_ddp enqueues ONE whole training step: forward, loss, backward with two gradient
+ * buckets (fc4 | fc1,fc21,fc22,fc3) summed across ranks on an internal high-priority stream as
+ * soon as backward has produced them, and Adam per bucket with the 1/world mean -- one host call,
+ * no host synchronisation, capturable in a hipGraph.  Needs a grad arena and a non-default stream. */
+typedef int (*rv_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
+                               void* comm, void* stream);
+int rv_plan_attach_comm(rv_plan*, rv_allreduce_fn allreduce, void* comm, int world);
+int rv_plan_step_ddp(rv_plan*, const float* x, const float* eps, float* recon_out, float kl_beta,
+                     float lr, unsigned long long seed, void* stream);
 /* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */
 void* rv_plan_buffer(rv_plan*, const char* name, long* n_bytes);
 

@@ -93,6 +93,8 @@ _SIGS = {
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
+    "rv_plan_attach_comm": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "rv_plan_step_ddp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
     "rv_graph_begin": (c_int, [c_void_p]),
     "rv_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),

@@ -50,6 +50,14 @@ struct rv_plan {
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int concurrent = 1;  // 0 serial, 1 two-stream backward, 2 only the fc3/fc4 optimizer forked
+  // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
+  // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
+  rv_allreduce_fn allreduce = nullptr;
+  void* comm = nullptr;
+  int world = 1;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+  void* comm_scratch = nullptr;  // 256 B: a one-rank group (rehearsal) still puts a real node on comm_stream
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -141,7 +149,13 @@ void rv_plan_destroy(rv_plan* p) {
   if (!p) return;
   for (hipEvent_t e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_ready)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_done)
+    if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+  if (p->comm_scratch) (void)hipFree(p->comm_scratch);
   delete p;
 }
 
@@ -369,6 +383,85 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                          p->b.step_counter, stream));
     i = j;
   }
+#undef RV_TRY
+  return RV_OK;
+}
+
+// ------------------------------------------------------------ data-parallel step
+int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int world) {
+  RV_REQUIRE(p && allreduce && comm, RV_ERR_NULL, "rv_plan_attach_comm: null argument");
+  RV_REQUIRE(world >= 1, RV_ERR_SHAPE, "rv_plan_attach_comm: world %d", world);
+  if (!p->comm_stream) {
+    int lo = 0, hi = 0;  // collectives ahead of compute when both are runnable
+    RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RV_HIP(hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, hi));
+    for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    RV_HIP(hipMalloc(&p->comm_scratch, 256));
+  }
+  p->allreduce = allreduce;
+  p->comm = comm;
+  p->world = world;
+  return RV_OK;
+}
+
+int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
+                     unsigned long long seed, void* stream) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
+  RV_REQUIRE(p->allreduce && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
+  RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
+  RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
+  const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
+  void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
+  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
+  float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
+  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const float* eps_used = eps ? eps : (float*)p->ws("eps");
+  hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
+  const float scale = 1.0f / (float)p->world;
+  int rc;
+#define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+  // Bucket b = tensors [t0, t1) of the flat arena, summed over ranks on the collective stream, which
+  // forks from and joins into the caller's stream only (a helper stream forking from another helper
+  // stream makes hipStreamEndCapture recurse without end in this HIP runtime).
+  auto reduce_bucket = [&](int b, int t0, int t1) -> int {
+    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
+    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
+    const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
+    const int nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
+                                 p->comm, (void*)sc);
+    if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-reduce of gradient bucket %d failed (collective library code %d)", b, nrc);
+    // a one-rank all-reduce enqueues nothing; keep the stream's branch of a captured graph non-empty
+    if (p->world == 1) RV_HIP(hipMemsetAsync(p->comm_scratch, 0, 256, sc));
+    RV_HIP(hipEventRecord(p->ev_done[b], sc));
+    return RV_OK;
+  };
+  // forward + loss, the paired fc4 backward, and the fc4 gradient into the flat arena (as rv_plan_step)
+  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
+  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                               (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+  RV_TRY(rv_grad_finalize(p->d_slab + 8, 2, p->b.grad, stream));
+  RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
+  // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
+  // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
+  RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
+                         p->s_dz, stream));
+  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
+  RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
+                         nullptr, 0, 1, stream));
+  RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
+  RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+  RV_TRY(rv_grad_finalize(p->d_slab, 8, p->b.grad, stream));  // fc1, fc21, fc22, fc3: contiguous in the arena
+  RV_TRY(reduce_bucket(1, 0, 8));
+  // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));
+  RV_TRY(rv_adam_multi(p->d_flat + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
+                       p->b.step_counter, stream));
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
+  RV_TRY(rv_adam_multi(p->d_flat, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
+                       p->b.step_counter, stream));
 #undef RV_TRY
   return RV_OK;
 }

@@ -8,6 +8,7 @@ large exchanges overlap the remaining backward GEMMs and the first optimizer lau
 equals the gradient of the global-batch mean loss (the reference's loss is a mean,
 rawvae/model.py:39,45); Adam then applies `grad_scale = 1/world`.
 """
+import ctypes as C
 import os
 
 import torch
@@ -139,4 +140,85 @@ class DdpRunner:
         self._rest[3].launch()
         s.wait()
         self._rest[4].launch()
+        e.host_steps += 1
+
+
+class RcclComm:
+    """An RCCL communicator owned by this package (one per process / GPU), created with ctypes from
+    the RCCL library PyTorch already loaded, so `rv_plan_step_ddp` can issue the gradient all-reduces
+    itself -- on its own stream, ordered by events, inside the same host call (and hipGraph) as the
+    kernels.  The unique id travels over the existing `torch.distributed` group (any backend)."""
+
+    class _UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_ubyte * 128)]
+
+    def __init__(self, group=None, lib_path=None):
+        if not dist.is_initialized():
+            raise RuntimeError("RcclComm needs an initialised torch.distributed group to share the RCCL unique id")
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        path = lib_path or os.environ.get("RV_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._lib = C.CDLL(path)
+        self._lib.ncclGetErrorString.restype = C.c_char_p
+        self._lib.ncclGetErrorString.argtypes = [C.c_int]
+        uid = self._UniqueId()
+        if self.rank == 0:
+            self._check(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [bytes(bytearray(uid.internal)) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self._UniqueId, C.c_int]
+        self._check(self._lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.handle = comm
+        self.allreduce_addr = C.cast(self._lib.ncclAllReduce, C.c_void_p)
+        self._lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce_(self, t, stream=None):
+        """In-place SUM of a contiguous fp32 tensor on `stream` (self-test / utility)."""
+        s = stream if stream is not None else torch.cuda.current_stream()
+        self._check(self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.handle,
+                                            s.cuda_stream or None), "ncclAllReduce")
+
+    def self_test(self, device):
+        """Every rank contributes rank+1 in each bucket-sized slot; the sum must be world(world+1)/2."""
+        t = torch.full((1 << 16,), float(self.rank + 1), dtype=torch.float32, device=device)
+        self.all_reduce_(t)
+        torch.cuda.synchronize(device)
+        want = self.world * (self.world + 1) / 2.0
+        if not bool((t == want).all()):
+            raise RuntimeError("RCCL self-test: expected %g everywhere, got [%g, %g]" % (want, t.min().item(), t.max().item()))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self._lib.ncclCommDestroy(self.handle)
+            self.handle = None
+
+
+class NativeDdpRunner:
+    """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
+    with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
+
+    def __init__(self, engine, comm, stream, use_graph=False):
+        self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
+        engine.attach_comm(comm)
+        self._graphs = {}
+
+    def step(self, x):
+        e = self.engine
+        if not self.use_graph:
+            return e.step_ddp(x, stream=self.stream)
+        key = x.data_ptr()
+        if key not in self._graphs:
+            from .engine import Graph
+            g = Graph(self.stream)
+            with g:
+                e.step_ddp(x, stream=self.stream)
+            e.host_steps -= 1   # the capture did not execute
+            self._graphs[key] = g
+        self._graphs[key].launch()
         e.host_steps += 1

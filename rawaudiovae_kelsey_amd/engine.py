@@ -155,6 +155,28 @@ class TrainEngine:
             self._shared["version"] += 1
             self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
 
+    def attach_comm(self, comm):
+        """Data-parallel mode with the collective issued by the library itself: `comm` is a
+        `ddp.RcclComm` (RCCL communicator + the address of its ncclAllReduce)."""
+        lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
+        self._comm = comm   # keep the communicator alive as long as the plan can use it
+
+    def step_ddp(self, x, eps=None, recon_out=None, stream=None):
+        """One whole data-parallel training step in one host call (`rv_plan_step_ddp`): every rank
+        calls it once per batch; gradients are averaged over ranks before Adam."""
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != self.B * self.S:
+            raise _lib.RvError("step_ddp: x must be contiguous fp32 with %d x %d elements" % (self.B, self.S))
+        if eps is not None and (eps.dtype != torch.float32 or not eps.is_contiguous()
+                                or eps.numel() != self.B * self.L):
+            raise _lib.RvError("step_ddp: eps must be contiguous fp32 [B, L]")
+        if self._shadow_version != self._shared["version"]:
+            self.refresh_shadows(stream)
+        lib().rv_plan_step_ddp(self._plan, ptr(x), ptr(eps), ptr(recon_out), self.kl_beta, self.lr, self.seed,
+                               stream_ptr(stream))
+        self.host_steps += 1
+        self._shared["version"] += 1
+        self._shadow_version = self._shared["version"]
+
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""
         n = C.c_long()

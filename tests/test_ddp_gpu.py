@@ -27,3 +27,53 @@ def test_two_rank_bench_flow_keeps_replicas_identical():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
     assert out["value"] > 0 and 0 < out["final_loss"] < 1
     assert "cpu_baseline" not in out          # reported at N=1 only
+
+
+def test_native_rccl_step_one_rank_equals_local_step():
+    """`rv_plan_step_ddp` (the library issues the RCCL all-reduces itself) with a real one-rank RCCL
+    communicator: eager and as a replayed hipGraph it must produce exactly the parameters of the plain
+    fused step (same kernels; sum over one rank and the 1/world mean are identities)."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29578"
+dist.init_process_group("gloo", rank=0, world_size=1)
+from oracle.inputs import make_frames, make_params
+from rawaudiovae_kelsey_amd import ddp
+from rawaudiovae_kelsey_amd.engine import Graph, TrainEngine
+S, H, L, B = 512, 1024, 16, 256
+def fresh():
+    e = TrainEngine(S, H, L, B, kl_beta=1e-4, lr=1e-4, seed=3)
+    e.load_params(make_params(S, H, L, 0))
+    return e
+x = torch.from_numpy(make_frames(B, S, 1)).cuda()
+st = torch.cuda.Stream()
+ref = fresh()
+with torch.cuda.stream(st):
+    for _ in range(4):
+        ref.step(x, stream=st)
+st.synchronize()
+comm = ddp.RcclComm()
+comm.self_test(torch.device("cuda", 0))
+eager = fresh(); eager.attach_comm(comm)
+with torch.cuda.stream(st):
+    for _ in range(4):
+        eager.step_ddp(x, stream=st)
+st.synchronize()
+assert torch.equal(eager.param, ref.param), "eager native step differs"
+assert eager.losses(4) == ref.losses(4)
+gr = fresh()
+run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True)
+with torch.cuda.stream(st):
+    for _ in range(4):
+        run.step(x)
+st.synchronize()
+assert torch.equal(gr.param, ref.param), "graph-replayed native step differs"
+assert gr.steps_done() == 4
+comm.destroy()
+dist.destroy_process_group()
+print("NATIVE_OK")
+''' % REPO
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0 and "NATIVE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
