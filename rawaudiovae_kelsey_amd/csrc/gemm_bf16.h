@@ -155,6 +155,135 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Ping-pong" main loop for the 256x256 tile (8 waves as 2 x 4 of 128 x 64; NSTAGE == 8 selects it).
+//
+// The two waves that share a SIMD (wave rows 0 and 1) run the same program ONE BARRIER APART: while one
+// is between the two barriers that bracket a cluster of 16 MFMAs, the other issues the LDS fragment
+// reads and the LDS-DMA staging of its next phase, so the matrix pipe of every SIMD is fed by one
+// wave while the other waits on memory.  Four phases per 64-deep K tile, one quadrant (64 x 32) of the
+// wave's 128 x 64 output per phase:
+//      phase 0: read B(n0) + A(m0)   MFMA (m0,n0)      stage B-half 1 of tile kt+1
+//      phase 1: read B(n1)           MFMA (m0,n1)      stage A-half 0 of tile kt+1
+//      phase 2: read A(m1)           MFMA (m1,n1)      stage A-half 1 of tile kt+1
+//      phase 3: (no reads)           MFMA (m1,n0)      stage B-half 0 of tile kt+2, wait: tile kt+1 landed
+// LDS: 2 buffers x {A half 0, A half 1, B half 0, B half 1} x 16 KiB (128 rows x 64 k).  A half is
+// restaged two or more phases after its last fragment read (the partner wave group runs a barrier
+// behind), and read two barriers after the counted vmcnt that retires its LDS-DMA.
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
+                                                  const long lda, const long ldb, const int nk, lds_char* smem,
+                                                  const int wave, const int lane, f32x4 (&acc)[8][4]) {
+  constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k half tile
+  constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
+  const int wr = wave >> 2, wc = wave & 3;
+  StageOffsets<128, A_KMAJ, 8> sa;
+  StageOffsets<128, B_KMAJ, 8> sb;
+  sa.init(lda, wave, lane);
+  sb.init(ldb, wave, lane);
+  const long a_step = A_KMAJ ? 64 : 64 * lda, b_step = B_KMAJ ? 64 : 64 * ldb;
+  const long a_half = A_KMAJ ? 128 * lda : 128, b_half = B_KMAJ ? 128 * ldb : 128;
+  auto stage_a = [&](int h, int t) {
+    if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, smem + (t & 1) * BUF + h * HALF, wave);
+  };
+  auto stage_b = [&](int h, int t) {
+    if (t < nk) sb.stage(Bg + h * b_half + (long)t * b_step, smem + (t & 1) * BUF + (2 + h) * HALF, wave);
+  };
+  bf16x8 a[4][2], b0[2][2], b1[2][2], b2[2][2];
+  const int brow = (wc & 1) * 64;
+  auto rd_a = [&](const lds_char* buf, int mq) {
+    const lds_char* base = buf + wr * HALF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) a[i][kk] = load_frag<128, A_KMAJ>(base, mq * 64 + i * 16, kk, lane);
+  };
+  auto rd_b = [&](bf16x8 (&b)[2][2], const lds_char* buf, int nq) {
+    const lds_char* base = buf + (2 + (wc >> 1)) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b[j][kk] = load_frag<128, B_KMAJ>(base, brow + nq * 32 + j * 16, kk, lane);
+  };
+  // close the memory half of a phase, run its MFMA cluster between two barriers
+  auto mma = [&](auto mq_c, auto nq_c, bf16x8 (&b)[2][2]) {
+    constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[MQ * 4 + i][NQ * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kk], b[j][kk], acc[MQ * 4 + i][NQ * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // One K tile = four phases.  `cur`/`nxt` are the (compile-time distinct) LDS buffers of tile kt and
+  // kt+1.  EARLY_B (both operands K-major: few address registers, so a third B fragment set fits):
+  // bq holds B(n0) of tile kt on entry and bn receives B(n0) of tile kt+1 in phase 3, which spreads the
+  // fragment reads 8 / 4 / 8 / 4 over the phases; otherwise B(n0) is read in phase 0 (12 / 4 / 8 / 0).
+  constexpr bool EARLY_B = A_KMAJ && B_KMAJ;
+  auto k_tile = [&](int kt, const lds_char* cur, const lds_char* nxt, bf16x8 (&bq)[2][2], bf16x8 (&bn)[2][2]) {
+    // phase 0: (B(n0),) A(m0);  stage B-half 1 of tile kt+1
+    if constexpr (!EARLY_B) rd_b(bq, cur, 0);
+    rd_a(cur, 0);
+    stage_b(1, kt + 1);
+    mma(I0{}, I0{}, bq);
+    // phase 1: B(n1);  stage A-half 0 of tile kt+1
+    rd_b(b1, cur, 1);
+    stage_a(0, kt + 1);
+    mma(I0{}, I1{}, b1);
+    // phase 2: A(m1);  stage A-half 1 of tile kt+1.  EARLY_B: both B halves of tile kt+1 must have landed
+    // for the phase-3 reads (the two A halves just issued may stay in flight)
+    rd_a(cur, 1);
+    stage_a(1, kt + 1);
+    if constexpr (EARLY_B) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    mma(I1{}, I1{}, b1);
+    // phase 3: (B(n0) of tile kt+1;)  stage B-half 0 of tile kt+2; all of tile kt+1 must have landed
+    if constexpr (EARLY_B) {
+      if (kt + 1 < nk) rd_b(bn, nxt, 0);
+    }
+    stage_b(0, kt + 2);
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mma(I1{}, I0{}, bq);
+  };
+
+  // prologue: tile 0 complete, B-half 0 of tile 1 in flight
+  stage_a(0, 0); stage_a(1, 0); stage_b(0, 0); stage_b(1, 0);
+  stage_b(0, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if constexpr (EARLY_B) rd_b(b0, smem, 0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; kt += 2) {   // nk is even (the launcher falls back to the ring loop otherwise)
+    if constexpr (EARLY_B) {
+      k_tile(kt, smem, smem + BUF, b0, b2);
+      k_tile(kt + 1, smem + BUF, smem, b2, b0);
+    } else {
+      k_tile(kt, smem, smem + BUF, b0, b0);
+      k_tile(kt + 1, smem + BUF, smem, b0, b0);
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Block tile BM x BN computed by a WGM x WGN grid of waves (wave tile BM/WGM x BN/WGN).
 //
 // NSTAGE-deep LDS ring, software-pipelined so it also runs at one wave per SIMD:
@@ -174,7 +303,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
   constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
-  static_assert(NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64, "vmcnt is a 6-bit counter");
+  constexpr bool PINGPONG = NSTAGE == 8;  // 256x256 ping-pong main loop (2 LDS buffers)
+  static_assert(PINGPONG || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
+  static_assert(!PINGPONG || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4), "ping-pong loop: 256x256, 2x4 waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,6 +334,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (PINGPONG) {
+    mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
+  } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
   sa.init(p.lda, wave, lane);
@@ -329,6 +463,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // last tile
   first_half(smem + slot * STAGE);
   second_half(F_{}, F_{}, kt, slot, slot);
+  }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses LDS
 
   // ------------------------------ epilogue ------------------------------

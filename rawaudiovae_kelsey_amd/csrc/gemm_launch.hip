@@ -19,13 +19,14 @@ int g_force_tile = -1;
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
-  constexpr int smem_max = NSTAGE * (BM + BN) * 128;
+  constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE;  // NSTAGE 8 = ping-pong main loop on two buffers
+  constexpr int smem_max = RING * (BM + BN) * 128;
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
   constexpr int stage_bytes = (BM + BN) * 128;
   constexpr int epi_rows = (BM / WGM) < 64 ? (BM / WGM) : 64;  // rows staged per epilogue round
   constexpr int epi_bytes = WGM * WGN * epi_rows * (BN / WGN + 4) * 4;
-  const int used = (a.k_tiles < NSTAGE ? a.k_tiles : NSTAGE) * stage_bytes;
+  const int used = (NSTAGE == 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE>;
   static bool attr_done = false;
@@ -57,14 +58,14 @@ bool tile_fits(int tile, long Mp, long Np) {
     case 1: return Mp % 128 == 0 && Np % 128 == 0;
     case 2: case 3: return Mp % 256 == 0 && Np % 128 == 0;
     case 4: return Mp % 128 == 0 && Np % 128 == 0;
-    case 5: return Mp % 256 == 0 && Np % 256 == 0;
+    case 5: case 7: return Mp % 256 == 0 && Np % 256 == 0;
     default: return false;
   }
 }
 
 void tile_dims(int tile, int* bm, int* bn) {
   *bm = tile == 0 ? 64 : (tile == 1 || tile == 4) ? 128 : 256;
-  *bn = tile == 0 ? 64 : tile == 5 ? 256 : 128;
+  *bn = tile == 0 ? 64 : (tile == 5 || tile == 7) ? 256 : 128;
 }
 
 template <bool AK, bool BK, int EPI>
@@ -81,8 +82,30 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
     case 2: return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 4: return launch<128, 128, 2, 4, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 5: return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 7:
+      if ((Kp / 64 / splits) % 2) return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
+      return launch<256, 256, 2, 4, 8, AK, BK, EPI>(a, Mp, Np, splits, st);
     default: return launch<256, 128, 2, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
   }
+}
+
+int g_pair_loop = 8;  // main loop of the paired 256x256 kernel: 8 = ping-pong (default), 2 = two-slot ring
+
+template <int NSTAGE>
+int launch_pair(const GemmArgs& d, const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
+  const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
+  constexpr int ring = 2 * (BM + BN) * 128, epi = WGM * WGN * 64 * (BN / WGN + 4) * 4;
+  constexpr int smem = ring > epi ? ring : epi;
+  auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_d + n_w)), dim3(64 * WGM * WGN), smem, st, d, g, n_d);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
 }
 
 }  // namespace
@@ -132,6 +155,7 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 }
 
 extern "C" int rv_gemm_force_tile(int tile) {
+  if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
   g_force_tile = tile;
   return RV_OK;
 }
@@ -253,7 +277,7 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   }
   RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: leading dims must be multiples of 8");
   RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: operands must be 16-byte aligned");
-  constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, NSTAGE = 2;
+  constexpr int BM = 256, BN = 256;
   GemmArgs d{}, g{};
   d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
   d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
@@ -263,18 +287,8 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
   g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
   g.tiles_m = (int)(Kp / BM); g.tiles_n = (int)(Np / BN); g.splits = splits;
-  const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * splits;
-  constexpr int ring = NSTAGE * (BM + BN) * 128, epi = WGM * WGN * 64 * (BN / WGN + 4) * 4;
-  constexpr int smem = ring > epi ? ring : epi;
-  auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_d + n_w)), dim3(64 * WGM * WGN), smem, (hipStream_t)stream, d, g, n_d);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
+  if (g_pair_loop == 8 && d.k_tiles % 2 == 0 && g.k_tiles % 2 == 0) return launch_pair<8>(d, g, (hipStream_t)stream);
+  return launch_pair<2>(d, g, (hipStream_t)stream);
 }
 
 }  // extern "C"

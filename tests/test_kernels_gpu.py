@@ -80,7 +80,7 @@ def test_linear_dgrad_f32(L, M, N, K, splits):
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5], ids=["auto", "t64", "t128w4", "t256x128w8", "t256x128w4", "t128w8", "t256x256"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7], ids=["auto", "t64", "t128w4", "t256x128w8", "t256x128w4", "t128w8", "t256x256", "t256x256pp"])
 def tile(request, L):
     """Pin each block-tile configuration in turn (256-row tiles only apply when M % 256 == 0)."""
     L.rv_gemm_force_tile(request.param)
@@ -339,13 +339,14 @@ def test_gather_frames_matches_audio_dataset_semantics(L):
     np.testing.assert_array_equal(out2.cpu().numpy(), ev)
 
 
-@pytest.mark.parametrize("force", [5, -1])
-@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (1024, 512, 256), (768, 256, 512)])
-def test_paired_dgrad_wgrad(L, force, M, N, K):
+@pytest.mark.parametrize("force,loop", [(5, 102), (5, 108), (-1, 102)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (1024, 512, 256), (768, 256, 512), (1024, 768, 1024)])
+def test_paired_dgrad_wgrad(L, force, loop, M, N, K):
     """rv_linear_dgrad_wgrad: dX = relu'(dY W) and dW = dY^T X from ONE launch (256x256 tiles, forced)
     and through its unpaired fallback; M = batch, K = out features, N = in features."""
     from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
     L.rv_gemm_force_tile(force)
+    L.rv_gemm_force_tile(loop)       # 102: two-slot ring main loop, 108: ping-pong main loop
     try:
         rng = np.random.default_rng(41)
         dy, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N), 0.1)
@@ -365,3 +366,4 @@ def test_paired_dgrad_wgrad(L, force, M, N, K):
         np.testing.assert_allclose(dw.sum(0).cpu().numpy(), ref_dw, rtol=1e-5, atol=1e-5 * np.abs(ref_dw).max())
     finally:
         L.rv_gemm_force_tile(-1)
+        L.rv_gemm_force_tile(108)    # the default

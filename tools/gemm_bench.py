@@ -15,6 +15,8 @@ L2 = 2 * L
 Lb = lib()
 if os.environ.get('RV_TILE'):
     Lb.rv_gemm_force_tile(int(os.environ['RV_TILE']))
+if os.environ.get('RV_PAIR_LOOP'):   # 2: two-slot ring, 8: ping-pong main loop of the paired 256x256 kernel
+    Lb.rv_gemm_force_tile(100 + int(os.environ['RV_PAIR_LOOP']))
 st = torch.cuda.current_stream().cuda_stream or None
 
 
