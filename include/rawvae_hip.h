@@ -51,8 +51,9 @@ int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, lo
  * GEMM is launched with a given split count; per-row-tile outputs (column-sum partials,
  * MSE partials) then have Mp/bm row tiles and Np/bn column tiles.
  * rv_gemm_force_tile: test hook, pins the tile configuration (0: 64x64, 1: 128x128,
- * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves, 4: 128x128 with 8 waves, 5: 256x256)
- * wherever it divides the extents; -1 = auto. */
+ * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves, 4: 128x128 with 8 waves, 5: 256x256 with the
+ * two-slot ring loop, 7: 256x256 with the ping-pong loop) wherever it divides the extents;
+ * -1 = auto.  108 / 102 select the ping-pong (default) / ring main loop of the paired kernel. */
 int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
 int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
 int rv_gemm_force_tile(int tile);
