@@ -117,12 +117,22 @@ int rv_linear_dgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw
  *   dw_slabs [splits][Kp][Np] = dY^T x        (split over the batch)
  * dy [Mp(batch), Kp(out)], w [Kp, Np] ([out,in]), x [Mp, Np] = the layer's ReLU output (mask AND
  * wgrad operand).  `splits` and `bm` must come from rv_dgrad_wgrad_pick(Mp, Np, Kp); when the
- * pairing does not apply the call falls back to rv_linear_dgrad + rv_linear_wgrad. */
+ * 256x256 pairing does not apply (e.g. the heads: Kp = 2 Lp) the two GEMMs still go out in one
+ * launch if they share a small tile, otherwise as rv_linear_dgrad + rv_linear_wgrad. */
 int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits);
 int rv_linear_dgrad_wgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw,
                           const void* x_bf16, long ldx, long Mp, long Np, long Kp, void* dx_bf16,
                           long lddx, float* colsum_partial, float* dw_slabs, long lddw, int splits,
                           void* stream);
+
+/* Backward of a Linear layer whose input had no activation (fc3, whose input is z): dX = dY W as
+ * `dgrad_splits` fp32 slabs [Mp, Np] and dW = dY^T X as `wgrad_splits` slabs [Kp, Np], in ONE launch
+ * when both GEMMs run on the same small tile (they read the same dY; each alone is mostly launch and
+ * store-tail time).  dy [Mp(batch), Kp(out)], w [Kp, Np], x [Mp, Np].  Autograd of F.linear, train.py:191. */
+int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16, long ldw,
+                              const void* x_bf16, long ldx, long Mp, long Np, long Kp, float* dx_slabs,
+                              long lddx, int dgrad_splits, float* dw_slabs, long lddw, int wgrad_splits,
+                              void* stream);
 
 /* dW = dY^T X as `splits` fp32 partial slabs [Mp(out), Np(in)] (split over the batch).
  * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS
@@ -267,9 +277,10 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
 void rv_plan_destroy(rv_plan*);
 long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
-/* The full local step (FWD|BWD_A|BWD_B|ADAM) forks the weight-gradient GEMMs and the
- * fc3/fc4 half of Adam onto an internal side stream and joins before returning to the
- * caller's stream order (needs a non-default `stream`).  0 disables (one serial stream). */
+/* Schedule of the full local step (FWD|BWD_A|BWD_B|ADAM).  0 (default): every kernel on the caller's
+ * stream.  Non-zero: the fc3/fc4 half of Adam is forked onto an internal side stream beside the fc1
+ * weight-gradient GEMM and joined before the call's last kernel (needs a non-default `stream`); each
+ * cross-stream edge costs 6-10 us on this runtime, so it measures slower than 0 at C2. */
 int rv_plan_set_concurrency(rv_plan*, int enable);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);

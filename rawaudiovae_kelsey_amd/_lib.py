@@ -51,6 +51,8 @@ _SIGS = {
     "rv_dgrad_wgrad_pick": (c_int, [c_long, c_long, c_long] + [C.POINTER(c_int)] * 3),
     "rv_linear_dgrad_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
                                       c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "rv_linear_dgrad_wgrad_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
+                                          c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),

@@ -676,4 +676,18 @@ gemm_dgrad_wgrad_kernel(const GemmArgs dgrad, const GemmArgs wgrad, const int n_
     gemm_body<BM, BN, WGM, WGN, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x - n_first, smem_dyn);
 }
 
+// Two independent GEMMs of the same block-tile configuration in ONE launch (blocks [0, n_first) run
+// the first): the latent-sized backward GEMMs are a few microseconds each, mostly launch, first-tile
+// latency and store tail, and come in pairs that read the same activation (dz and dW3 read dP3; the
+// heads' dgrad and wgrad read dmulv and h1) -- one grid runs both pairs' blocks side by side.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool A1, bool B1, int E1, bool A2, bool B2, int E2>
+__global__ void __launch_bounds__(64 * WGM * WGN)
+gemm_dual_kernel(const GemmArgs first, const GemmArgs second, const int n_first) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  if ((int)blockIdx.x < n_first)
+    gemm_body<BM, BN, WGM, WGN, A1, B1, E1, NSTAGE>(first, blockIdx.x, smem_dyn);
+  else
+    gemm_body<BM, BN, WGM, WGN, A2, B2, E2, NSTAGE>(second, blockIdx.x - n_first, smem_dyn);
+}
+
 }  // namespace rv

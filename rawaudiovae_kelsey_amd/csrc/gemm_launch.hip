@@ -108,6 +108,41 @@ int launch_pair(const GemmArgs& d, const GemmArgs& g, hipStream_t st) {
   return RV_OK;
 }
 
+// Two GEMMs of one tile configuration in one launch (gemm_dual_kernel).  `a`/`b` carry operands,
+// k_tiles and outputs; tiles/splits are filled in here.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool A1, bool B1, int E1, bool A2, bool B2, int E2>
+int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmArgs& b, long Mp2, long Np2, int splits2,
+                hipStream_t st) {
+  constexpr int stage_bytes = (BM + BN) * 128, smem_max = NSTAGE * stage_bytes;
+  constexpr int epi_rows = (BM / WGM) < 64 ? (BM / WGM) : 64;
+  constexpr int epi_bytes = WGM * WGN * epi_rows * (BN / WGN + 4) * 4;
+  const int kt = a.k_tiles > b.k_tiles ? a.k_tiles : b.k_tiles;
+  const int used = (kt < NSTAGE ? kt : NSTAGE) * stage_bytes;
+  const int smem = used > epi_bytes ? used : epi_bytes;
+  auto kern = gemm_dual_kernel<BM, BN, WGM, WGN, NSTAGE, A1, B1, E1, A2, B2, E2>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
+    attr_done = true;
+  }
+  GemmArgs g1 = a, g2 = b;
+  g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
+  g2.tiles_m = (int)(Mp2 / BM); g2.tiles_n = (int)(Np2 / BN); g2.splits = splits2;
+  const int n1 = g1.tiles_m * g1.tiles_n * splits1, n2 = g2.tiles_m * g2.tiles_n * splits2;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 + n2)), dim3(64 * WGM * WGN), smem, st, g1, g2, n1);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+// Dual launch on tile 0 (64x64) or tile 4 (128x128, 8 waves); false if `tile` is neither.
+template <bool A1, bool B1, int E1, bool A2, bool B2, int E2>
+bool try_dual(int tile, const GemmArgs& a, long Mp1, long Np1, int s1, const GemmArgs& b, long Mp2, long Np2, int s2,
+              hipStream_t st, int* rc) {
+  if (tile == 0) { *rc = launch_dual<64, 64, 2, 2, 4, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
+  if (tile == 4) { *rc = launch_dual<128, 128, 2, 4, 4, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
+  return false;
+}
+
 }  // namespace
 
 // Tile used for a GEMM launched with a given split count (deterministic: callers size their
@@ -239,6 +274,14 @@ int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp,
 // ---- paired backward of one Linear layer: dX = relu'(dY W) and dW = dY^T X in one launch ----
 // dy [Mp(batch), Kp(out features)], w [Kp, Np] ([out,in]), x [Mp, Np] is BOTH the ReLU output that
 // masks dX and the right operand of dW.  dW[Kp, Np] leaves as `splits` slabs over the batch.
+// Unpaired backward of a Linear layer: when the wgrad runs on a dual-capable tile (64x64 or 128x128 with
+// 8 waves) that also divides the dgrad's output, the dgrad takes the same tile and both go out in one launch.
+static int dgrad_tile_unpaired(long Mp, long Np, long Kp, int wgrad_splits) {
+  const int tw = choose_tile(Kp, Np, wgrad_splits);
+  if (g_force_tile < 0 && (tw == 0 || tw == 4) && tile_fits(tw, Mp, Np)) return tw;
+  return choose_tile(Mp, Np, 1);
+}
+
 int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits) {
   RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 64 == 0 && Np % 64 == 0 && Kp % 64 == 0, RV_ERR_SHAPE,
              "rv_dgrad_wgrad_pick: extents must be positive multiples of 64");
@@ -252,8 +295,8 @@ int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, i
   }
   if (!pr) {
     int bn;
-    tile_dims(choose_tile(Mp, Np, 1), &bm, &bn);
     rv_gemm_pick(Kp, Np, Mp, 16, nullptr, nullptr, &sp);
+    tile_dims(dgrad_tile_unpaired(Mp, Np, Kp, sp), &bm, &bn);
   }
   if (paired) *paired = pr;
   if (bm_dgrad) *bm_dgrad = bm;
@@ -271,7 +314,18 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   RV_REQUIRE(sp == splits, RV_ERR_STATE, "rv_linear_dgrad_wgrad: caller passed %d splits, rv_dgrad_wgrad_pick says %d",
              splits, sp);
   if (!paired) {
-    rc = rv_linear_dgrad(dy, lddy, w, ldw, Mp, Np, Kp, x, ldx, dx_bf16, lddx, colsum_partial, nullptr, 0, 1, stream);
+    const int td = dgrad_tile_unpaired(Mp, Np, Kp, splits), tw = choose_tile(Kp, Np, splits);
+    GemmArgs d{}, g{};
+    d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
+    d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
+    d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+    g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
+    g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
+    g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
+    if (td == tw && (Mp / 64) % splits == 0 &&
+        try_dual<true, false, EPI_MASK_BF16, false, false, EPI_F32>(td, d, Mp, Np, 1, g, Kp, Np, splits, (hipStream_t)stream, &rc))
+      return rc;
+    rc = launch_tile<true, false, EPI_MASK_BF16>(td, d, Mp, Np, Kp, 1, (hipStream_t)stream);
     if (rc) return rc;
     return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, splits, dw_slabs, lddw, stream);
   }
@@ -289,6 +343,36 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   g.tiles_m = (int)(Kp / BM); g.tiles_n = (int)(Np / BN); g.splits = splits;
   if (g_pair_loop == 8 && d.k_tiles % 2 == 0 && g.k_tiles % 2 == 0) return launch_pair<8>(d, g, (hipStream_t)stream);
   return launch_pair<2>(d, g, (hipStream_t)stream);
+}
+
+
+// Backward of a Linear layer whose input had no activation (fc3: its input is z): dX as fp32 split-K
+// slabs and dW slabs, in one launch when both GEMMs run on the same dual-capable tile.
+int rv_linear_dgrad_wgrad_f32(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx, long Mp,
+                              long Np, long Kp, float* dx_slabs, long lddx, int dgrad_splits, float* dw_slabs,
+                              long lddw, int wgrad_splits, void* stream) {
+  RV_REQUIRE(dy && w && x && dx_slabs && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad_f32: null operand");
+  RV_REQUIRE(dgrad_splits >= 1 && wgrad_splits >= 1 && (Kp / 64) % dgrad_splits == 0 && (Mp / 64) % wgrad_splits == 0,
+             RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_f32: splits %d / %d do not divide the K tiles", dgrad_splits, wgrad_splits);
+  const int td = choose_tile(Mp, Np, dgrad_splits), tw = choose_tile(Kp, Np, wgrad_splits);
+  int rc;
+  if (td == tw) {
+    GemmArgs d{}, g{};
+    d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
+    d.k_tiles = (int)(Kp / 64 / dgrad_splits); d.M_valid = (int)Mp; d.N_valid = (int)Np;
+    d.out_f32 = dx_slabs; d.ld_f32 = lddx; d.split_stride_f32 = Mp * lddx;
+    g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
+    g.k_tiles = (int)(Mp / 64 / wgrad_splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
+    g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
+    RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_f32: leading dims must be multiples of 8");
+    RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_f32: operands must be 16-byte aligned");
+    if (try_dual<true, false, EPI_F32, false, false, EPI_F32>(td, d, Mp, Np, dgrad_splits, g, Kp, Np, wgrad_splits,
+                                                              (hipStream_t)stream, &rc))
+      return rc;
+  }
+  rc = rv_linear_dgrad(dy, lddy, w, ldw, Mp, Np, Kp, nullptr, 0, nullptr, 0, nullptr, dx_slabs, lddx, dgrad_splits, stream);
+  if (rc) return rc;
+  return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, wgrad_splits, dw_slabs, lddw, stream);
 }
 
 }  // extern "C"

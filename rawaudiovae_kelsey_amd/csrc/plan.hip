@@ -49,7 +49,7 @@ struct rv_plan {
   // side stream, ordered against the caller's stream with events (graph-capture safe)
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int concurrent = 1;  // 0 serial, 1 two-stream backward, 2 only the fc3/fc4 optimizer forked
+  int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
   // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
   rv_allreduce_fn allreduce = nullptr;
@@ -94,11 +94,16 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     p->n_mt3 = (int)(Bp / bm);
   }
   p->s_w3 = splits_of(Hp, Lp, Bp);
-  p->s_wh = splits_of(L2p, Hp, Bp);
+  {
+    // heads backward (dgrad with the ReLU mask of h1 + wgrad) also goes through rv_linear_dgrad_wgrad
+    int paired = 0, bm = 128, sp = 1;
+    rv_dgrad_wgrad_pick(Bp, Hp, L2p, &paired, &bm, &sp);
+    p->s_wh = sp;
+    p->n_mt1 = (int)(Bp / bm);
+  }
   p->s_w1 = splits_of(Hp, Sp, Bp);
   // per-row-tile partial counts follow the tile each producing GEMM will use
   p->n_mt4 = row_tiles(Bp, Sp);   // fc4 fwd: dP4 column sums (db4) and MSE partials
-  p->n_mt1 = row_tiles(Bp, Hp);   // heads dgrad: dP1 column sums (db1)
   {
     int bm = 128, bn = 128;
     rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
@@ -270,58 +275,35 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
                               (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
                           !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
-  if (full_local && p->concurrent == 2 && stream) {
-    // Variant: one fork only -- every GEMM stays on the main stream, the fc3/fc4 optimizer launch
-    // overlaps the last weight-gradient GEMM.
+  // The latent layer's backward (dz + dW3, both read dP3) and the heads' backward (dP1 + dWh, both read
+  // dmulv and h1) each go out as ONE launch (rv_linear_dgrad_wgrad_f32 / rv_linear_dgrad_wgrad).
+  auto latent_bwd = [&](void* st) {
+    return rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
+                                     (float*)p->ws("dW3"), Lp, p->s_w3, st);
+  };
+  auto heads_bwd = [&](void* st) {
+    return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
+                                 (float*)p->ws("dWh"), Hp, p->s_wh, st);
+  };
+  auto reparam_bwd = [&](void* st) {
+    return rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+                          mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, st);
+  };
+  if (full_local && p->concurrent != 0 && stream) {
+    // One fork: everything on the caller's stream except the fc3/fc4 half of Adam, which runs on the side
+    // stream beside the fc1 weight-gradient GEMM (each cross-stream edge costs 6-10 us on this runtime).
     hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
     RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                  (float*)p->ws("dW4"), Hp, p->s_w4, stream));
-    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
-                           p->s_dz, stream));
-    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
-    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
-                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
-                          p->b.step_counter, p->b.ring, stream));
-    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
-                           nullptr, 0, 1, stream));
-    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
-    RV_HIP(hipEventRecord(p->ev[1], s0));
+    RV_TRY(latent_bwd(stream));
+    RV_HIP(hipEventRecord(p->ev[1], s0));  // dW4, db4, dW3, db3 ready; W3b, W4b no longer read
+    RV_TRY(reparam_bwd(stream));
     RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_adam_multi(p->d_slab + 2, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, (void*)s1));
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
-    RV_HIP(hipEventRecord(p->ev[3], s1));
-    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));
-    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, stream));
-    return RV_OK;
-  }
-  if (full_local && p->concurrent == 1 && stream) {
-    // Two-stream backward.  Main stream: the dependent chain fc4 backward (paired dgrad+wgrad) ->
-    // dz -> reparam_bwd -> dgrad heads -> wgrad fc1 -> Adam(fc1, heads).  Side stream: wgrad fc3 ->
-    // wgrad heads -> Adam(fc3, fc4), each gated by an event on the tensor it consumes.
-    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
-    void* v1 = (void*)s1;
-    (void)p->ev[0];
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
-    RV_HIP(hipEventRecord(p->ev[1], s0));  // dP3, db3, dW4 ready; W4b no longer read
-    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
-                           p->s_dz, stream));
-    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
-                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
-                          p->b.step_counter, p->b.ring, stream));
-    RV_HIP(hipEventRecord(p->ev[2], s0));  // dmulv ready; W3b no longer read
-    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, v1));
-    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
-                           nullptr, 0, 1, stream));
-    RV_HIP(hipStreamWaitEvent(s1, p->ev[2], 0));
-    RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, v1));
     RV_TRY(rv_adam_multi(p->d_slab + 6, 4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, v1));
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+                         p->b.step_counter, (void*)s1));
     RV_HIP(hipEventRecord(p->ev[3], s1));
+    RV_TRY(heads_bwd(stream));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
     RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join
     RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
@@ -331,26 +313,23 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const bool old_a = phases & RV_PHASE_BWD_A, old_b = phases & RV_PHASE_BWD_B;
   const bool do_pair = old_a || (phases & RV_PHASE_BWD_FC4);
   const bool do_chain_a = old_a || (phases & RV_PHASE_BWD_CHAIN);   // dz, reparam_bwd
-  const bool do_chain_b = old_b || (phases & RV_PHASE_BWD_CHAIN);   // heads dgrad, fc1 wgrad
-  const bool do_w3 = old_a || (phases & RV_PHASE_BWD_REST);
-  const bool do_wh = old_b || (phases & RV_PHASE_BWD_REST);
+  const bool do_chain_b = old_b || (phases & RV_PHASE_BWD_CHAIN);   // heads dgrad + wgrad (one launch), fc1 wgrad
+  const bool do_w3 = old_a || (phases & RV_PHASE_BWD_REST);         // fc3 wgrad
   if (do_pair)
     RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                  (float*)p->ws("dW4"), Hp, p->s_w4, stream));
-  if (do_chain_a) {
+  if (do_chain_a && do_w3) {
+    RV_TRY(latent_bwd(stream));
+  } else if (do_chain_a) {
     RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
                            p->s_dz, stream));
-    RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv,
-                          (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
-                          p->b.step_counter, p->b.ring, stream));
   }
+  if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
-    RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
-                           nullptr, 0, 1, stream));
+    RV_TRY(heads_bwd(stream));
     RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
   }
-  if (do_w3) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
-  if (do_wh) RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+  if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
 
   // tensor masks (bit i = parameter i in state_dict order)
   unsigned fin = 0, adam = 0;
@@ -444,14 +423,12 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
   // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
   // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
-  RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
-                         p->s_dz, stream));
+  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
+                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
   RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
-  RV_TRY(rv_linear_dgrad(dmulv, L2p, p->ws("Whb"), Hp, Bp, Hp, L2p, h1, Hp, dP1, Hp, (float*)p->ws("db1p"),
-                         nullptr, 0, 1, stream));
-  RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
-  RV_TRY(rv_linear_wgrad(dmulv, L2p, h1, Hp, L2p, Hp, Bp, p->s_wh, (float*)p->ws("dWh"), Hp, stream));
+  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
+                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
   RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
   RV_TRY(rv_grad_finalize(p->d_slab, 8, p->b.grad, stream));  // fc1, fc21, fc22, fc3: contiguous in the arena
   RV_TRY(reduce_bucket(1, 0, 8));

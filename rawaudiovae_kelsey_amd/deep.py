@@ -273,10 +273,9 @@ class DeepTrainEngine:
                                      ptr(self.slabs[wname]), Hp, self.splits[wname], st)
             dy, kd, wname = self.d_dec[i], Hp, "dec.%d.weight" % i
         # dec.0: input is z (no ReLU): dz as fp32 slabs, weight gradient separately
-        L_.rv_linear_dgrad(ptr(dy), Hp, W("dec.0.weight"), Lp, Bp, Lp, Hp, None, 0, None, 0, None,
-                           ptr(self.dz_slabs), Lp, self.s_dz, st)
-        L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.z), Lp, Hp, Lp, Bp, self.splits["dec.0.weight"],
-                           ptr(self.slabs["dec.0.weight"]), Lp, st)
+        L_.rv_linear_dgrad_wgrad_f32(ptr(dy), Hp, W("dec.0.weight"), Lp, ptr(self.z), Lp, Bp, Lp, Hp,
+                                     ptr(self.dz_slabs), Lp, self.s_dz, ptr(self.slabs["dec.0.weight"]), Lp,
+                                     self.splits["dec.0.weight"], st)
         L_.rv_reparam_bwd(ptr(self.dz_slabs), self.s_dz, Bp, Lp, B, L, S, ptr(self.mulv),
                           ptr(eps if eps is not None else self.eps), self.kl_beta, ptr(self.dmulv),
                           ptr(self.dbh_part), ptr(self.mse_part), self.n_mse, ptr(self.kl_part), self.n_kl,

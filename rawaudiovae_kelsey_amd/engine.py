@@ -111,7 +111,8 @@ class TrainEngine:
         self.refresh_shadows()
 
     def set_concurrency(self, enable):
-        """Fork independent backward GEMMs / half of Adam onto a side stream (default on)."""
+        """0 (default): the whole step on the caller's stream; non-zero: the fc3/fc4 half of Adam is forked
+        onto a side stream beside the fc1 weight-gradient GEMM (measured slower at C2: 224 vs 217 us)."""
         lib().rv_plan_set_concurrency(self._plan, int(enable))
 
     def refresh_shadows(self, stream=None):
