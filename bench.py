@@ -9,9 +9,11 @@ step (forward + fused loss + backward + Adam) on synthetic 1024-sample frames.
 Workload (BASELINE.json configs[1] / configs[2]): S=1024, H=2048, L=64, per-GPU batch
 4096, bf16 MFMA inputs with fp32 accumulation, fp32 master weights and Adam state.
 A step is one pass of the hot path over one resident batch (a pool of 8 distinct
-device-resident batches is cycled); eps is drawn on-device.  One process per GPU;
-with N > 1 the fp32 gradients are all-reduced over RCCL in three buckets (fc4, fc1, rest)
-issued as they become available in backward (weak scaling: per-GPU batch fixed).
+device-resident batches is cycled); eps is drawn on-device: one host call per step
+(`rv_plan_step`) enqueues its 12 kernels back to back on one stream (`--graph` replays them from a
+hipGraph instead; measured ~6 us/step slower).  One process per GPU; with N > 1 each step is one
+`rv_plan_step_ddp` call that also issues the two RCCL all-reduces of the fp32 gradients (fc4 | rest)
+as backward produces them (weak scaling: per-GPU batch fixed).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the paired fc4
 backward GEMM launch, the longest kernel of the step), timed live with HIP events; `cpu_baseline`

@@ -139,7 +139,8 @@ template <bool A1, bool B1, int E1, bool A2, bool B2, int E2>
 bool try_dual(int tile, const GemmArgs& a, long Mp1, long Np1, int s1, const GemmArgs& b, long Mp2, long Np2, int s2,
               hipStream_t st, int* rc) {
   if (tile == 0) { *rc = launch_dual<64, 64, 2, 2, 4, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
-  if (tile == 4) { *rc = launch_dual<128, 128, 2, 4, 4, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
+  // two ring slots (64 KiB) so that two blocks share a CU: these GEMMs are short and latency-bound
+  if (tile == 4) { *rc = launch_dual<128, 128, 2, 4, 2, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
   return false;
 }
 
@@ -323,7 +324,7 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
     g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
     g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
     if (td == tw && (Mp / 64) % splits == 0 &&
-        try_dual<true, false, EPI_MASK_BF16, false, false, EPI_F32>(td, d, Mp, Np, 1, g, Kp, Np, splits, (hipStream_t)stream, &rc))
+        try_dual<false, false, EPI_F32, true, false, EPI_MASK_BF16>(td, g, Kp, Np, splits, d, Mp, Np, 1, (hipStream_t)stream, &rc))  // long (wgrad) blocks first
       return rc;
     rc = launch_tile<true, false, EPI_MASK_BF16>(td, d, Mp, Np, Kp, 1, (hipStream_t)stream);
     if (rc) return rc;
