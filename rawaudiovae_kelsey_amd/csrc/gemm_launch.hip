@@ -150,6 +150,9 @@ bool try_dual(int tile, const GemmArgs& a, long Mp1, long Np1, int s1, const Gem
 // partial-sum buffers from it).
 static int choose_tile(long Mp, long Np, int splits) {
   if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) return g_force_tile;
+  // skinny outputs (the heads: N = 2 Lp = 128): 64x64 tiles, 64 KiB of LDS, two blocks per CU
+  // (measured 7.4 us vs 8.4-9.0 on 128x128 for 4096x128x2048)
+  if (Np <= 128) return 0;
   // 256x128 only when it fills the chip without slicing K finely (small-N GEMMs do better on 128x128)
   if (tile_fits(2, Mp, Np) && splits <= 4 && (Mp / 256) * (Np / 128) * splits >= 192) return 2;
   return tile_fits(4, Mp, Np) ? 4 : 0;
@@ -173,6 +176,8 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
   int t = -1;
   if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) {
     t = g_force_tile;
+  } else if (Np <= 128) {
+    t = 0;
   } else if (tile_fits(2, Mp, Np)) {
     const long tl = (Mp / 256) * (Np / 128);
     const int sp = splits_for(tl, kt, max_splits);

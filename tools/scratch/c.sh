@@ -1,2 +1,3 @@
-timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py tests/test_deep_gpu.py -q -m gpu -x 2>&1 | tail -2
-for t in -1 0 4 1; do for sp in 2 4 8 16; do echo -n "tile $t splits $sp: "; RV_TILE=$t SPL_heads=$sp timeout -k 10 100 python tools/gemm_bench.py 2>&1 | grep "heads fwd"; done; done
+timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/full.log 2>&1; tail -3 gpurun_out/full.log
+for rep in 1 2 3; do python bench.py --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step']*1e3,1), d['config']['launch'])"; done
+python tools/deep_bench.py 2>&1 | tail -1 | cut -c1-200
