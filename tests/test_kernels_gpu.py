@@ -367,3 +367,43 @@ def test_paired_dgrad_wgrad(L, force, loop, M, N, K):
     finally:
         L.rv_gemm_force_tile(-1)
         L.rv_gemm_force_tile(108)    # the default
+
+
+@pytest.mark.parametrize("M,N,K,ds,ws", [(512, 64, 256, 2, 4), (4096, 64, 2048, 4, 8), (256, 256, 512, 1, 2), (384, 128, 192, 1, 1)])
+def test_linear_dgrad_wgrad_f32(L, M, N, K, ds, ws):
+    """rv_linear_dgrad_wgrad_f32: dX = dY W as fp32 split slabs and dW = dY^T X slabs -- one dual launch when
+    both GEMMs run on the same small tile (N = 64 / 128), two launches otherwise; M = batch, K = out, N = in."""
+    rng = np.random.default_rng(43)
+    dy, w, x = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N), 0.1), rand_bf16(rng, (M, N))
+    DY, W, X = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+    dx = torch.full((ds, M, N), 3.0, dtype=torch.float32, device="cuda")
+    dw = torch.full((ws, K, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad_wgrad_f32(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N, ds,
+                                dw.data_ptr(), N, ws, sp())
+    ref_dx = dy.astype(np.float64) @ w.astype(np.float64)
+    ref_dw = dy.astype(np.float64).T @ x.astype(np.float64)
+    np.testing.assert_allclose(dx.sum(0).cpu().numpy(), ref_dx, rtol=1e-5, atol=1e-5 * np.abs(ref_dx).max())
+    np.testing.assert_allclose(dw.sum(0).cpu().numpy(), ref_dw, rtol=1e-5, atol=1e-5 * np.abs(ref_dw).max())
+
+
+def test_heads_backward_dual_launch(L):
+    """rv_linear_dgrad_wgrad where the 256x256 pairing does not apply (K = 2 Lp = 128, the heads): the
+    dgrad takes the wgrad's 128x128 tile and both go out in one launch; column sums follow that tile."""
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
+    M, N, K = 1024, 512, 128
+    rng = np.random.default_rng(44)
+    dy, w = rand_bf16(rng, (M, K)), rand_bf16(rng, (K, N), 0.1)
+    x = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
+    paired, bm, splits = dgrad_wgrad_pick(M, N, K)
+    assert paired == 0 and bm == 128
+    DY, W, X = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+    dx = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
+    dw = torch.full((splits, K, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad_wgrad(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N,
+                            cs.data_ptr(), dw.data_ptr(), N, splits, sp())
+    ref_dx = (dy.astype(np.float64) @ w.astype(np.float64)) * (x > 0)
+    ref_dw = dy.astype(np.float64).T @ x.astype(np.float64)
+    assert np.abs(dx.float().cpu().numpy() - ref_dx).max() <= 2 ** -7 * np.abs(ref_dx).max()
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), ref_dx.sum(0), rtol=1e-4, atol=1e-4 * np.abs(ref_dx.sum(0)).max())
+    np.testing.assert_allclose(dw.sum(0).cpu().numpy(), ref_dw, rtol=1e-5, atol=1e-5 * np.abs(ref_dw).max())
