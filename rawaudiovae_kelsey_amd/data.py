@@ -130,6 +130,27 @@ class DeviceAudio:
             yield self.gather(perm[lo:lo + batch_size])
 
 
+    def sharded_batches(self, batch_size, rank, world, shuffle=True, generator=None):
+        """One data-parallel epoch.  The epoch's permutation (the same `generator` state on every rank) is
+        cut into global batches of world * batch_size frames and rank r takes the r-th slice of each; the
+        ragged tail is split evenly, because every rank must step with the same batch size for the mean of
+        rank gradients to be the global-batch gradient (up to world - 1 frames of an epoch are left out)."""
+        n = len(self)
+        if shuffle:
+            perm = torch.randperm(n, generator=generator).to(self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        gb = world * batch_size
+        full = n // gb
+        for i in range(full):
+            lo = i * gb + rank * batch_size
+            yield self.gather(perm[lo:lo + batch_size])
+        tail = (n - full * gb) // world
+        if tail:
+            lo = full * gb + rank * tail
+            yield self.gather(perm[lo:lo + tail])
+
+
 class DeviceEvalAudio(DeviceAudio):
     """TestDataset: non-overlapping frames, tail zero-padded to a whole frame."""
 

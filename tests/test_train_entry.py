@@ -173,3 +173,54 @@ def test_device_audio_epoch_is_a_permutation_with_ragged_tail():
     assert not np.array_equal(got, ref)  # and shuffled
     with pytest.raises(ValueError):
         D.DeviceAudio(audio, 250, 64)
+
+
+@pytest.mark.gpu
+def test_train_py_data_parallel_two_ranks(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 train.py`: both ranks on one GPU with gloo carrying the
+    all-reduces (on a multi-GPU node the same code runs over RCCL).  Rank 0 alone writes the workspace; the
+    replicas must stay identical (train.py raises otherwise); per-rank batch 32 => global batch 64."""
+    import subprocess
+    ds = _dataset(tmp_path)
+    ini = _ini(ds, training__batch_size="32")
+    env = dict(os.environ, RV_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(REPO, "train.py"), "--config", str(ini)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = r.stdout
+    assert out.count("Training Finished: Saved the last model") == 1 and "(data parallel)" in out
+    runs = sorted((ds / "unit").iterdir())
+    assert [p.name for p in runs] == ["run-000"]                       # one workspace, made by rank 0
+    for rel in ("config.ini", "model/checkpoints/ckpt_00004", "model/last_model.pt", "audio_logs/test_reconst_00004.wav"):
+        assert (runs[0] / rel).exists(), rel
+    losses = [float(l.split("Total loss: ")[1].split(" - ")[0]) for l in out.splitlines() if l.startswith("====> Epoch")]
+    assert len(losses) == 4 and losses[-1] < losses[0]
+    ck = torch.load(runs[0] / "model/checkpoints/ckpt_00004", weights_only=False)
+    from rawaudiovae_kelsey_amd import data as D
+    n_frames, _ = D.frame_count(int(1.3 * 8000) + int(0.9 * 8000), 256, 64)
+    per_epoch = n_frames // 64 + (1 if (n_frames % 64) // 2 else 0)    # full global batches + the evenly split tail
+    assert int(ck["optimizer"]["state"][0]["step"]) == 4 * per_epoch
+
+
+def test_sharded_batches_cover_the_epoch_once():
+    """Index logic of the data-parallel epoch (no GPU): every frame of the permutation is used at most once,
+    all ranks get the same batch sizes, and at most world - 1 frames are left out."""
+    from rawaudiovae_kelsey_amd.data import DeviceAudio
+
+    class FakeAudio(DeviceAudio):
+        def __init__(self, n):
+            self.n_frames, self.device = n, torch.device("cpu")
+
+        def gather(self, index, out=None, stream=None):
+            return index
+
+    for n, bs, world in ((1000, 64, 4), (257, 32, 8), (64, 64, 2), (10, 4, 3)):
+        seen, sizes = [], []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(7)
+            got = list(FakeAudio(n).sharded_batches(bs, rank, world, generator=g))
+            sizes.append([len(b) for b in got])
+            seen += [int(v) for b in got for v in b]
+        assert all(s == sizes[0] for s in sizes)
+        assert len(seen) == len(set(seen)) and n - len(seen) < world

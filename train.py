@@ -19,9 +19,17 @@ test_original.wav, test_reconst_%05d.wav}}`), same checkpoint dict keys
   * librosa / soundfile are replaced by scipy wav I/O; TensorBoard is used when importable.
 
 An optional `[mi355x]` section adds `seed`, `loss_ring` and `tensorboard` keys.
+
+Data-parallel training (no counterpart in the reference, which is single-process): launch with
+`python -m torch.distributed.run --nproc-per-node N train.py --config default.ini`, one process per
+GPU.  `batch_size` is then the per-GPU batch (global batch N * batch_size); every rank keeps the
+waveform in its own HBM and takes its slice of each global batch of the shared epoch permutation;
+gradients are averaged over ranks inside `engine.step_ddp` (RCCL); rank 0 alone writes the
+workspace.  The reported epoch loss is the sum over global batches of the rank-mean batch loss.
 """
 import argparse
 import configparser
+import contextlib
 import os
 import sys
 import time
@@ -47,10 +55,83 @@ def read_config(path):
     return config
 
 
-def require_gpu():
+def require_gpu(local_rank=0):
     if not torch.cuda.is_available():
         raise RuntimeError("train.py (MI355X build) needs a GPU: torch.cuda.is_available() is False")
-    return torch.device('cuda')
+    index = local_rank % torch.cuda.device_count()   # the modulo only matters for one-GPU rehearsals
+    torch.cuda.set_device(index)
+    return torch.device('cuda', index)
+
+
+class DataParallel:
+    """Rank bookkeeping + the per-step exchange for train.py under torch.distributed.run."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world, self.rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        self.active = self.world > 1
+        self.device = device
+        self.comm = None
+        if self.active:
+            backend = os.environ.get("RV_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+            if backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch":
+                from rawaudiovae_kelsey_amd import ddp
+                self.comm = ddp.RcclComm()
+                self.comm.self_test(device)
+
+    @property
+    def main(self):
+        return self.rank == 0
+
+    def share(self, obj):
+        """Rank 0's object on every rank."""
+        if not self.active:
+            return obj
+        box = [obj if self.main else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def prepare(self, engine):
+        """Attach the exchange to an engine; returns its step function."""
+        if not self.active:
+            return engine.step
+        if self.comm is not None:
+            engine.attach_comm(self.comm)
+            return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
+        from rawaudiovae_kelsey_amd import ddp
+        sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
+        return lambda x: ddp.ddp_step(engine, sync, x)
+
+    def mean(self, value):
+        """Mean over ranks of a host scalar."""
+        if not self.active:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t)
+        return float(t.item()) / self.world
+
+    def check_replicas(self, engine):
+        if not self.active:
+            return
+        chk = torch.stack([engine.param.double().sum(), engine.param.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("data-parallel replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()))
+
+    def close(self):
+        if self.active:
+            torch.cuda.synchronize()
+            if self.comm is not None:
+                self.comm.destroy()
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 def make_workspace(dataset, desc, run_number):
@@ -158,48 +239,57 @@ def main(argv=None):
     ring = int(hw.get('loss_ring', 256))
     use_tb = str(hw.get('tensorboard', 'True')).lower() in ('1', 'true', 'yes')
 
-    device = require_gpu()
+    device = require_gpu(int(os.environ.get("LOCAL_RANK", "0")))
+    dp = DataParallel(device)
+    say = print if dp.main else (lambda *a, **k: None)
     device_name = torch.cuda.get_device_name()
-    print('Device: {}'.format(device_name))
+    say('Device: {}'.format(device_name) + (' x {} (data parallel)'.format(dp.world) if dp.active else ''))
     config['VAE']['device_name'] = device_name
 
-    workdir = make_workspace(dataset, desc, run_number)
+    workdir = dp.share(make_workspace(dataset, desc, run_number) if dp.main else None)
     config['dataset']['workspace'] = str(workdir.resolve())
-    print("Workspace: {}".format(workdir))
+    say("Workspace: {}".format(workdir))
 
-    print('creating the dataset...')
-    training_array = load_folder(my_audio, sampling_rate)
+    say('creating the dataset...')
+    training_array = load_folder(my_audio, sampling_rate, verbose=dp.main)
     total_frames = len(training_array) // segment_length
-    print('Total number of audio frames: {}'.format(total_frames))
+    say('Total number of audio frames: {}'.format(total_frames))
     config['dataset']['total_frames'] = str(total_frames)
     training_dataset = D.DeviceAudio(training_array, segment_length, hop_length, device)
-    n_batches = training_dataset.num_batches(batch_size)
+    n_batches = training_dataset.num_batches(batch_size * dp.world)
 
-    print("saving initial configs...")
     config_path = workdir / 'config.ini'
-    with open(config_path, 'w') as configfile:
-        config.write(configfile)
-
     checkpoint_dir = workdir / 'model' / 'checkpoints'
-    os.makedirs(checkpoint_dir, exist_ok=True)
     log_dir = workdir / 'logs'
-    os.makedirs(log_dir, exist_ok=True)
-    writer = Writer(log_dir, use_tb)
+    if dp.main:
+        print("saving initial configs...")
+        with open(config_path, 'w') as configfile:
+            config.write(configfile)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        os.makedirs(log_dir, exist_ok=True)
+    writer = Writer(log_dir, use_tb and dp.main)
 
-    if generate_test:
+    if generate_test and dp.main:
         test_dataset, audio_log_dir = init_test_audio(workdir, test_audio, dataset_test_audio, sampling_rate,
                                                       segment_length, device)
 
-    torch.manual_seed(seed)
+    torch.manual_seed(seed)   # same seed on every rank: identical initial replicas
     model = VAE(segment_length, n_units, latent_dim).to(device)
-    full = min(batch_size, len(training_dataset))
+    n_frames = len(training_dataset)
+    if n_frames < dp.world:
+        raise ValueError("{} frames cannot be split over {} ranks".format(n_frames, dp.world))
+    full = min(batch_size, n_frames // dp.world)                 # per-rank batch
+    ragged = (n_frames % (full * dp.world)) // dp.world          # per-rank size of the epoch's last step
     engine = TrainEngine(segment_length, n_units, latent_dim, full, device=device, kl_beta=kl_beta,
-                         lr=learning_rate, seed=seed, ring=ring)
+                         lr=learning_rate, seed=seed + dp.rank, ring=ring)   # per-rank eps stream
     engine.adopt(model)
-    ragged = len(training_dataset) % full
     tail_engine = TrainEngine(segment_length, n_units, latent_dim, ragged, device=device, kl_beta=kl_beta,
-                              lr=learning_rate, seed=seed, share=engine) if ragged else None
-    shuffle_gen = torch.Generator().manual_seed(seed)
+                              lr=learning_rate, seed=seed + dp.rank, share=engine) if ragged else None
+    step_full = dp.prepare(engine)
+    step_tail = dp.prepare(tail_engine) if tail_engine is not None else None
+    # the data-parallel step forks its collectives from the caller's stream: it needs a non-default one
+    train_stream = torch.cuda.Stream(device) if dp.active else None
+    shuffle_gen = torch.Generator().manual_seed(seed)   # the same permutation on every rank
 
     def checkpoint_state(epoch):
         return {'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': engine.optimizer_state_dict()}
@@ -216,8 +306,8 @@ def main(argv=None):
     train_loss = 0.0
     epoch = 0
     for epoch in range(epochs):
-        print('Epoch {}/{}'.format(epoch, epochs - 1))
-        print('-' * 10)
+        say('Epoch {}/{}'.format(epoch, epochs - 1))
+        say('-' * 10)
         model.train()
         train_loss = 0.0
         seen = 0
@@ -230,20 +320,29 @@ def main(argv=None):
                 train_loss += v
                 seen += 1
 
-        for i, batch in enumerate(training_dataset.batches(batch_size, shuffle=True, generator=shuffle_gen)):
-            (engine if batch.shape[0] == full else tail_engine).step(batch)
-            if (i + 1) % ring == 0:
-                drain()
-        drain()
+        if dp.active:
+            epoch_batches = training_dataset.sharded_batches(full, dp.rank, dp.world, shuffle=True, generator=shuffle_gen)
+        else:
+            epoch_batches = training_dataset.batches(batch_size, shuffle=True, generator=shuffle_gen)
+        with torch.cuda.stream(train_stream) if train_stream is not None else contextlib.nullcontext():
+            for i, batch in enumerate(epoch_batches):
+                (step_full if batch.shape[0] == full else step_tail)(batch)
+                if (i + 1) % ring == 0:
+                    drain()
+            drain()
+        if train_stream is not None:
+            train_stream.synchronize()     # evaluation / checkpoints below read the parameters on the default stream
+        train_loss = dp.mean(train_loss)   # global-batch loss = mean of the ranks' batch losses
 
-        print('====> Epoch: {} - Total loss: {} - Average loss: {:.9f}'.format(
+        say('====> Epoch: {} - Total loss: {} - Average loss: {:.9f}'.format(
             epoch, train_loss, train_loss / len(training_dataset)))
         writer.add_scalar('Loss/train_total', train_loss, epoch)
         writer.add_scalar('Loss/train_average', train_loss / len(training_dataset), epoch)
-        for name, param in model.named_parameters():
-            writer.add_histogram(name, param, epoch)
+        if dp.main:
+            for name, param in model.named_parameters():
+                writer.add_histogram(name, param, epoch)
 
-        if epoch % checkpoint_interval == 0 and epoch != 0:
+        if epoch % checkpoint_interval == 0 and epoch != 0 and dp.main:
             print('Checkpoint - Epoch {}'.format(epoch))
             if generate_test:
                 write_reconstruction(epoch, epoch)
@@ -258,25 +357,28 @@ def main(argv=None):
                 print("Loss did not improve.")
         final_loss = train_loss
 
-    print('Last Checkpoint - Epoch {}'.format(epoch))
-    if generate_test:
-        write_reconstruction(epochs, epoch)
-    torch.save(checkpoint_state(epoch), checkpoint_dir / 'ckpt_{:05d}'.format(epochs))
+    dp.check_replicas(engine)
+    if dp.main:
+        print('Last Checkpoint - Epoch {}'.format(epoch))
+        if generate_test:
+            write_reconstruction(epochs, epoch)
+        torch.save(checkpoint_state(epoch), checkpoint_dir / 'ckpt_{:05d}'.format(epochs))
 
-    if final_loss > best_loss:
-        print("Final loss was not better than the last best model.")
-        print("Final Loss: {}".format(final_loss))
-        print("Best Loss: {}".format(best_loss))
-    else:
-        print("The last model is the best model.")
-    torch.save(model, workdir / 'model' / 'last_model.pt')
-    print('Training Finished: Saved the last model')
+        if final_loss > best_loss:
+            print("Final loss was not better than the last best model.")
+            print("Final Loss: {}".format(final_loss))
+            print("Best Loss: {}".format(best_loss))
+        else:
+            print("The last model is the best model.")
+        torch.save(model, workdir / 'model' / 'last_model.pt')
+        print('Training Finished: Saved the last model')
 
-    config['extra']['end'] = time.asctime(time.localtime(time.time()))
-    config['extra']['time_elapsed'] = str(time.time() - start_time)
-    with open(config_path, 'w') as configfile:
-        config.write(configfile)
+        config['extra']['end'] = time.asctime(time.localtime(time.time()))
+        config['extra']['time_elapsed'] = str(time.time() - start_time)
+        with open(config_path, 'w') as configfile:
+            config.write(configfile)
     writer.close()
+    dp.close()
     return workdir
 
 
