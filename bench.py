@@ -195,6 +195,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             one_step(args.warmup + i)
+        host_dt = time.perf_counter() - t0     # all K steps enqueued (the host runs ahead of the GPU)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -239,6 +240,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
                        "grad_allreduce": ddp_mode},
+            "host_us_per_step": host_dt / args.steps * 1e6,
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             # algorithmic HBM bytes per step: 54,784 B/frame of activations + 38 B/param
