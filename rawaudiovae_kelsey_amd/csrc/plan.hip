@@ -57,7 +57,6 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
-  void* comm_scratch = nullptr;  // 256 B: a one-rank group (rehearsal) still puts a real node on comm_stream
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -160,7 +159,6 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
-  if (p->comm_scratch) (void)hipFree(p->comm_scratch);
   delete p;
 }
 
@@ -376,7 +374,6 @@ int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int w
     RV_HIP(hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, hi));
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    RV_HIP(hipMalloc(&p->comm_scratch, 256));
   }
   p->allreduce = allreduce;
   p->comm = comm;
@@ -406,20 +403,20 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   auto reduce_bucket = [&](int b, int t0, int t1) -> int {
     RV_HIP(hipEventRecord(p->ev_ready[b], s0));
     RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
+    // slabs -> flat fp32 payload on the collective stream too: it overlaps the caller's next kernels
+    int frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, (void*)sc);
+    if (frc) return frc;
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
     const int nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
                                  p->comm, (void*)sc);
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-reduce of gradient bucket %d failed (collective library code %d)", b, nrc);
-    // a one-rank all-reduce enqueues nothing; keep the stream's branch of a captured graph non-empty
-    if (p->world == 1) RV_HIP(hipMemsetAsync(p->comm_scratch, 0, 256, sc));
     RV_HIP(hipEventRecord(p->ev_done[b], sc));
     return RV_OK;
   };
-  // forward + loss, the paired fc4 backward, and the fc4 gradient into the flat arena (as rv_plan_step)
+  // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                (float*)p->ws("dW4"), Hp, p->s_w4, stream));
-  RV_TRY(rv_grad_finalize(p->d_slab + 8, 2, p->b.grad, stream));
   RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
   // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
   // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
@@ -430,8 +427,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
   RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
-  RV_TRY(rv_grad_finalize(p->d_slab, 8, p->b.grad, stream));  // fc1, fc21, fc22, fc3: contiguous in the arena
-  RV_TRY(reduce_bucket(1, 0, 8));
+  RV_TRY(reduce_bucket(1, 0, 8));          // fc1, fc21, fc22, fc3: contiguous in the arena
   // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));
   RV_TRY(rv_adam_multi(p->d_flat + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
