@@ -214,6 +214,30 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if rank == 0 and not torch.equal(lo, hi):
                 print("bench.py: WARNING replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
+        # Not the headline: the same K steps again with the bf16 gradient payload (half the all-reduce
+        # bytes), so that one run shows what the exchange costs at this GPU count.
+        alt = None
+        if isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
+            runner.set_payload("bf16")
+            for i in range(5):
+                one_step(i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            adt = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([adt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                adt = float(t.item())
+            alt = {"grad_allreduce": "bf16 payload, same schedule", "ms_per_step": adt / args.steps * 1e3,
+                   "value": float(B) * world * args.steps / adt}
+            runner.set_payload("fp32")
         kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
@@ -241,6 +265,7 @@ def main():
                        "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
                        "grad_allreduce": ddp_mode},
             "host_us_per_step": host_dt / args.steps * 1e6,
+            **({"alt_bf16_payload": alt} if alt else {}),
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             # algorithmic HBM bytes per step: 54,784 B/frame of activations + 38 B/param

@@ -241,6 +241,15 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
  * what loss.backward() leaves in .grad; also the all-reduce payload builder. */
 int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream);
 
+/* bf16 variants for the data-parallel exchange (halves the all-reduce bytes; the in-rank sums stay
+ * fp32): rv_grad_finalize_bf16 rounds the summed gradient to a flat bf16 arena (same element offsets
+ * as the fp32 arenas); rv_adam_multi_bf16grad takes the gradient from such an arena (after its
+ * all-reduce) instead of the descriptors' slabs. */
+int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out_bf16, void* stream);
+int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                           float* exp_avg_sq, const void* grad_bf16, float lr, float grad_scale,
+                           const long long* step_counter, void* stream);
+
 /* ---- whole-step plan: one call enqueues forward, loss, backward (and Adam) ---- */
 typedef struct rv_plan rv_plan;
 
@@ -303,6 +312,9 @@ int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* 
 typedef int (*rv_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
                                void* comm, void* stream);
 int rv_plan_attach_comm(rv_plan*, rv_allreduce_fn allreduce, void* comm, int world);
+/* Payload of the gradient all-reduces: 0 = fp32 (default, exact mean of the ranks' fp32 gradients),
+ * 1 = bf16 (each rank's summed gradient rounded to bf16, summed by the collective in bf16). */
+int rv_plan_set_ddp_payload(rv_plan*, int bf16);
 int rv_plan_step_ddp(rv_plan*, const float* x, const float* eps, float* recon_out, float kl_beta,
                      float lr, unsigned long long seed, void* stream);
 /* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */

@@ -96,6 +96,10 @@ _SIGS = {
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_attach_comm": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "rv_plan_set_ddp_payload": (c_int, [c_void_p, c_int]),
+    "rv_grad_finalize_bf16": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
+    "rv_adam_multi_bf16grad": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_float, c_void_p, c_void_p]),
     "rv_plan_step_ddp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
     "rv_graph_begin": (c_int, [c_void_p]),

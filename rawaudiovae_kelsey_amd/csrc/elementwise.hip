@@ -520,7 +520,8 @@ template <bool UPDATE>
 __global__ void __launch_bounds__(256)
 k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
        float* __restrict__ v_arena, float* __restrict__ grad_out, float lr, float grad_scale,
-       const long long* __restrict__ step_counter) {
+       const long long* __restrict__ step_counter, bf16_t* __restrict__ grad_out_bf16,
+       const bf16_t* __restrict__ grad_in_bf16) {
   int t = 0;
   while (t + 1 < tab.n && (long)blockIdx.x >= tab.blk_start[t + 1]) ++t;
   const rv_param_desc d = tab.d[t];
@@ -555,7 +556,18 @@ k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_are
     }
   }
   float4 g;
-  if (coop) {
+  if (grad_in_bf16) {
+    // gradient = flat bf16 arena (the data-parallel payload after its all-reduce), same element offsets
+    if (coop && (threadIdx.x & 63) != 0) return;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && (reinterpret_cast<uintptr_t>(grad_in_bf16) & 7) == 0) {
+      const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(grad_in_bf16 + o);
+      t4[0] = (float)b4[0]; t4[1] = (float)b4[1]; t4[2] = (float)b4[2]; t4[3] = (float)b4[3];
+    } else {
+      for (int j = 0; j < nvalid; ++j) t4[j] = (float)grad_in_bf16[o + j];
+    }
+    g = make_float4(t4[0], t4[1], t4[2], t4[3]);
+  } else if (coop) {
     // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
     const int lane = threadIdx.x & 63;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -576,6 +588,14 @@ k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_are
     if (vec) *reinterpret_cast<float4*>(grad_out + o) = g;
     else
       for (int j = 0; j < nvalid; ++j) grad_out[o + j] = gv[j];
+  }
+  if (grad_out_bf16) {
+    if (vec && (reinterpret_cast<uintptr_t>(grad_out_bf16) & 7) == 0) {
+      const bf16x4 b4 = {(bf16_t)gv[0], (bf16_t)gv[1], (bf16_t)gv[2], (bf16_t)gv[3]};
+      *reinterpret_cast<bf16x4*>(grad_out_bf16 + o) = b4;
+    } else {
+      for (int j = 0; j < nvalid; ++j) grad_out_bf16[o + j] = (bf16_t)gv[j];
+    }
   }
   if constexpr (UPDATE) {
     // bias corrections 1-b^t through the hardware exp2 (b^t = 2^(t log2 b)); relative error ~1e-6
@@ -802,7 +822,21 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
-                     step_counter);
+                     step_counter, (bf16_t*)nullptr, (const bf16_t*)nullptr);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                           float* exp_avg_sq, const void* grad_bf16, float lr, float grad_scale,
+                           const long long* step_counter, void* stream) {
+  RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter && grad_bf16, RV_ERR_NULL, "rv_adam_multi_bf16grad: null pointer");
+  DescTable tab;
+  int rc = build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
+                     (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, (float*)nullptr, lr, grad_scale,
+                     step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -814,7 +848,19 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, vo
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, grad_out,
-                     0.f, 1.f, (const long long*)nullptr);
+                     0.f, 1.f, (const long long*)nullptr, (bf16_t*)nullptr, (const bf16_t*)nullptr);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out_bf16, void* stream) {
+  RV_REQUIRE(grad_out_bf16, RV_ERR_NULL, "rv_grad_finalize_bf16: null pointer");
+  DescTable tab;
+  int rc = build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
+                     (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     0.f, 1.f, (const long long*)nullptr, (bf16_t*)grad_out_bf16, (const bf16_t*)nullptr);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

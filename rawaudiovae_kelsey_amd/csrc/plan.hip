@@ -57,6 +57,8 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+  int payload_bf16 = 0;
+  void* grad_bf16 = nullptr;   // flat bf16 payload arena (allocated when the bf16 payload is first selected)
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -159,6 +161,7 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+  if (p->grad_bf16) (void)hipFree(p->grad_bf16);
   delete p;
 }
 
@@ -381,6 +384,13 @@ int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int w
   return RV_OK;
 }
 
+int rv_plan_set_ddp_payload(rv_plan* p, int bf16) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_ddp_payload: null plan");
+  if (bf16 && !p->grad_bf16) RV_HIP(hipMalloc(&p->grad_bf16, (size_t)p->n_params * 2));
+  p->payload_bf16 = bf16 ? 1 : 0;
+  return RV_OK;
+}
+
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                      unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
@@ -403,12 +413,20 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   auto reduce_bucket = [&](int b, int t0, int t1) -> int {
     RV_HIP(hipEventRecord(p->ev_ready[b], s0));
     RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
-    // slabs -> flat fp32 payload on the collective stream too: it overlaps the caller's next kernels
-    int frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, (void*)sc);
-    if (frc) return frc;
+    // slabs -> flat payload on the collective stream too: it overlaps the caller's next kernels
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
-    const int nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
-                                 p->comm, (void*)sc);
+    int frc, nrc;
+    if (p->payload_bf16) {
+      frc = rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, (void*)sc);
+      if (frc) return frc;
+      char* g = (char*)p->grad_bf16 + 2 * lo;
+      nrc = p->allreduce(g, g, (size_t)(hi - lo), /*ncclBfloat16*/ 9, /*ncclSum*/ 0, p->comm, (void*)sc);
+    } else {
+      frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, (void*)sc);
+      if (frc) return frc;
+      nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
+                         p->comm, (void*)sc);
+    }
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-reduce of gradient bucket %d failed (collective library code %d)", b, nrc);
     RV_HIP(hipEventRecord(p->ev_done[b], sc));
     return RV_OK;
@@ -430,11 +448,16 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(reduce_bucket(1, 0, 8));          // fc1, fc21, fc22, fc3: contiguous in the arena
   // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));
-  RV_TRY(rv_adam_multi(p->d_flat + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
-                       p->b.step_counter, stream));
+  auto adam_bucket = [&](int t0, int n) -> int {
+    if (p->payload_bf16)
+      return rv_adam_multi_bf16grad(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, p->grad_bf16, lr,
+                                    scale, p->b.step_counter, stream);
+    return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
+                         p->b.step_counter, stream);
+  };
+  RV_TRY(adam_bucket(8, 2));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
-  RV_TRY(rv_adam_multi(p->d_flat, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
-                       p->b.step_counter, stream));
+  RV_TRY(adam_bucket(0, 8));
 #undef RV_TRY
   return RV_OK;
 }

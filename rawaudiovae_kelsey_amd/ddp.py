@@ -203,9 +203,16 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False):
+    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32"):
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
         engine.attach_comm(comm)
+        self._graphs = {}
+        self.set_payload(payload)
+
+    def set_payload(self, payload):
+        """"fp32" or "bf16" gradient exchange (captured graphs are dropped: the payload is baked in)."""
+        self.engine.set_ddp_payload(payload)
+        self.payload = payload
         self._graphs = {}
 
     def step(self, x):

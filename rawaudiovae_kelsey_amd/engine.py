@@ -162,6 +162,14 @@ class TrainEngine:
         lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
         self._comm = comm   # keep the communicator alive as long as the plan can use it
 
+    def set_ddp_payload(self, payload):
+        """Gradient all-reduce payload of `step_ddp`: "fp32" (default; exact mean of the ranks' fp32
+        gradients) or "bf16" (half the bytes: each rank's summed gradient is rounded to bf16 before the
+        exchange, which then sums in bf16)."""
+        if payload not in ("fp32", "bf16"):
+            raise _lib.RvError("set_ddp_payload: %r (expected 'fp32' or 'bf16')" % (payload,))
+        lib().rv_plan_set_ddp_payload(self._plan, int(payload == "bf16"))
+
     def step_ddp(self, x, eps=None, recon_out=None, stream=None):
         """One whole data-parallel training step in one host call (`rv_plan_step_ddp`): every rank
         calls it once per batch; gradients are averaged over ranks before Adam."""

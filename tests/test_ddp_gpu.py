@@ -71,6 +71,20 @@ with torch.cuda.stream(st):
 st.synchronize()
 assert torch.equal(gr.param, ref.param), "graph-replayed native step differs"
 assert gr.steps_done() == 4
+# bf16 payload: the summed gradient is rounded to bf16 before the exchange; Adam's first steps move every
+# weight by ~lr whatever the gradient's magnitude, so the parameters stay within a fraction of lr of the
+# fp32-payload run (sign flips of near-zero gradients aside) and the loss trajectory within 1e-4
+bf = fresh(); bf.attach_comm(comm); bf.set_ddp_payload("bf16")
+with torch.cuda.stream(st):
+    for _ in range(4):
+        bf.step_ddp(x, stream=st)
+st.synchronize()
+d = (bf.param - ref.param).abs()
+assert float(d.max()) <= 2.1 * 4 * 1e-4 and float(d.mean()) < 0.02 * 4 * 1e-4, (float(d.max()), float(d.mean()))
+assert not torch.equal(bf.param, ref.param)
+for a, b in zip(bf.losses(4), ref.losses(4)):
+    assert abs(a - b) <= 1e-4 * abs(b)
+bf.set_ddp_payload("fp32")
 comm.destroy()
 dist.destroy_process_group()
 print("NATIVE_OK")

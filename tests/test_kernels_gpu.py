@@ -407,3 +407,35 @@ def test_heads_backward_dual_launch(L):
     assert np.abs(dx.float().cpu().numpy() - ref_dx).max() <= 2 ** -7 * np.abs(ref_dx).max()
     np.testing.assert_allclose(cs.sum(0).cpu().numpy(), ref_dx.sum(0), rtol=1e-4, atol=1e-4 * np.abs(ref_dx.sum(0)).max())
     np.testing.assert_allclose(dw.sum(0).cpu().numpy(), ref_dw, rtol=1e-5, atol=1e-5 * np.abs(ref_dw).max())
+
+
+def test_bf16_gradient_payload_kernels(L):
+    """rv_grad_finalize_bf16 == bf16(rv_grad_finalize), and rv_adam_multi_bf16grad == rv_adam_multi fed the
+    same (already bf16-valued) gradient."""
+    from rawaudiovae_kelsey_amd._lib import ParamDesc
+    rng = np.random.default_rng(45)
+    rows, cols, splits = 37, 50, 3
+    slabs = dev(rng.standard_normal((splits, rows, cols)).astype(np.float32))
+    d = (ParamDesc * 1)(ParamDesc(8, rows, cols, slabs.data_ptr(), cols, rows * cols, splits, None, None, 0))
+    n = 8 + rows * cols + 5
+    g32 = torch.zeros(n, device="cuda")
+    g16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    L.rv_grad_finalize(d, 1, g32.data_ptr(), sp())
+    L.rv_grad_finalize_bf16(d, 1, g16.data_ptr(), sp())
+    assert torch.equal(g16, g32.to(torch.bfloat16))
+    step = torch.tensor([3], dtype=torch.int64, device="cuda")
+    outs = []
+    for use_bf16 in (False, True):
+        p = dev(rng.standard_normal(n).astype(np.float32) * 0 + 0.5)
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        if use_bf16:
+            L.rv_adam_multi_bf16grad(d, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(), 1e-3, 0.5,
+                                     step.data_ptr(), sp())
+        else:
+            flat = g16.float()
+            df = (ParamDesc * 1)(ParamDesc(8, rows, cols, flat.data_ptr() + 4 * 8, cols, 0, 1, None, None, 0))
+            L.rv_adam_multi(df, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), None, 1e-3, 0.5, step.data_ptr(), sp())
+        torch.cuda.synchronize()
+        outs.append((p.clone(), m.clone(), v.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
