@@ -218,26 +218,30 @@ def main():
         # bytes), so that one run shows what the exchange costs at this GPU count.
         alt = None
         if isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
-            runner.set_payload("bf16")
-            for i in range(5):
-                one_step(i)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                one_step(i)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            adt = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([adt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                adt = float(t.item())
-            alt = {"grad_allreduce": "bf16 payload, same schedule", "ms_per_step": adt / args.steps * 1e3,
-                   "value": float(B) * world * args.steps / adt}
-            runner.set_payload("fp32")
+            try:
+                runner.set_payload("bf16")
+                for i in range(5):
+                    one_step(i)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    one_step(i)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                adt = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([adt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    adt = float(t.item())
+                alt = {"grad_allreduce": "bf16 payload, same schedule", "ms_per_step": adt / args.steps * 1e3,
+                       "value": float(B) * world * args.steps / adt}
+            except Exception as exc:   # the headline above is already measured: report, do not lose it
+                alt = {"grad_allreduce": "bf16 payload, same schedule", "error": str(exc)[:200]}
+            finally:
+                runner.set_payload("fp32")
         kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
