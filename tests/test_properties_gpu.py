@@ -176,3 +176,23 @@ def test_reference_default_ini_batch_131072():
     assert rel < 5e-5, rel
     # last rows of the last chunk: same GEMM inputs, only the split-K count (fp32 summation order) differs
     assert torch.allclose(mu_big, small.outputs()[0][-3:], rtol=0, atol=2e-6)
+
+
+def test_soak_two_thousand_steps_bit_reproducible():
+    """Race screen for the hand-placed LDS-DMA waits / barriers (ping-pong and ring main loops, dual
+    launches): 2000 full-size steps on cycling batches, twice from the same state -- any tile read before
+    its DMA landed, even once, shows up as a differing bit in the final parameters or the loss ring."""
+    xs = [torch.from_numpy(make_frames(B, S, 50 + i)).cuda() for i in range(4)]
+    st = torch.cuda.Stream()
+    runs = []
+    for _ in range(2):
+        e = _engine(B, seed=21, ring=2048)
+        with torch.cuda.stream(st):
+            for i in range(2000):
+                e.step(xs[i % 4], stream=st)
+        st.synchronize()
+        runs.append((e.param.clone(), e.exp_avg_sq.clone(), torch.tensor(e.losses(2000))))
+        del e
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][2], runs[1][2])
+    assert bool(torch.isfinite(runs[0][2]).all()) and float(runs[0][2][-1]) < float(runs[0][2][0])
