@@ -63,6 +63,19 @@ with torch.cuda.stream(st):
 st.synchronize()
 assert torch.equal(eager.param, ref.param), "eager native step differs"
 assert eager.losses(4) == ref.losses(4)
+# 300 more steps enqueued without a host sync (events and the collective stream are reused while
+# earlier steps are still in flight): still bit-identical to the local step
+with torch.cuda.stream(st):
+    for _ in range(300):
+        eager.step_ddp(x, stream=st)
+        ref.step(x, stream=st)
+st.synchronize()
+assert torch.equal(eager.param, ref.param) and torch.equal(eager.exp_avg_sq, ref.exp_avg_sq)
+ref = fresh()
+with torch.cuda.stream(st):
+    for _ in range(4):
+        ref.step(x, stream=st)
+st.synchronize()
 gr = fresh()
 run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True)
 with torch.cuda.stream(st):
