@@ -154,3 +154,32 @@ def test_header_is_plain_c_and_matches_the_library(tmp_path):
                     "-L", libdir, "-l:librawvae_hip.so", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[:5] == ["100", "4096", "1024", "2048", "64"]
+
+
+def test_host_logic_under_asan_ubsan(tmp_path):
+    """SURVEY 5 (race detection / sanitizers): the native host code now exists, so its pure-host logic
+    (pickers, descriptor tables, argument checks, error strings) runs under ASan + UBSan on the CPU.
+    Device code is compiled normally (`-fno-gpu-sanitize`; GPU sanitizers are not available on this pool)."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(REPO, "rawaudiovae_kelsey_amd", "csrc")
+    flags = ["--offload-arch=gfx950", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer",
+             "-g", "-O1", "-std=c++17", "-fPIC"]
+    objs = []
+    for name in ("gemm_launch", "elementwise", "plan", "linear_fp32"):
+        o = str(tmp_path / (name + ".o"))
+        r = subprocess.run(["hipcc"] + flags + ["-c", os.path.join(src, name + ".hip"), "-o", o],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        objs.append(o)
+    exe = str(tmp_path / "host_checks")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-g",
+                        "-I", os.path.join(REPO, "include"), "-x", "c++", os.path.join(REPO, "tests", "host", "host_checks.cpp"),
+                        "-x", "none"] + objs + ["-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
