@@ -319,7 +319,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   const int item = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   const int split = item / nt, tid_lin = item - split * nt;
-  const int tile_m = tid_lin / tiles_n, tile_n = tid_lin - tile_m * tiles_n;
+  // within a split, tiles are enumerated in 4x4 super-tiles where the grid allows it, so that an XCD's
+  // contiguous run of items is a near-square patch: fewer distinct A row panels + B column panels stream
+  // through its private L2 than with row-major order (a 2 x 16 strip needs 1 + 4 MB at C2, a 4 x 8 patch 2 + 2)
+  int tile_m, tile_n;
+  if (((tiles_n | p.tiles_m) & 3) == 0) {
+    const int sn = tiles_n >> 2, s4 = tid_lin >> 4, w4 = tid_lin & 15;
+    tile_m = (s4 / sn) * 4 + (w4 >> 2);
+    tile_n = (s4 % sn) * 4 + (w4 & 3);
+  } else {
+    tile_m = tid_lin / tiles_n;
+    tile_n = tid_lin - tile_m * tiles_n;
+  }
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const long k0 = (long)split * p.k_tiles * 64;
 
