@@ -138,7 +138,9 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
 template <bool A1, bool B1, int E1, bool A2, bool B2, int E2>
 bool try_dual(int tile, const GemmArgs& a, long Mp1, long Np1, int s1, const GemmArgs& b, long Mp2, long Np2, int s2,
               hipStream_t st, int* rc) {
-  if (tile == 0) { *rc = launch_dual<64, 64, 2, 2, 4, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
+  // dual launches run on two ring slots: more co-resident blocks hide the latency of these short GEMMs
+  // (measured ~1 us/step better than four slots for the 64x64 pair; the opposite holds for a lone 64x64 GEMM)
+  if (tile == 0) { *rc = launch_dual<64, 64, 2, 2, 2, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
   // two ring slots (64 KiB) so that two blocks share a CU: these GEMMs are short and latency-bound
   if (tile == 4) { *rc = launch_dual<128, 128, 2, 4, 2, A1, B1, E1, A2, B2, E2>(a, Mp1, Np1, s1, b, Mp2, Np2, s2, st); return true; }
   return false;
