@@ -11,7 +11,9 @@
  *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures
  *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
  *   - every pointer is a DEVICE pointer owned by the caller; the library allocates
- *     nothing except the opaque rv_plan / rv_graph host objects.
+ *     nothing except the opaque rv_plan / rv_graph host objects, a plan's internal
+ *     streams and events, and -- only when the bf16 data-parallel payload is selected
+ *     (rv_plan_set_ddp_payload) -- that plan's flat bf16 gradient arena.
  *   - every function returns 0 on success or a negative RV_ERR_* code;
  *     rv_last_error() gives the message.  Nothing throws, aborts or synchronises
  *     unless its name ends in _sync; all launches are safe under stream capture.
