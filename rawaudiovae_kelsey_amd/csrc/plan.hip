@@ -411,19 +411,20 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   // forks from and joins into the caller's stream only (a helper stream forking from another helper
   // stream makes hipStreamEndCapture recurse without end in this HIP runtime).
   auto reduce_bucket = [&](int b, int t0, int t1) -> int {
-    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
-    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
-    // slabs -> flat payload on the collective stream too: it overlaps the caller's next kernels
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
     int frc, nrc;
+    // slabs -> flat payload on the caller's stream: with exchanges that take as long as the backward that
+    // hides them (tools/ddp_occupancy_probe.py) the collective stream is the critical path, and a payload
+    // kernel queued there behind the previous exchange costs 20+ us per step; here it costs ~9
+    if (p->payload_bf16) frc = rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, stream);
+    else frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, stream);
+    if (frc) return frc;
+    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
+    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
     if (p->payload_bf16) {
-      frc = rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, (void*)sc);
-      if (frc) return frc;
       char* g = (char*)p->grad_bf16 + 2 * lo;
       nrc = p->allreduce(g, g, (size_t)(hi - lo), /*ncclBfloat16*/ 9, /*ncclSum*/ 0, p->comm, (void*)sc);
     } else {
-      frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, (void*)sc);
-      if (frc) return frc;
       nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
                          p->comm, (void*)sc);
     }
