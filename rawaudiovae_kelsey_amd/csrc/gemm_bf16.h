@@ -59,6 +59,8 @@ struct GemmArgs {
   float* colsum;    // [grid.y][grid.x*BN] per-row-tile column sums of the bf16 output
   float* blocksum;  // [grid.y*grid.x] per-block sum of (recon-x)^2
   float scale;      // 2/(B*S)
+  int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
+                    // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
 };
 
 template <int ROWS>
@@ -345,7 +347,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (PINGPONG) {
+  if (p.dbg & 4) {
+    // diagnostic: epilogue only
+  } else if constexpr (PINGPONG) {
     mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
@@ -476,6 +480,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   second_half(F_{}, F_{}, kt, slot, slot);
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses LDS
+  if (p.dbg & 2) {  // diagnostic: main loop only (the accumulators stay live)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+    return;
+  }
+  const bool mem = !(p.dbg & 1);  // diagnostic: epilogue arithmetic and LDS staging without global traffic
 
   // ------------------------------ epilogue ------------------------------
   // acc[mi][ni][j] = C[wave row mi*16 + (lane>>4)*4 + j][wave col ni*16 + (lane&15)].
@@ -547,7 +559,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           if (p.relu) t = fmaxf(t, 0.f);
           o[e] = (bf16_t)t;
         }
-        *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        if (mem) *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        else asm volatile("" ::"v"(o));
       }
     } else if constexpr (EPI == EPI_F32) {
       float* out = p.out_f32 + split * p.split_stride_f32;
@@ -556,14 +569,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[e]; hi[e] = v[it][4 + e] + bias[4 + e]; }
-        *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col) = lo;
-        *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col + 4) = hi;
+        if (mem) {
+          *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col) = lo;
+          *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col + 4) = hi;
+        } else {
+          asm volatile("" ::"v"(lo), "v"(hi));
+        }
       }
     } else if constexpr (EPI == EPI_TANH_LOSS) {
       // target frames: exact [M_valid, N_valid] fp32.  Rows/columns past the valid extent are
       // read from a clamped address and masked by select (no per-element branches).
       float xin[CH][8];
-      if (p.x) {
+#pragma unroll
+      for (int it = 0; it < CH; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xin[it][e] = 0.f;
+      if (p.x && mem) {
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
           const long r = rowc + it * RPP;
@@ -601,8 +622,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           }
           o[e] = (bf16_t)g;
         }
-        if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
-        if (p.recon && rv_) {
+        if (p.x && mem) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
+        else asm volatile("" ::"v"(o));
+        if (p.recon && rv_ && mem) {
           if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
             *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
             *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
@@ -616,7 +638,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     } else {  // EPI_MASK_BF16
       bf16x8 mk[CH];
 #pragma unroll
-      for (int it = 0; it < CH; ++it) mk[it] = *(const bf16x8*)(p.mask + (rowc + it * RPP) * p.ld_mask + col);
+      for (int it = 0; it < CH; ++it)
+        mk[it] = mem ? *(const bf16x8*)(p.mask + (rowc + it * RPP) * p.ld_mask + col) : bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         bf16x8 o;
@@ -626,7 +649,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           cs[e] += t;
           o[e] = (bf16_t)t;
         }
-        *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        if (mem) *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        else asm volatile("" ::"v"(o));
       }
     }
   }

@@ -16,6 +16,8 @@ namespace {
 //   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring, 136 KiB with epilogue staging); only
 //      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
 int g_force_tile = -1;
+int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
+int g_pair_only = 0;  // paired launch: 1 = dgrad blocks only, 2 = wgrad blocks only (diagnostics: 300 + v)
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
@@ -38,6 +40,7 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
   g.splits = splits;
+  g.dbg = g_dbg;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), smem, st, g);
   RV_CHECK_LAUNCH();
@@ -92,9 +95,13 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
 int g_pair_loop = 8;  // main loop of the paired 256x256 kernel: 8 = ping-pong (default), 2 = two-slot ring
 
 template <int NSTAGE>
-int launch_pair(const GemmArgs& d, const GemmArgs& g, hipStream_t st) {
+int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
-  const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
+  GemmArgs d = d_in, g = g_in;
+  d.dbg = g.dbg = g_dbg;
+  int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
+  if (g_pair_only == 1) n_w = 0;
+  if (g_pair_only == 2) n_d = 0;
   constexpr int ring = 2 * (BM + BN) * 128, epi = WGM * WGN * 64 * (BN / WGN + 4) * 4;
   constexpr int smem = ring > epi ? ring : epi;
   auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
@@ -126,6 +133,7 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
     attr_done = true;
   }
   GemmArgs g1 = a, g2 = b;
+  g1.dbg = g2.dbg = g_dbg;
   g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
   g2.tiles_m = (int)(Mp2 / BM); g2.tiles_n = (int)(Np2 / BN); g2.splits = splits2;
   const int n1 = g1.tiles_m * g1.tiles_n * splits1, n2 = g2.tiles_m * g2.tiles_n * splits2;
@@ -199,6 +207,8 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 
 extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
+  if (tile >= 200 && tile < 208) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
+  if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
   g_force_tile = tile;
   return RV_OK;
 }

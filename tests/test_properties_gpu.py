@@ -106,39 +106,6 @@ def test_api_path_and_engine_agree_on_one_step():
     assert float((g_api - g_eng).norm() / g_eng.norm()) < 2e-4
 
 
-def test_default_ini_shape_max_batch_matches_sub_batches():
-    """default.ini of the reference: latent_dim=256, batch_size=131072 (default.ini:18,27).  One
-    forward+backward at that size; its loss and gradients must equal the mean over 32 sub-batches of
-    4096 frames run through a B=4096 engine (the loss is a mean over frames)."""
-    from rawaudiovae_kelsey_amd import engine as E
-    from rawaudiovae_kelsey_amd.engine import TrainEngine
-    S_, H_, L_, Bbig, Bsub = 1024, 2048, 256, 131072, 4096
-    params = make_params(S_, H_, L_, 0)
-    gen = torch.Generator(device="cuda").manual_seed(5)
-    x = torch.rand(Bbig, S_, device="cuda", generator=gen) * 2 - 1
-    eps = torch.randn(Bbig, L_, device="cuda", generator=gen)
-    ph = E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B
-    big = TrainEngine(S_, H_, L_, Bbig, kl_beta=KL, lr=LR)
-    big.load_params(params)
-    big.step(x, eps, phases=ph)
-    torch.cuda.synchronize()
-    g_big, l_big = big.grad.clone(), big.last_loss()
-    del big
-    sub = TrainEngine(S_, H_, L_, Bsub, kl_beta=KL, lr=LR)
-    sub.load_params(params)
-    acc = torch.zeros_like(g_big, dtype=torch.float64)
-    lsum = 0.0
-    for i in range(Bbig // Bsub):
-        sl = slice(i * Bsub, (i + 1) * Bsub)
-        sub.step(x[sl], eps[sl], phases=ph)
-        acc += sub.grad.double()
-        lsum += sub.last_loss()[0]
-    n = Bbig // Bsub
-    assert abs(l_big[0] - lsum / n) < 2e-6 * l_big[0]
-    rel = float(((acc / n).float() - g_big).norm() / g_big.norm())
-    assert rel < 5e-5, rel
-
-
 def test_reference_default_ini_batch_131072():
     """The reference's own default.ini (default.ini:18-28): S=1024, H=2048, L=256, batch 131072 -- the
     largest size the path is configured for.  Checked through the data-parallel identity: the loss of

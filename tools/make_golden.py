@@ -31,12 +31,23 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-sys.path.insert(0, "/root/reference")
+import importlib.util  # noqa: E402
 
-import rawvae.model as ref  # noqa: E402  (the reference, namespace package)
+
+def load_reference(name):
+    """Import /root/reference/rawvae/<name>.py by path: the reference's `rawvae` is a namespace package
+    (rawvae/init.py is not __init__.py), which the repo's own regular `rawvae` package
+    shadows on sys.path whatever the order."""
+    path = "/root/reference/rawvae/%s.py" % name
+    spec = importlib.util.spec_from_file_location("reference_rawvae_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.__file__.startswith("/root/reference/"), mod.__file__
+    return mod
+
+
+ref = load_reference("model")
 from oracle.inputs import PARAM_NAMES, make_eps, make_frames, make_params  # noqa: E402
-
-assert ref.__file__.startswith("/root/reference/"), ref.__file__
 
 KL_BETA = 1e-4
 LR = 1e-4
@@ -151,9 +162,71 @@ def init_stats():
     return st
 
 
+def dataset_case():
+    """AudioDataset / TestDataset / ToTensor of the reference itself (rawvae/dataset.py:86-160), run here.
+    The module imports torchaudio and librosa at the top (dataset.py:2-3), which this container lacks;
+    the three classes exercised need neither, so empty stand-in modules are placed in sys.modules for the
+    import only.  Captured: known answers for 30 s @ 44.1 kHz, and for a 1000-sample ramp +
+    a seeded 5000-sample waveform the complete frame matrices (bit-exact fixtures for rv_gather_frames,
+    data.DeviceAudio and the oracle's hop_frames / eval_frames)."""
+    import types
+    import zlib
+    for name in ("torchaudio", "librosa"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    rd = load_reference("dataset")
+    out = {}
+    # (1) the survey's known answers, now produced by the reference classes
+    n, S, hop, batch = 1323000, 1024, 128, 4096
+    wave = np.random.default_rng(7).uniform(-1, 1, n).astype(np.float32)
+    ds = rd.AudioDataset(wave, S, 44100, hop, transform=rd.ToTensor())
+    dl = torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False)
+    last = None
+    for b in dl:
+        last = b
+    picks = [0, 1, 7, 4095, 4096, len(ds) - 2, len(ds) - 1]
+    info = {"n_samples": n, "segment_length": S, "hop": hop, "padded": int(len(ds.audio_np)), "len": len(ds),
+            "batch": batch, "last_batch": int(last.shape[0]), "bad_segment_length": 1000, "wave_seed": 7,
+            "frame_idx": picks,
+            "frame_crc32": [int(zlib.crc32(ds[i].numpy().tobytes())) for i in picks],
+            "frame_sum": [float(ds[i].numpy().astype(np.float64).sum()) for i in picks],
+            "last_batch_crc32": int(zlib.crc32(last.numpy().tobytes()))}
+    try:
+        rd.AudioDataset(wave, 1000, 44100, hop)
+        info["bad_segment_raises"] = None
+    except ValueError as exc:
+        info["bad_segment_raises"] = str(exc)
+    td = rd.TestDataset(wave, S, 44100, transform=rd.ToTensor())
+    info["test_len"] = len(td)
+    info["test_padded"] = int(len(td.audio_np))
+    info["test_last_crc32"] = int(zlib.crc32(td[len(td) - 1].numpy().tobytes()))
+    # (2) complete frame matrices at small sizes
+    ramp = np.arange(1000, dtype=np.float32)
+    a = rd.AudioDataset(ramp, 256, 44100, 64, transform=rd.ToTensor())
+    out["ramp_hop_frames"] = np.stack([a[i].numpy() for i in range(len(a))])
+    t = rd.TestDataset(ramp, 256, 44100, transform=rd.ToTensor())
+    out["ramp_eval_frames"] = np.stack([t[i].numpy() for i in range(len(t))])
+    w2 = np.random.default_rng(11).uniform(-1, 1, 5000).astype(np.float32)
+    a2 = rd.AudioDataset(w2, 512, 44100, 128, transform=rd.ToTensor())
+    out["rand_hop_frames"] = np.stack([a2[i].numpy() for i in range(len(a2))])
+    t2 = rd.TestDataset(w2, 512, 44100, transform=rd.ToTensor())
+    out["rand_eval_frames"] = np.stack([t2[i].numpy() for i in range(len(t2))])
+    out["rand_wave_seed"] = np.array(11)
+    np.savez_compressed(os.path.join(OUT, "dataset_frames.npz"), **out)
+    print("dataset: len", info["len"], "padded", info["padded"], "last batch", info["last_batch"],
+          "| ramp frames", out["ramp_hop_frames"].shape, "rand frames", out["rand_hop_frames"].shape)
+    return info
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--dataset-only" in sys.argv:   # refresh only the dataset fixtures (the model cases take minutes)
+        with open(os.path.join(OUT, "summary.json")) as f:
+            summ = json.load(f)
+        summ["dataset"] = dataset_case()
+        with open(os.path.join(OUT, "summary.json"), "w") as f:
+            json.dump(summ, f, indent=1)
+        return
     small_case(torch.float32, "f32")
     small_case(torch.float64, "f64")
     summ = {"kl_beta": KL_BETA, "lr": LR, "torch": torch.__version__,
@@ -163,11 +236,7 @@ def main():
         for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
             summ["cases"]["%s_%s" % (name, tag)] = summary_case(*shp, dtype)
             print(name, tag, "loss0", summ["cases"]["%s_%s" % (name, tag)]["loss0"])
-    # Dataset known answers measured on the reference classes during the survey
-    # (rawvae/dataset.py:99-121,141-160): 30 s @ 44.1 kHz.
-    summ["dataset"] = {"n_samples": 1323000, "segment_length": 1024, "hop": 128,
-                       "padded": 1323008, "len": 10329, "batch": 4096, "last_batch": 2137,
-                       "bad_segment_length": 1000}
+    summ["dataset"] = dataset_case()
     with open(os.path.join(OUT, "summary.json"), "w") as f:
         json.dump(summ, f, indent=1)
 
