@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
     ap.add_argument("--sched", type=int, default=0,
-                    help="backward schedule: 0 one stream (default), 1 fc3/fc4 half of Adam forked beside the fc1 wgrad")
+                    help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()

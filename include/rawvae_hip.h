@@ -141,6 +141,11 @@ int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16
  * reads.  Autograd of F.linear w.r.t. weight, train.py:191. */
 int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp,
                     long Np, long Kp, int splits, float* dw_f32_slabs, long lddw, void* stream);
+/* The same on a named block tile instead of the picker's choice (extents must be multiples of it; `splits`
+ * must divide Kp/64).  RV_TILE_256x256 runs the ping-pong main loop when Kp/64/splits is even. */
+enum { RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x256 = 7 };
+int rv_linear_wgrad_tile(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np,
+                         long Kp, int splits, int tile, float* dw_f32_slabs, long lddw, void* stream);
 
 /* Reparameterisation forward, model.py:23-26, fused with the KL half of
  * loss_function (model.py:45):
@@ -242,6 +247,15 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
 /* Sum gradient slabs into the flat exact-shape gradient arena only (no update):
  * what loss.backward() leaves in .grad; also the all-reduce payload builder. */
 int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream);
+/* dW = dY^T X on 256x256 tiles (as rv_linear_wgrad_tile with RV_TILE_256x256) in a launch that ALSO runs the
+ * fused Adam update (rv_adam_multi) of the `n_desc` tensors in `descs` -- tensors whose gradients earlier
+ * launches completed, never the one this GEMM produces -- on `n_adam_blocks` extra 512-thread blocks that take
+ * the CUs the GEMM's tiles * splits blocks leave idle.  rv_wgrad_adam_fits says whether the extents tile. */
+int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);
+int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
+                         int splits, float* dw_f32_slabs, long lddw, const rv_param_desc* descs, int n_desc,
+                         float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
+                         const long long* step_counter, int n_adam_blocks, void* stream);
 
 /* bf16 variants for the data-parallel exchange (halves the all-reduce bytes; the in-rank sums stay
  * fp32): rv_grad_finalize_bf16 rounds the summed gradient to a flat bf16 arena (same element offsets
@@ -288,10 +302,17 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
 void rv_plan_destroy(rv_plan*);
 long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
-/* Schedule of the full local step (FWD|BWD_A|BWD_B|ADAM).  0 (default): every kernel on the caller's
- * stream.  Non-zero: the fc3/fc4 half of Adam is forked onto an internal side stream beside the fc1
- * weight-gradient GEMM and joined before the call's last kernel (needs a non-default `stream`); each
- * cross-stream edge costs 6-10 us on this runtime, so it measures slower than 0 at C2. */
+/* Schedule of the full local step (FWD|BWD_A|BWD_B|ADAM; needs a non-default `stream` when non-zero).
+ * 0 (default): every kernel on the caller's stream; fc4's dgrad and wgrad share one launch, and the launch of
+ *    the fc1 weight gradient also carries the Adam update of fc21/fc22/fc3/fc4 (rv_linear_wgrad_adam) when the
+ *    extents tile by 256 -- otherwise as 3.
+ * 3: every kernel on the caller's stream, Adam as one launch of its own at the end (the round-1 schedule).
+ * 2: the backward's dependency chain (dP3 -> dz -> dmu/dlogvar -> dP1 -> dW1 -> Adam) runs alone on the
+ *    caller's stream; dW4 and the fc4 half of Adam, which nothing in the step waits for, run on an internal
+ *    side stream (one fork after dP3, one join at the end of the call).
+ * 1: only the fc3/fc4 half of Adam is forked, beside the fc1 weight-gradient GEMM (round-1 experiment; its
+ *    join sits on the critical path and it measures slower than 0 at C2).
+ * rv_plan_step_ddp refuses to run while a non-zero schedule is set (see there). */
 int rv_plan_set_concurrency(rv_plan*, int enable);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);

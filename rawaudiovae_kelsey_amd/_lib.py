@@ -73,6 +73,12 @@ _SIGS = {
                                 c_int, c_void_p]),
     "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
                                 c_void_p, c_long, c_void_p]),
+    "rv_linear_wgrad_tile": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int,
+                                     c_void_p, c_long, c_void_p]),
+    "rv_wgrad_adam_fits": (c_int, [c_long, c_long, c_long, c_int]),
+    "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
+                                     C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_void_p, c_int, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
@@ -134,7 +140,7 @@ class _Lib:
             fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-            checked = res is c_int and name != "rv_version"
+            checked = res is c_int and name not in ("rv_version", "rv_wgrad_adam_fits")
             setattr(self, name, _wrap(fn, name) if checked else fn)
 
 

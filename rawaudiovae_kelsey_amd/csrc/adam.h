@@ -1,0 +1,308 @@
+// Fused multi-tensor Adam / gradient finaliser: device code shared by the stand-alone kernel
+// (elementwise.hip: rv_adam_multi, rv_grad_finalize) and by the weight-gradient GEMM launch that
+// carries optimizer blocks beside its GEMM blocks (gemm_launch.hip: rv_linear_wgrad_adam).
+// torch.optim.Adam defaults as constructed at train.py:163 and stepped at train.py:193.
+#pragma once
+#include "common.h"
+#include "../../include/rawvae_hip.h"
+
+namespace rv {
+
+constexpr int MAX_DESC = 16;
+struct DescTable {
+  rv_param_desc d[MAX_DESC];
+  long blk_start[MAX_DESC + 1];  // first block of each tensor
+  int n;
+};
+
+
+// Sum of the gradient slabs for 4 consecutive elements of one row.
+template <bool VEC>
+__device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long c, int nvalid) {
+  const float* base = d.grad_slabs + r * d.grad_ld + c;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  if constexpr (VEC) {
+    for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent 16-B loads in flight
+      const float4 a = *reinterpret_cast<const float4*>(base + (long)(s + 0) * d.grad_split_stride);
+      const float4 b = *reinterpret_cast<const float4*>(base + (long)(s + 1) * d.grad_split_stride);
+      const float4 e = *reinterpret_cast<const float4*>(base + (long)(s + 2) * d.grad_split_stride);
+      const float4 f = *reinterpret_cast<const float4*>(base + (long)(s + 3) * d.grad_split_stride);
+      g.x += (a.x + b.x) + (e.x + f.x); g.y += (a.y + b.y) + (e.y + f.y);
+      g.z += (a.z + b.z) + (e.z + f.z); g.w += (a.w + b.w) + (e.w + f.w);
+    }
+    for (; s < d.grad_splits; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (long)s * d.grad_split_stride);
+      g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+    }
+  } else {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (; s + 4 <= d.grad_splits; s += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) {
+          const float* q = base + j + (long)s * d.grad_split_stride;
+          t[j] += (q[0] + q[d.grad_split_stride]) + (q[2 * d.grad_split_stride] + q[3 * d.grad_split_stride]);
+        }
+    }
+    for (; s < d.grad_splits; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) t[j] += base[j + (long)s * d.grad_split_stride];
+    g = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return g;
+}
+
+__host__ __device__ inline bool adam_coop(const rv_param_desc& d) { return d.rows == 1 && d.grad_splits >= 16; }
+
+// One virtual block of 256 threads (`vblock` of tab.blk_start[tab.n], thread `tid` of it).  Each thread owns
+// 4 consecutive elements of one row (rows are processed in 4-element groups, so a group never straddles a
+// row).  The caller maps real blocks to virtual ones: 1:1 in k_adam, a strided loop in the GEMM launch.
+template <bool UPDATE>
+__device__ __forceinline__ void adam_block(const DescTable& tab, const long vblock, const int tid,
+                                           float* __restrict__ param, float* __restrict__ m_arena,
+                                           float* __restrict__ v_arena, float* __restrict__ grad_out, float lr,
+                                           float grad_scale, const long long* __restrict__ step_counter,
+                                           bf16_t* __restrict__ grad_out_bf16,
+                                           const bf16_t* __restrict__ grad_in_bf16) {
+  int t = 0;
+  while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
+  t = __builtin_amdgcn_readfirstlane(t);   // vblock is wave-uniform in every caller
+  const rv_param_desc d = tab.d[t];
+  const long gpr = (d.cols + 3) / 4;  // 4-element groups per row
+  const bool coop = adam_coop(d);     // bias rows with many partials: one WAVE per group
+  const long blk = vblock - tab.blk_start[t];
+  const long grp = coop ? blk * 4 + (tid >> 6) : blk * 256 + tid;
+  if (grp >= gpr * d.rows) return;
+  const long r = grp / gpr, c = (grp % gpr) * 4;
+  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
+  const long o = d.offset + r * d.cols + c;
+  const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
+  // issue the optimizer-state loads first so they are in flight under the slab sums
+  float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (UPDATE) {
+    if (!coop || (tid & 63) == 0) {
+      if (vec) {
+        const float4 m4 = *reinterpret_cast<const float4*>(m_arena + o);
+        const float4 v4 = *reinterpret_cast<const float4*>(v_arena + o);
+        const float4 w4 = *reinterpret_cast<const float4*>(param + o);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+      } else {
+        for (int j = 0; j < nvalid; ++j) {
+          mv[j] = m_arena[o + j];
+          vv[j] = v_arena[o + j];
+          wv[j] = param[o + j];
+        }
+      }
+    }
+  }
+  float4 g;
+  if (grad_in_bf16) {
+    // gradient = flat bf16 arena (the data-parallel payload after its all-reduce), same element offsets
+    if (coop && (tid & 63) != 0) return;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && (reinterpret_cast<uintptr_t>(grad_in_bf16) & 7) == 0) {
+      const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(grad_in_bf16 + o);
+      t4[0] = (float)b4[0]; t4[1] = (float)b4[1]; t4[2] = (float)b4[2]; t4[3] = (float)b4[3];
+    } else {
+      for (int j = 0; j < nvalid; ++j) t4[j] = (float)grad_in_bf16[o + j];
+    }
+    g = make_float4(t4[0], t4[1], t4[2], t4[3]);
+  } else if (coop) {
+    // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
+    const int lane = tid & 63;
+    float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = lane; s < d.grad_splits; s += 64) {
+      const float* q = d.grad_slabs + (long)s * d.grad_split_stride + r * d.grad_ld + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nvalid) tsum[j] += q[j];
+    }
+    g = make_float4(wave_sum(tsum[0]), wave_sum(tsum[1]), wave_sum(tsum[2]), wave_sum(tsum[3]));
+    if (lane != 0) return;
+  } else {
+    g = vec ? slab_sum4<true>(d, r, c, 4) : slab_sum4<false>(d, r, c, nvalid);
+  }
+  g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
+  float gv[4] = {g.x, g.y, g.z, g.w};
+  if (grad_out) {
+    if (vec) *reinterpret_cast<float4*>(grad_out + o) = g;
+    else
+      for (int j = 0; j < nvalid; ++j) grad_out[o + j] = gv[j];
+  }
+  if (grad_out_bf16) {
+    if (vec && (reinterpret_cast<uintptr_t>(grad_out_bf16) & 7) == 0) {
+      const bf16x4 b4 = {(bf16_t)gv[0], (bf16_t)gv[1], (bf16_t)gv[2], (bf16_t)gv[3]};
+      *reinterpret_cast<bf16x4*>(grad_out_bf16 + o) = b4;
+    } else {
+      for (int j = 0; j < nvalid; ++j) grad_out_bf16[o + j] = (bf16_t)gv[j];
+    }
+  }
+  if constexpr (UPDATE) {
+    // bias corrections 1-b^t through the hardware exp2 (b^t = 2^(t log2 b)); relative error ~1e-6
+    const float tt = (float)(*step_counter);
+    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);      // log2(0.9)
+    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));  // log2(0.999)
+    const float step_size = lr / bc1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
+      vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
+      wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(m_arena + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v_arena + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      *reinterpret_cast<float4*>(param + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    } else {
+      for (int j = 0; j < nvalid; ++j) {
+        m_arena[o + j] = mv[j];
+        v_arena[o + j] = vv[j];
+        param[o + j] = wv[j];
+      }
+    }
+    if (d.shadow_bf16) {
+      bf16_t* sp = reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c;
+      if (nvalid == 4 && (d.shadow_ld & 3) == 0) {
+        bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+        *reinterpret_cast<bf16x4*>(sp) = b4;
+      } else {
+        for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
+      }
+    }
+    if (d.shadow_f32)
+      for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
+  }
+}
+
+// Two virtual blocks per thread with all loads of both issued before the first dependent instruction (twice
+// the bytes in flight per lane): for callers that walk the table with few resident threads (the optimizer blocks
+// of rv_linear_wgrad_adam get one 512-thread block per CU).  Same arithmetic as adam_block; anything off the
+// aligned 4-wide path (ragged row ends, bias rows summed by a wave) falls back to it.
+struct AdamItem {
+  int state;  // 0: nothing to do, 1: aligned 4-wide group, 2: general path
+  int t;
+  long r, c, o;
+};
+
+// `vblock` must be wave-uniform (it is in both callers: a virtual block is 256 consecutive threads); the
+// readfirstlane makes that provable, so the descriptor is read with scalar loads instead of a per-lane loop.
+__device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long vblock, const int tid) {
+  AdamItem it{0, 0, 0, 0, 0};
+  if (vblock >= tab.blk_start[tab.n]) return it;
+  int t = 0;
+  while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
+  t = __builtin_amdgcn_readfirstlane(t);
+  const rv_param_desc d = tab.d[t];
+  it.t = t;
+  if (adam_coop(d)) { it.state = 2; return it; }
+  const long gpr = (d.cols + 3) / 4;
+  const long grp = (vblock - tab.blk_start[t]) * 256 + tid;
+  if (grp >= gpr * d.rows) return it;
+  it.r = grp / gpr;
+  it.c = (grp % gpr) * 4;
+  it.o = d.offset + it.r * d.cols + it.c;
+  const bool vec = d.cols - it.c >= 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0) && d.grad_splits <= 4 &&
+                   (!d.shadow_bf16 || (d.shadow_ld & 3) == 0) && !d.shadow_f32;
+  it.state = vec ? 1 : 2;
+  return it;
+}
+
+__device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, const long vb1, const int tid,
+                                          float* __restrict__ param, float* __restrict__ m_arena,
+                                          float* __restrict__ v_arena, const float lr, const float grad_scale,
+                                          const long long* __restrict__ step_counter) {
+  const AdamItem it[2] = {adam_locate(tab, vb0, tid), adam_locate(tab, vb1, tid)};
+  if (it[0].state == 1 && it[1].state == 1) {
+    float4 m4[2], v4[2], w4[2], sl[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it[u].t)];
+      m4[u] = *reinterpret_cast<const float4*>(m_arena + it[u].o);
+      v4[u] = *reinterpret_cast<const float4*>(v_arena + it[u].o);
+      w4[u] = *reinterpret_cast<const float4*>(param + it[u].o);
+      const float* base = d.grad_slabs + it[u].r * d.grad_ld + it[u].c;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+        sl[u][s_] = s_ < d.grad_splits ? *reinterpret_cast<const float4*>(base + (long)s_ * d.grad_split_stride)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float tt = (float)(*step_counter);
+    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);
+    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));
+    const float step_size = lr / bc1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it[u].t)];
+      float gv[4];
+      if (d.grad_splits == 4) {  // the summation order of slab_sum4
+        gv[0] = (sl[u][0].x + sl[u][1].x) + (sl[u][2].x + sl[u][3].x);
+        gv[1] = (sl[u][0].y + sl[u][1].y) + (sl[u][2].y + sl[u][3].y);
+        gv[2] = (sl[u][0].z + sl[u][1].z) + (sl[u][2].z + sl[u][3].z);
+        gv[3] = (sl[u][0].w + sl[u][1].w) + (sl[u][2].w + sl[u][3].w);
+      } else {
+        gv[0] = gv[1] = gv[2] = gv[3] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+          if (s_ < d.grad_splits) { gv[0] += sl[u][s_].x; gv[1] += sl[u][s_].y; gv[2] += sl[u][s_].z; gv[3] += sl[u][s_].w; }
+      }
+      float mv[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+      float wv[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gv[j] *= grad_scale;
+        mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
+        vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
+        wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
+      }
+      *reinterpret_cast<float4*>(m_arena + it[u].o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v_arena + it[u].o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      *reinterpret_cast<float4*>(param + it[u].o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      if (d.shadow_bf16) {
+        const bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(d.shadow_bf16) + it[u].r * d.shadow_ld + it[u].c) = b4;
+      }
+    }
+    return;
+  }
+  if (it[0].state)
+    adam_block<true>(tab, vb0, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
+  if (it[1].state)
+    adam_block<true>(tab, vb1, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
+}
+
+template <bool UPDATE>
+__global__ void __launch_bounds__(256)
+k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
+       float* __restrict__ v_arena, float* __restrict__ grad_out, float lr, float grad_scale,
+       const long long* __restrict__ step_counter, bf16_t* __restrict__ grad_out_bf16,
+       const bf16_t* __restrict__ grad_in_bf16) {
+  adam_block<UPDATE>(tab, (long)blockIdx.x, (int)threadIdx.x, param, m_arena, v_arena, grad_out, lr, grad_scale,
+                     step_counter, grad_out_bf16, grad_in_bf16);
+}
+
+// Host side: descriptor table with the first virtual block of every tensor.
+inline int adam_build_table(const rv_param_desc* descs, int n, DescTable* tab) {
+  RV_REQUIRE(descs && n > 0 && n <= MAX_DESC, RV_ERR_SHAPE, "param desc count %d out of range", n);
+  tab->n = n;
+  long blk = 0;
+  for (int i = 0; i < n; ++i) {
+    tab->d[i] = descs[i];
+    RV_REQUIRE(descs[i].rows > 0 && descs[i].cols > 0 && descs[i].grad_slabs && descs[i].grad_splits >= 1,
+               RV_ERR_SHAPE, "param desc %d invalid", i);
+    tab->blk_start[i] = blk;
+    {
+      const long groups = descs[i].rows * ((descs[i].cols + 3) / 4);
+      blk += adam_coop(descs[i]) ? (groups + 3) / 4 : (groups + 255) / 256;
+    }
+  }
+  tab->blk_start[n] = blk;
+  return RV_OK;
+}
+
+}  // namespace rv

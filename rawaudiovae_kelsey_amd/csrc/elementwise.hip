@@ -3,6 +3,7 @@
 // standalone single-kernel loss (MSE + KL + their gradients), and the fused
 // multi-tensor Adam / gradient finaliser.  C ABI: include/rawvae_hip.h.
 #include "common.h"
+#include "adam.h"
 #include "../../include/rawvae_hip.h"
 
 #include <stdarg.h>
@@ -465,192 +466,6 @@ k_gather_frames(const float* __restrict__ audio, long n_samples, const long long
   }
 }
 
-// ------------------------------------------------------------------ Adam / gradient finaliser
-constexpr int MAX_DESC = 16;
-struct DescTable {
-  rv_param_desc d[MAX_DESC];
-  long blk_start[MAX_DESC + 1];  // first block of each tensor
-  int n;
-};
-
-
-// Sum of the gradient slabs for 4 consecutive elements of one row.
-template <bool VEC>
-__device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long c, int nvalid) {
-  const float* base = d.grad_slabs + r * d.grad_ld + c;
-  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  int s = 0;
-  if constexpr (VEC) {
-    for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent 16-B loads in flight
-      const float4 a = *reinterpret_cast<const float4*>(base + (long)(s + 0) * d.grad_split_stride);
-      const float4 b = *reinterpret_cast<const float4*>(base + (long)(s + 1) * d.grad_split_stride);
-      const float4 e = *reinterpret_cast<const float4*>(base + (long)(s + 2) * d.grad_split_stride);
-      const float4 f = *reinterpret_cast<const float4*>(base + (long)(s + 3) * d.grad_split_stride);
-      g.x += (a.x + b.x) + (e.x + f.x); g.y += (a.y + b.y) + (e.y + f.y);
-      g.z += (a.z + b.z) + (e.z + f.z); g.w += (a.w + b.w) + (e.w + f.w);
-    }
-    for (; s < d.grad_splits; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(base + (long)s * d.grad_split_stride);
-      g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
-    }
-  } else {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (; s + 4 <= d.grad_splits; s += 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nvalid) {
-          const float* q = base + j + (long)s * d.grad_split_stride;
-          t[j] += (q[0] + q[d.grad_split_stride]) + (q[2 * d.grad_split_stride] + q[3 * d.grad_split_stride]);
-        }
-    }
-    for (; s < d.grad_splits; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nvalid) t[j] += base[j + (long)s * d.grad_split_stride];
-    g = make_float4(t[0], t[1], t[2], t[3]);
-  }
-  return g;
-}
-
-__host__ __device__ inline bool adam_coop(const rv_param_desc& d) { return d.rows == 1 && d.grad_splits >= 16; }
-
-// Each thread owns 4 consecutive elements of one row (rows are processed in
-// 4-element groups, so a group never straddles a row).
-template <bool UPDATE>
-__global__ void __launch_bounds__(256)
-k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
-       float* __restrict__ v_arena, float* __restrict__ grad_out, float lr, float grad_scale,
-       const long long* __restrict__ step_counter, bf16_t* __restrict__ grad_out_bf16,
-       const bf16_t* __restrict__ grad_in_bf16) {
-  int t = 0;
-  while (t + 1 < tab.n && (long)blockIdx.x >= tab.blk_start[t + 1]) ++t;
-  const rv_param_desc d = tab.d[t];
-  const long gpr = (d.cols + 3) / 4;  // 4-element groups per row
-  const bool coop = adam_coop(d);     // bias rows with many partials: one WAVE per group
-  const long blk = (long)blockIdx.x - tab.blk_start[t];
-  const long grp = coop ? blk * 4 + (threadIdx.x >> 6) : blk * 256 + threadIdx.x;
-  if (grp >= gpr * d.rows) return;
-  const long r = grp / gpr, c = (grp % gpr) * 4;
-  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
-  const long o = d.offset + r * d.cols + c;
-  const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
-  // issue the optimizer-state loads first so they are in flight under the slab sums
-  float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (UPDATE) {
-    if (!coop || (threadIdx.x & 63) == 0) {
-      if (vec) {
-        const float4 m4 = *reinterpret_cast<const float4*>(m_arena + o);
-        const float4 v4 = *reinterpret_cast<const float4*>(v_arena + o);
-        const float4 w4 = *reinterpret_cast<const float4*>(param + o);
-        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-        vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
-        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
-      } else {
-        for (int j = 0; j < nvalid; ++j) {
-          mv[j] = m_arena[o + j];
-          vv[j] = v_arena[o + j];
-          wv[j] = param[o + j];
-        }
-      }
-    }
-  }
-  float4 g;
-  if (grad_in_bf16) {
-    // gradient = flat bf16 arena (the data-parallel payload after its all-reduce), same element offsets
-    if (coop && (threadIdx.x & 63) != 0) return;
-    float t4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec && (reinterpret_cast<uintptr_t>(grad_in_bf16) & 7) == 0) {
-      const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(grad_in_bf16 + o);
-      t4[0] = (float)b4[0]; t4[1] = (float)b4[1]; t4[2] = (float)b4[2]; t4[3] = (float)b4[3];
-    } else {
-      for (int j = 0; j < nvalid; ++j) t4[j] = (float)grad_in_bf16[o + j];
-    }
-    g = make_float4(t4[0], t4[1], t4[2], t4[3]);
-  } else if (coop) {
-    // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
-    const int lane = threadIdx.x & 63;
-    float tsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = lane; s < d.grad_splits; s += 64) {
-      const float* q = d.grad_slabs + (long)s * d.grad_split_stride + r * d.grad_ld + c;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nvalid) tsum[j] += q[j];
-    }
-    g = make_float4(wave_sum(tsum[0]), wave_sum(tsum[1]), wave_sum(tsum[2]), wave_sum(tsum[3]));
-    if (lane != 0) return;
-  } else {
-    g = vec ? slab_sum4<true>(d, r, c, 4) : slab_sum4<false>(d, r, c, nvalid);
-  }
-  g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
-  float gv[4] = {g.x, g.y, g.z, g.w};
-  if (grad_out) {
-    if (vec) *reinterpret_cast<float4*>(grad_out + o) = g;
-    else
-      for (int j = 0; j < nvalid; ++j) grad_out[o + j] = gv[j];
-  }
-  if (grad_out_bf16) {
-    if (vec && (reinterpret_cast<uintptr_t>(grad_out_bf16) & 7) == 0) {
-      const bf16x4 b4 = {(bf16_t)gv[0], (bf16_t)gv[1], (bf16_t)gv[2], (bf16_t)gv[3]};
-      *reinterpret_cast<bf16x4*>(grad_out_bf16 + o) = b4;
-    } else {
-      for (int j = 0; j < nvalid; ++j) grad_out_bf16[o + j] = (bf16_t)gv[j];
-    }
-  }
-  if constexpr (UPDATE) {
-    // bias corrections 1-b^t through the hardware exp2 (b^t = 2^(t log2 b)); relative error ~1e-6
-    const float tt = (float)(*step_counter);
-    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);      // log2(0.9)
-    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));  // log2(0.999)
-    const float step_size = lr / bc1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
-      vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
-      wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
-    }
-    if (vec) {
-      *reinterpret_cast<float4*>(m_arena + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-      *reinterpret_cast<float4*>(v_arena + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      *reinterpret_cast<float4*>(param + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-    } else {
-      for (int j = 0; j < nvalid; ++j) {
-        m_arena[o + j] = mv[j];
-        v_arena[o + j] = vv[j];
-        param[o + j] = wv[j];
-      }
-    }
-    if (d.shadow_bf16) {
-      bf16_t* sp = reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c;
-      if (nvalid == 4 && (d.shadow_ld & 3) == 0) {
-        bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
-        *reinterpret_cast<bf16x4*>(sp) = b4;
-      } else {
-        for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
-      }
-    }
-    if (d.shadow_f32)
-      for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
-  }
-}
-
-int build_table(const rv_param_desc* descs, int n, DescTable* tab) {
-  RV_REQUIRE(descs && n > 0 && n <= MAX_DESC, RV_ERR_SHAPE, "param desc count %d out of range", n);
-  tab->n = n;
-  long blk = 0;
-  for (int i = 0; i < n; ++i) {
-    tab->d[i] = descs[i];
-    RV_REQUIRE(descs[i].rows > 0 && descs[i].cols > 0 && descs[i].grad_slabs && descs[i].grad_splits >= 1,
-               RV_ERR_SHAPE, "param desc %d invalid", i);
-    tab->blk_start[i] = blk;
-    {
-      const long groups = descs[i].rows * ((descs[i].cols + 3) / 4);
-      blk += adam_coop(descs[i]) ? (groups + 3) / 4 : (groups + 255) / 256;
-    }
-  }
-  tab->blk_start[n] = blk;
-  return RV_OK;
-}
 
 inline unsigned grid_for(long n_threads, long cap = 2048) {
   long g = (n_threads + 255) / 256;
@@ -818,7 +633,7 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
                   const long long* step_counter, void* stream) {
   RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_adam_multi: null pointer");
   DescTable tab;
-  int rc = build_table(descs, n_desc, &tab);
+  int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
@@ -832,7 +647,7 @@ int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param,
                            const long long* step_counter, void* stream) {
   RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter && grad_bf16, RV_ERR_NULL, "rv_adam_multi_bf16grad: null pointer");
   DescTable tab;
-  int rc = build_table(descs, n_desc, &tab);
+  int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, (float*)nullptr, lr, grad_scale,
@@ -844,7 +659,7 @@ int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param,
 int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream) {
   RV_REQUIRE(grad_out, RV_ERR_NULL, "rv_grad_finalize: null pointer");
   DescTable tab;
-  int rc = build_table(descs, n_desc, &tab);
+  int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, grad_out,
@@ -856,7 +671,7 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, vo
 int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out_bf16, void* stream) {
   RV_REQUIRE(grad_out_bf16, RV_ERR_NULL, "rv_grad_finalize_bf16: null pointer");
   DescTable tab;
-  int rc = build_table(descs, n_desc, &tab);
+  int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,

@@ -134,6 +134,14 @@ __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int k
   }
 }
 
+// v_permlane16_swap_b32: lanes 16-31 / 48-63 of `a` trade places with lanes 0-15 / 32-47 of `b`.  Inline asm
+// on scalars: hipcc (ROCm 7.2) miscompiles __builtin_amdgcn_permlane16_swap when its results are inserted into
+// vector elements (tools/scratch/probe.hip: elements 1..3 come back as copies of other lanes' element 0).  The
+// s_nop covers the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside an asm.
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 // Wait until at most `tiles` staged tiles (GL LDS-DMA instructions each) are still in flight.
 template <int GL>
 __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
@@ -221,7 +229,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[MQ * 4 + i][NQ * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kk], b[j][kk], acc[MQ * 4 + i][NQ * 2 + j], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[MQ * 4 + i][NQ * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -390,7 +398,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
     // issue order: MFMA, then {k ds_reads, MFMA} ...
     constexpr int K1 = (NRD + NMF - 2) / (NMF - 1);  // reads per MFMA gap
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -423,7 +431,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
     if constexpr (NEXT) {
       constexpr int NV = REFILL ? GL : 0;
       constexpr int K2 = (NV + NRD + NMF - 2) / (NMF - 1);  // memory instructions per MFMA gap
@@ -479,7 +487,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   first_half(smem + slot * STAGE);
   second_half(F_{}, F_{}, kt, slot, slot);
   }
-  __syncthreads();  // every wave is done with the ring before the epilogue reuses LDS
+  __syncthreads();  // every wave is done with the ring before the epilogue's reductions reuse LDS
   if (p.dbg & 2) {  // diagnostic: main loop only (the accumulators stay live)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -487,67 +495,74 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
     return;
   }
-  const bool mem = !(p.dbg & 1);  // diagnostic: epilogue arithmetic and LDS staging without global traffic
+  const bool mem = !(p.dbg & 1);  // diagnostic: epilogue arithmetic without global traffic
 
   // ------------------------------ epilogue ------------------------------
-  // acc[mi][ni][j] = C[wave row mi*16 + (lane>>4)*4 + j][wave col ni*16 + (lane&15)].
-  // Each wave transposes its WTM x WTN fp32 tile through its own LDS region so that global
-  // traffic is row-contiguous: a lane then owns 8 consecutive columns of one row (16-B bf16
-  // stores, 32-B fp32 loads/stores; WTN/8 lanes cover a row of the wave tile).  Within a
-  // chunk of passes all global LOADS are issued before the first store (loads and stores
-  // share the in-order vmcnt counter).
-  constexpr int LDW = WTN + 4;    // padded row: fragment writes 2-way conflict at most
-  constexpr int LPRW = WTN / 8;   // lanes per row of the wave tile (8 columns each)
-  constexpr int RPP = 64 / LPRW;  // rows per pass
-  constexpr int ER = WTM < 64 ? WTM : 64;  // wave-tile rows staged per round (bounds the LDS area)
-  constexpr int IT = ER / RPP;    // passes per round
-  constexpr int CH = IT < 8 ? IT : 8;  // passes per chunk (bounds live registers)
-  float* ep = (float*)smem_generic + wave * (ER * LDW);
+  // The MFMAs are issued with the operands swapped (first operand = the B fragment), so the accumulator
+  // of fragment (mi, ni) holds C^T: lane l owns row mi*16 + (l&15) of the wave tile and the FOUR CONSECUTIVE
+  // columns ni*16 + 4*(l>>4) + r, r = 0..3 -- row-contiguous straight out of the registers, no LDS staging.
+  // One v_permlane16_swap per register between the fragments of a column-block pair (2t, 2t+1) widens
+  // that to EIGHT consecutive columns per lane: afterwards lane (q = l>>4, j = l&15) holds columns
+  // [c, c+8), c = (2t + (q&1))*16 + (q>>1)*8, of row mi*16 + j (first four in the pair's first fragment
+  // register set, last four in the second), i.e. 16-byte bf16 / 2 x 16-byte fp32 accesses, and one store
+  // instruction covers 16 rows x 64 B (bf16).  Within a chunk all global LOADS are issued before the first
+  // store (loads and stores share the in-order vmcnt counter).
+  static_assert(NI % 2 == 0, "epilogue pairs column fragments");
+  constexpr int NP = NI / 2;                       // column-block pairs per wave tile
+  constexpr int CM = NP >= 2 ? 2 : (MI >= 4 ? 4 : MI);  // fragment rows per chunk (bounds live registers)
+  static_assert(MI % CM == 0, "chunking must divide the wave tile");
+  constexpr int CH = CM * NP;                      // (row, 8-column) items per chunk
+  const int eq = lane >> 4, ej = lane & 15;
+  const long colw = n0 + wn * WTN + (eq & 1) * 16 + (eq >> 1) * 8;   // + 32 * t
+  const long roww = m0 + wm * WTM + ej;                              // + 16 * mi
 
-  const int er = lane / LPRW, ec = (lane % LPRW) * 8;  // row within the pass, first of 8 columns
-  const long col = n0 + wn * WTN + ec;
-  const long row0 = m0 + wm * WTM + er;
-
-  float cs[8];
+  float cs[NP][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[t][e] = 0.f;
   float sq = 0.f;
 
-  float bias[8];
+  float bias[NP][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[t][e] = 0.f;
   if constexpr (EPI != EPI_MASK_BF16) {
     if (p.bias && (EPI != EPI_F32 || split == 0)) {  // split-K: slab 0 carries the bias
-      const f32x4 lo = *(const f32x4*)(p.bias + col), hi = *(const f32x4*)(p.bias + col + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { bias[e] = lo[e]; bias[4 + e] = hi[e]; }
+      for (int t = 0; t < NP; ++t) {
+        const f32x4 lo = *(const f32x4*)(p.bias + colw + 32 * t), hi = *(const f32x4*)(p.bias + colw + 32 * t + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[t][e] = lo[e]; bias[t][4 + e] = hi[e]; }
+      }
     }
   }
-  const bool vec_x = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && col + 8 <= p.N_valid &&
-                     ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+  const bool x_al = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
 #pragma unroll
-  for (int rd = 0; rd < WTM / ER; ++rd) {
-  // stage this round's ER rows of the wave tile (same-wave LDS hand-off: a wave's DS ops
-  // execute in order, so the previous round's reads are done before these writes land)
-#pragma unroll
-  for (int mi = 0; mi < ER / 16; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ep[(mi * 16 + (lane >> 4) * 4 + j) * LDW + ni * 16 + (lane & 15)] = acc[rd * (ER / 16) + mi][ni][j];
-#pragma unroll 1
-  for (int c0 = 0; c0 < IT; c0 += CH) {
+  for (int c0 = 0; c0 < MI; c0 += CM) {
     float v[CH][8];
+    long rowi[CH], coli[CH];
 #pragma unroll
-    for (int it = 0; it < CH; ++it) {
-      const f32x4 lo = *(const f32x4*)(ep + ((c0 + it) * RPP + er) * LDW + ec);
-      const f32x4 hi = *(const f32x4*)(ep + ((c0 + it) * RPP + er) * LDW + ec + 4);
+    for (int cm = 0; cm < CM; ++cm)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
-    }
-    const long rowc = row0 + (long)rd * ER + (long)c0 * RPP;
+      for (int t = 0; t < NP; ++t) {
+        const int it = cm * NP + t;
+        f32x4 lo = acc[c0 + cm][2 * t], hi = acc[c0 + cm][2 * t + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // rows 1 and 3 (16-lane groups) of `lo` trade places with rows 0 and 2 of `hi`
+          float a_ = lo[r], b_ = hi[r];
+          swap_rows16(a_, b_);
+          lo[r] = a_;
+          hi[r] = b_;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
+        rowi[it] = roww + 16 * (c0 + cm);
+        coli[it] = colw + 32 * t;
+      }
 
     if constexpr (EPI == EPI_BIAS_ACT_BF16) {
 #pragma unroll
@@ -555,11 +570,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float t = v[it][e] + bias[e];
-          if (p.relu) t = fmaxf(t, 0.f);
-          o[e] = (bf16_t)t;
+          float tt = v[it][e] + bias[it % NP][e];
+          if (p.relu) tt = fmaxf(tt, 0.f);
+          o[e] = (bf16_t)tt;
         }
-        if (mem) *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         else asm volatile("" ::"v"(o));
       }
     } else if constexpr (EPI == EPI_F32) {
@@ -568,10 +583,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       for (int it = 0; it < CH; ++it) {
         f32x4 lo, hi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[e]; hi[e] = v[it][4 + e] + bias[4 + e]; }
+        for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[it % NP][e]; hi[e] = v[it][4 + e] + bias[it % NP][4 + e]; }
         if (mem) {
-          *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col) = lo;
-          *(f32x4*)(out + (rowc + it * RPP) * p.ld_f32 + col + 4) = hi;
+          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
+          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;
         } else {
           asm volatile("" ::"v"(lo), "v"(hi));
         }
@@ -587,9 +602,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       if (p.x && mem) {
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
-          const long r = rowc + it * RPP;
+          const long r = rowi[it], col = coli[it];
           const long rc = r < p.M_valid ? r : p.M_valid - 1;
-          if (vec_x) {
+          if (x_al && col + 8 <= p.N_valid) {
             const f32x4 lo = *(const f32x4*)(p.x + rc * p.ld_x + col);
             const f32x4 hi = *(const f32x4*)(p.x + rc * p.ld_x + col + 4);
 #pragma unroll
@@ -605,20 +620,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       }
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
-        const long r = rowc + it * RPP;
+        const long r = rowi[it], col = coli[it];
         const bool rv_ = r < p.M_valid;
         bf16x8 o;
         float rec[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          rec[e] = fast_tanh(v[it][e] + bias[e]);
+          rec[e] = fast_tanh(v[it][e] + bias[it % NP][e]);
           const bool valid = rv_ && col + e < p.N_valid;
           float g = 0.f;
           if (p.x) {
             const float d = valid ? rec[e] - xin[it][e] : 0.f;
             sq += d * d;
             g = p.scale * d * (1.f - rec[e] * rec[e]);
-            cs[e] += g;
+            cs[it % NP][e] += g;
           }
           o[e] = (bf16_t)g;
         }
@@ -639,39 +654,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       bf16x8 mk[CH];
 #pragma unroll
       for (int it = 0; it < CH; ++it)
-        mk[it] = mem ? *(const bf16x8*)(p.mask + (rowc + it * RPP) * p.ld_mask + col) : bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
+        mk[it] = mem ? *(const bf16x8*)(p.mask + rowi[it] * p.ld_mask + coli[it]) : bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float t = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
-          cs[e] += t;
-          o[e] = (bf16_t)t;
+          const float tt = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
+          cs[it % NP][e] += tt;
+          o[e] = (bf16_t)tt;
         }
-        if (mem) *(bf16x8*)(p.out_bf16 + (rowc + it * RPP) * p.ld_bf16 + col) = o;
+        if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         else asm volatile("" ::"v"(o));
       }
     }
   }
 
-  }  // rounds
-
   if constexpr (EPI == EPI_TANH_LOSS || EPI == EPI_MASK_BF16) {
     if (p.colsum) {
-      // lanes with equal (lane % LPRW) own the same 8 columns: butterfly over the row bits
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float s_ = cs[e];
-#pragma unroll
-        for (int o = LPRW; o < 64; o <<= 1) s_ += __shfl_xor(s_, o, 64);
-        cs[e] = s_;
-      }
-      __syncthreads();  // all waves finished reading their staging regions
+      // lanes with equal (lane >> 4) own the same columns: butterfly over the 16 row lanes, then across
+      // the block's wave rows through LDS (the ring is no longer read: barrier after the main loop)
       float* red = (float*)smem_generic;
-      if (lane < LPRW) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wm * BN + wn * WTN + lane * 8 + e] = cs[e];
+      for (int t = 0; t < NP; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s_ = cs[t][e];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+          cs[t][e] = s_;
+        }
+      if (ej == 0) {
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            red[wm * BN + wn * WTN + (eq & 1) * 16 + (eq >> 1) * 8 + 32 * t + e] = cs[t][e];
       }
       __syncthreads();
       if (tid < BN) {

@@ -1,5 +1,6 @@
 // Host-side launchers for the bf16 MFMA GEMM family (C ABI: include/rawvae_hip.h).
 #include "gemm_bf16.h"
+#include "adam.h"
 #include "../../include/rawvae_hip.h"
 
 using namespace rv;
@@ -13,7 +14,7 @@ namespace {
 //   3: 256x128 2x2 waves of 128x64, 3 stages (144 KiB) one wave per SIMD, half the LDS reads
 //   4: 128x128 2x4 waves of 64x32, 4 stages (128 KiB)  two waves per SIMD; default 128x128
 //      (measured 4-10 % faster than config 1 on every 128-tile GEMM of the step)
-//   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring, 136 KiB with epilogue staging); only
+//   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring); only
 //      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
 int g_force_tile = -1;
 int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
@@ -26,8 +27,7 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
   constexpr int stage_bytes = (BM + BN) * 128;
-  constexpr int epi_rows = (BM / WGM) < 64 ? (BM / WGM) : 64;  // rows staged per epilogue round
-  constexpr int epi_bytes = WGM * WGN * epi_rows * (BN / WGN + 4) * 4;
+  constexpr int epi_bytes = WGM * BN * 4 + 256;  // column-sum / block-sum reductions of the epilogue
   const int used = (NSTAGE == 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE>;
@@ -92,6 +92,31 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
   }
 }
 
+// A weight-gradient GEMM whose launch also carries optimizer work: blocks [0, n_gemm) run the 256x256 TN GEMM
+// (dW = dY^T X as split-K slabs); the blocks behind them walk the fused Adam update of OTHER tensors, whose
+// gradients earlier launches have completed, in a strided loop over the 256-thread "virtual blocks" of adam.h.
+// Why one launch: dW1 is the last GEMM of the backward and runs alone on the chip (32 output tiles x 4 K splits
+// = 128 blocks of this tile), while Adam is pure HBM streaming that the GEMM's MFMA loop leaves idle.  Every
+// block of a launch gets the same dynamic LDS, so an optimizer block cannot share a CU with a GEMM block: the
+// optimizer blocks take the CUs the GEMM does not fill.  (Two streams instead cost a 6 us bubble per event
+// record on this runtime and slowed the co-running GEMMs by more than was hidden: profiles/r02_sched2_*.)
+template <int NSTAGE>
+__global__ void __launch_bounds__(512)
+gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable tab, float* __restrict__ param,
+                       float* __restrict__ m_arena, float* __restrict__ v_arena, const float lr,
+                       const float grad_scale, const long long* __restrict__ step_counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  if ((int)blockIdx.x < n_gemm) {
+    gemm_body<256, 256, 2, 4, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x, smem_dyn);
+  } else {
+    const long total = tab.blk_start[tab.n];
+    const long stride = 2L * ((long)gridDim.x - n_gemm);   // virtual blocks taken per sweep of the optimizer blocks
+    const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // wave-uniform
+    for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += 2 * stride)
+      adam_pair(tab, vb, vb + stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter);
+  }
+}
+
 int g_pair_loop = 8;  // main loop of the paired 256x256 kernel: 8 = ping-pong (default), 2 = two-slot ring
 
 template <int NSTAGE>
@@ -102,8 +127,7 @@ int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
   if (g_pair_only == 1) n_w = 0;
   if (g_pair_only == 2) n_d = 0;
-  constexpr int ring = 2 * (BM + BN) * 128, epi = WGM * WGN * 64 * (BN / WGN + 4) * 4;
-  constexpr int smem = ring > epi ? ring : epi;
+  constexpr int smem = 2 * (BM + BN) * 128;  // the ring; the epilogue's reductions reuse its first bytes
   auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -121,8 +145,7 @@ template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool A1, bool B1, int E1
 int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmArgs& b, long Mp2, long Np2, int splits2,
                 hipStream_t st) {
   constexpr int stage_bytes = (BM + BN) * 128, smem_max = NSTAGE * stage_bytes;
-  constexpr int epi_rows = (BM / WGM) < 64 ? (BM / WGM) : 64;
-  constexpr int epi_bytes = WGM * WGN * epi_rows * (BN / WGN + 4) * 4;
+  constexpr int epi_bytes = WGM * BN * 4 + 256;
   const int kt = a.k_tiles > b.k_tiles ? a.k_tiles : b.k_tiles;
   const int used = (kt < NSTAGE ? kt : NSTAGE) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
@@ -286,6 +309,59 @@ int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp,
   a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.out_f32 = dw; a.ld_f32 = lddw; a.split_stride_f32 = Mp * lddw;
   return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+// Weight gradient on a named block tile (the training plan runs dW4 on 256x256 ping-pong tiles on its side stream).
+int rv_linear_wgrad_tile(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                         int tile, float* dw, long lddw, void* stream) {
+  RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad_tile: null operand");
+  RV_REQUIRE(tile == RV_TILE_256x256 || tile == RV_TILE_256x128 || tile == RV_TILE_128x128 || tile == RV_TILE_64x64,
+             RV_ERR_UNSUPPORTED, "rv_linear_wgrad_tile: unknown tile %d", tile);
+  RV_REQUIRE(splits >= 1, RV_ERR_SHAPE, "rv_linear_wgrad_tile: splits %d", splits);
+  GemmArgs a{};
+  a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
+  a.k_tiles = (int)(Kp / 64 / splits); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.out_f32 = dw; a.ld_f32 = lddw; a.split_stride_f32 = Mp * lddw;
+  return launch_tile<false, false, EPI_F32>(tile, a, Mp, Np, Kp, splits, (hipStream_t)stream);
+}
+
+int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {
+  return Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 64 == 0 && splits >= 1 &&
+         (Kp / 64) % splits == 0 && g_force_tile < 0;
+}
+
+int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                         float* dw, long lddw, const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                         float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
+                         int n_adam_blocks, void* stream) {
+  RV_REQUIRE(dy && x && dw && param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_linear_wgrad_adam: null pointer");
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 64 == 0 && splits >= 1 &&
+                 (Kp / 64) % splits == 0, RV_ERR_SHAPE,
+             "rv_linear_wgrad_adam: %ld x %ld x %ld / %d splits does not tile by 256x256x64", Mp, Np, Kp, splits);
+  RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE,
+             "rv_linear_wgrad_adam: operands must be 16-byte aligned with leading dims multiples of 8");
+  RV_REQUIRE(n_adam_blocks >= 1 && n_adam_blocks <= 4096, RV_ERR_SHAPE, "rv_linear_wgrad_adam: n_adam_blocks %d", n_adam_blocks);
+  DescTable tab;
+  int rc = adam_build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  GemmArgs g{};
+  g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
+  g.k_tiles = (int)(Kp / 64 / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np;
+  g.out_f32 = dw; g.ld_f32 = lddw; g.split_stride_f32 = Mp * lddw;
+  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.dbg = g_dbg;
+  const int n_gemm = g.tiles_m * g.tiles_n * splits;
+  constexpr int smem = 2 * (256 + 256) * 128;
+  const bool pp = g.k_tiles % 2 == 0;
+  auto kern = pp ? gemm_wgrad_adam_kernel<8> : gemm_wgrad_adam_kernel<2>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[pp]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done[pp] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_adam_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
+                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
 }
 
 

@@ -290,7 +290,53 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     return rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
                           mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, st);
   };
-  if (full_local && p->concurrent != 0 && stream) {
+  if (full_local && p->concurrent == 0 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) &&
+      (Hp / 256) * (Sp / 256) * p->s_w1 <= 192) {
+    // Default schedule, one stream.  dW1 is the last GEMM of the backward: 32 tiles x 4 K splits of 256x256 fill
+    // half the chip, so its launch also carries the optimizer step of every tensor whose gradient is already
+    // complete on the other CUs (fc3 and fc4, below); fc1's and the heads' updates are the step's last launch.
+    const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_TRY(latent_bwd(stream));
+    RV_TRY(reparam_bwd(stream));
+    RV_TRY(heads_bwd(stream));
+    // fc3 + fc4 ride along (92 MB at C2): an optimizer block streams ~25 GB/s from its CU, so half the chip
+    // moves ~3 TB/s -- about what the GEMM blocks take to finish; the heads' update on top made the launch wait
+    // for the optimizer (43 us against 36)
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, p->d_slab + 6, 4,
+                                p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter,
+                                256 - n_gemm, stream));
+    RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, stream));
+    return RV_OK;
+  }
+  if (full_local && p->concurrent == 2 && stream) {
+    // Off the critical path: the fc4 weight gradient and the fc4 half of Adam.  The backward's dependency chain
+    // is dP3 -> dz -> dmu/dlogvar -> dP1 -> dW1; dW4 = dP4^T h3 needs only forward outputs and nothing in this
+    // step needs W4's update.  So the chain runs alone on the caller's stream (dP3 as a 256-block GEMM of its
+    // own instead of sharing the chip with dW4), and dW4 + Adam(fc4) run on the side stream beside the latent-sized
+    // kernels that leave most of the chip idle.  ONE fork (after dP3: from there on nobody reads W4b, and dP4 / h3
+    // are only read) and ONE join at the end of the step, which the side work reaches long before the chain does.
+    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
+    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"), nullptr, 0, 1,
+                           stream));
+    RV_HIP(hipEventRecord(p->ev[1], s0));
+    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
+    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, (float*)p->ws("dW4"), Hp, (void*)s1));
+    RV_TRY(rv_adam_multi(p->d_slab + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, (void*)s1));
+    RV_HIP(hipEventRecord(p->ev[3], s1));
+    RV_TRY(latent_bwd(stream));
+    RV_TRY(reparam_bwd(stream));
+    RV_TRY(heads_bwd(stream));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_TRY(rv_adam_multi(p->d_slab, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+                         p->b.step_counter, stream));
+    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join: the caller's stream owns the whole step again
+    return RV_OK;
+  }
+  if (full_local && p->concurrent == 1 && stream) {
     // One fork: everything on the caller's stream except the fc3/fc4 half of Adam, which runs on the side
     // stream beside the fc1 weight-gradient GEMM (each cross-stream edge costs 6-10 us on this runtime).
     hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
@@ -397,6 +443,10 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE(p->allreduce && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
+  // the collective stream must fork from / join into the caller's stream only: a second helper stream in the same
+  // capture has made hipStreamEndCapture recurse without end (unrecoverable), so the two modes exclude each other
+  RV_REQUIRE(p->concurrent == 0, RV_ERR_STATE, "rv_plan_step_ddp: not available while rv_plan_set_concurrency(%d) is set",
+             p->concurrent);
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
   void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
