@@ -50,6 +50,9 @@ def parse():
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed passes of K steps each (0 = at least 5 and enough for --min-seconds of timed work)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="minimum total timed work (all repeats)")
     return ap.parse_args()
 
 
@@ -136,19 +139,29 @@ def main():
     # RV_DDP=torch (or a non-RCCL rehearsal backend, or a failed RCCL self-test) selects the
     # torch.distributed path: six host calls + three dist.all_reduce per step (ddp.ddp_step).
     runner, ddp_mode, comm = None, None, None
+    native_fallback_reason = None    # why the library-driven RCCL step was not used (None: it was, or N = 1)
     if sync is not None:
         want_native = dist.is_initialized() and backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch"
         ok = 0
-        if want_native:
+        if not want_native:
+            native_fallback_reason = "RV_DDP=torch" if os.environ.get("RV_DDP") == "torch" else \
+                "backend %s is not RCCL" % backend
+        else:
+            my_reason = ""
             try:
                 comm = ddp.RcclComm()
                 comm.self_test(dev)
                 ok = 1
             except Exception as exc:  # fall back together, below
-                print("bench.py: rank %d: native RCCL path unavailable (%s)" % (rank, exc), file=sys.stderr)
+                my_reason = "rank %d: %s: %s" % (rank, type(exc).__name__, str(exc)[:300])
+                print("bench.py: native RCCL path unavailable (%s)" % my_reason, file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
+            if not ok:   # every rank's reason reaches rank 0's JSON line
+                reasons = [None] * world
+                dist.all_gather_object(reasons, my_reason)
+                native_fallback_reason = "; ".join(r for r in reasons if r) or "another rank failed"
         if ok:
             runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1")
             ddp_mode = "fp32, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its own stream, " \
@@ -189,31 +202,54 @@ def main():
         for i in range(args.warmup):
             one_step(i)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(args.warmup + i)
-        host_dt = time.perf_counter() - t0     # all K steps enqueued (the host runs ahead of the GPU)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
 
+        def timed_pass(first):
+            """EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(first + i)
+            host = time.perf_counter() - t0   # all K steps enqueued (the host runs ahead of the GPU)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el, host
+
+        # median of >= 5 passes and >= --min-seconds of timed work in total (SURVEY 8d); every rank runs
+        # the same number of passes (the count comes from rank 0's first pass)
+        first_dt, host_dt = timed_pass(args.warmup)
+        n_rep = args.repeats if args.repeats > 0 else max(5, int(args.min_seconds / max(first_dt, 1e-6)) + 1)
+        n_rep = min(n_rep, 2000)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.tensor([n_rep], dtype=torch.int64, device=dev)
+            dist.broadcast(t, 0)
+            n_rep = int(t.item())
+        passes = [first_dt]
+        for r in range(1, n_rep):
+            el, _ = timed_pass(args.warmup + r * args.steps)
+            passes.append(el)
+        passes.sort()
+        dt = passes[len(passes) // 2]
+        dt_min, dt_max = passes[0], passes[-1]
+
         last = eng.losses(min(8, args.steps))
+        replicas_consistent = None
         if world > 1:  # replicas must hold identical weights after identical averaged updates
             chk = torch.stack([eng.param.double().sum(), eng.param.double().abs().sum()])
             lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if rank == 0 and not torch.equal(lo, hi):
-                print("bench.py: WARNING replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
+            replicas_consistent = bool(torch.equal(lo, hi))
+            if rank == 0 and not replicas_consistent:
+                print("bench.py: replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
         # Not the headline: the same K steps again with the bf16 gradient payload (half the all-reduce
         # bytes), so that one run shows what the exchange costs at this GPU count.
         alt = None
@@ -252,24 +288,39 @@ def main():
         frames = float(B) * world * args.steps
         value = frames / dt
         achieved = kern_flops / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        try:  # HBM bytes per launch of the same kernel from the committed PMC passes (profiles/r01_traffic.json)
-            with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+        # HBM bytes per launch of the same kernel: NOT measured in this run -- the newest committed PMC summary
+        # (profiles/rNN_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command,
+        # corrected as MI355X_MICROARCH.md 'HBM' prescribes; tools/pmc_round.sh), labelled with its source
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_traffic.json")))
+            with open(cand[-1]) as f:
                 traffic = json.load(f)["traffic_bytes"]
+            traffic_src = "profiles/%s (PMC passes of an earlier builder run, not this run)" % os.path.basename(cand[-1])
         except Exception:
             pass
+        ms = [p_ / args.steps * 1e3 for p_ in passes]
         out = {
             "metric": "audio frames/sec (fwd+bwd+step), 1024-sample frames",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": value if replicas_consistent is not False else None,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
+                       "schedule": int(0 if args.serial else args.sched),
                        "grad_allreduce": ddp_mode},
+            # `value` / `ms_per_step` are the MEDIAN over `repeats` passes of exactly `steps` steps each
+            "timing": {"repeats": len(passes), "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+                       "timed_seconds_total": sum(passes)},
             "host_us_per_step": host_dt / args.steps * 1e6,
             **({"alt_bf16_payload": alt} if alt else {}),
+            **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
+            **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None)}
+               if world > 1 or force_ddp else {}),
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),
             # algorithmic HBM bytes per step: 54,784 B/frame of activations + 38 B/param
@@ -277,16 +328,22 @@ def main():
             "final_loss": last[-1],
             "roofline": {"bound": "mfma", "kernel": kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": kern_ms * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.torch_port import time_cpu_step
-            fps, ms, n, threads = time_cpu_step(S, H, L, B, make_params(S, H, L, 0), make_frames(B, S, 1234),
-                                                seconds=args.cpu_seconds)
+            from oracle.torch_port import cpu_description, time_cpu_step
+            fps, ms_c, n, threads = time_cpu_step(S, H, L, B, make_params(S, H, L, 0), make_frames(B, S, 1234),
+                                                  seconds=args.cpu_seconds)
+            # BASELINE configs[0] (the reference's own CPU-runnable case: 512-sample frames, latent 8, batch 32)
+            s_fps, s_ms, s_n, _ = time_cpu_step(512, H, 8, 32, make_params(512, H, 8, 0), make_frames(32, 512, 1234),
+                                                seconds=min(3.0, args.cpu_seconds), threads=threads)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d steps of the same C2 step (B=4096) in stock PyTorch fp32 on the "
-                                             "host, median %.1f ms/step" % (n, ms)}
+                                             "host, median %.1f ms/step" % (n, ms_c),
+                                   "smoke_shape": {"value": s_fps, "unit": "frames/s", "ms_per_step": s_ms,
+                                                   "sample": "%d steps of S=512 H=2048 L=8 B=32" % s_n},
+                                   **cpu_description()}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()   # rank 0 did extra timing work; leave together
@@ -294,6 +351,8 @@ def main():
             torch.cuda.synchronize()
             comm.destroy()
         dist.destroy_process_group()
+    if replicas_consistent is False:
+        sys.exit(4)   # a data-parallel step that leaves the replicas with different weights is not a result
 
 
 if __name__ == "__main__":

@@ -51,6 +51,29 @@ def port_loss(recon, x, mu, logvar, kl_beta, S):
     return mse + kl_beta * kld
 
 
+def cpu_description():
+    """What the CPU baseline ran on: model string, logical CPUs the OS reports, CPUs this process may use,
+    torch version."""
+    import os
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "cpus_usable": usable,
+            "torch_version": torch.__version__,
+            "threads_note": "`cores` = torch threads used: min(usable CPUs, RV_CPU_THREADS or 16) -- a one-GPU box "
+                            "is a 16-CPU share of a larger host"}
+
+
 def time_cpu_step(S, H, L, B, params, x, seconds=15.0, warmup=2, kl_beta=1e-4, lr=1e-4,
                   threads=None):
     """Time zero_grad/forward/loss/backward/Adam.step on the host CPU.

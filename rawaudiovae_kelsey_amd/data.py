@@ -171,7 +171,8 @@ class StreamingFrames:
     shuffled once per iterator (dataset.py:38-42,77-84).  Each file's waveform is uploaded once
     and cached on the device; a batch that straddles a file boundary is gathered in two pieces."""
 
-    def __init__(self, files, sampling_rate, hop_size, segment_length, device="cuda", shuffle=True, seed=None):
+    def __init__(self, files, sampling_rate, hop_size, segment_length, device="cuda", shuffle=True, seed=None,
+                 cache_bytes=8 << 30):
         self.files = list(files)
         if not self.files:
             raise FileNotFoundError("no .wav files to stream")
@@ -179,19 +180,26 @@ class StreamingFrames:
         self.device = torch.device(device)
         self.shuffle = shuffle
         self._rng = random.Random(seed)
-        self._cache = {}
+        # decoded waveforms kept on the device, least recently used first out once `cache_bytes` is exceeded
+        # (the reference streams files lazily, dataset.py:44-75; a corpus larger than HBM must not pile up here)
+        self._cache, self._cache_bytes, self.cache_limit = {}, 0, int(cache_bytes)
 
     def _dataset(self, f):
-        d = self._cache.get(f)
+        d = self._cache.pop(f, None)
         if d is None:
             d = DeviceAudio(load_audio_ch0(f, self.sampling_rate), self.segment_length, self.hop_size, self.device)
-            self._cache[f] = d
+            self._cache_bytes += d.audio.numel() * 4
+            while self._cache and self._cache_bytes > self.cache_limit:
+                old = self._cache.pop(next(iter(self._cache)))
+                self._cache_bytes -= old.audio.numel() * 4
+        self._cache[f] = d   # most recently used last
         return d
 
     def batches(self, batch_size, n_batches):
         order = self._rng.sample(self.files, len(self.files)) if self.shuffle else list(self.files)
         stream = itertools.cycle(order)
         cur, pos = None, 0
+        empty_run = 0   # consecutive files without a single full frame
         for _ in range(n_batches):
             out = torch.empty((batch_size, self.segment_length), dtype=torch.float32, device=self.device)
             filled = 0
@@ -200,7 +208,11 @@ class StreamingFrames:
                     cur, pos = self._dataset(next(stream)), 0
                     if len(cur) <= 0:
                         cur = None
+                        empty_run += 1
+                        if empty_run >= len(order):
+                            raise ValueError("no file yields a full %d-sample frame" % self.segment_length)
                         continue
+                    empty_run = 0
                 take = min(batch_size - filled, len(cur) - pos)
                 cur.frames(pos, take, out=out[filled:filled + take])
                 filled += take

@@ -143,6 +143,18 @@ class DdpRunner:
         e.host_steps += 1
 
 
+def _loaded_rccl_path():
+    """Path of the librccl this process has mapped already, or None."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
 class RcclComm:
     """An RCCL communicator owned by this package (one per process / GPU), created with ctypes from
     the RCCL library PyTorch already loaded, so `rv_plan_step_ddp` can issue the gradient all-reduces
@@ -156,8 +168,26 @@ class RcclComm:
         if not dist.is_initialized():
             raise RuntimeError("RcclComm needs an initialised torch.distributed group to share the RCCL unique id")
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        path = lib_path or os.environ.get("RV_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self._lib = C.CDLL(path)
+        # Use the RCCL instance PyTorch itself has mapped (a second copy of the library would be a second,
+        # unrelated collective runtime in this process): take its path from /proc/self/maps and open it with
+        # RTLD_NOLOAD, which fails instead of loading anything new.  Only when torch has not loaded RCCL yet
+        # (no "nccl" process group so far) is the library next to torch opened by path.
+        loaded = _loaded_rccl_path()
+        path = lib_path or os.environ.get("RV_RCCL_LIB") or loaded or \
+            os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if loaded and os.path.realpath(path) == os.path.realpath(loaded):
+            self._lib = C.CDLL(path, mode=os.RTLD_NOW | getattr(os, "RTLD_NOLOAD", 4))
+        else:
+            self._lib = C.CDLL(path)
+            if loaded:
+                raise RuntimeError("RcclComm: asked to open %s while the process already maps %s" % (path, loaded))
+        self.lib_path = path
+        v = C.c_int(0)
+        try:
+            self._lib.ncclGetVersion(C.byref(v))
+        except AttributeError:
+            pass
+        self.version = int(v.value)
         self._lib.ncclGetErrorString.restype = C.c_char_p
         self._lib.ncclGetErrorString.argtypes = [C.c_int]
         uid = self._UniqueId()

@@ -17,6 +17,13 @@ from ._lib import (PHASE_ADAM, PHASE_ADAM_A, PHASE_ADAM_B, PHASE_ALL_LOCAL, PHAS
                    PHASE_BWD_B, PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr,
                    stream_ptr)
 
+def _ops_invalidate():
+    """The API path (ops.py) caches operand shadows by tensor version; the engine writes parameters through
+    the C ABI, which PyTorch's version counters do not see."""
+    from . import ops
+    ops.invalidate_shadows()
+
+
 PARAM_NAMES = ("fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias",
                "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias")
 
@@ -155,6 +162,7 @@ class TrainEngine:
         if phases & PHASE_ANY_ADAM:
             self._shared["version"] += 1
             self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
+            _ops_invalidate()
 
     def attach_comm(self, comm):
         """Data-parallel mode with the collective issued by the library itself: `comm` is a
@@ -185,6 +193,7 @@ class TrainEngine:
         self.host_steps += 1
         self._shared["version"] += 1
         self._shadow_version = self._shared["version"]
+        _ops_invalidate()
 
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""

@@ -49,6 +49,56 @@ def _pad_bias(b, n_p):
     return out
 
 
+# Operand shadows of the PARAMETERS (padded bf16 weights, padded fp32 biases) are rebuilt only when a parameter
+# has changed: keyed by storage address + shape + padding and validated by the tensors' `_version` counters,
+# which every in-place update (optimizer.step, load_state_dict, .copy_) increments.  Without it each forward
+# re-cast all five weights (~60 small launches per step, host-bound at ~1 ms/step on the reference-style loop).
+_SHADOWS = {}
+_SHADOW_SLOTS = 64
+
+
+def _shadow(kind, tensors, dims, build):
+    key = (kind, tuple(t.data_ptr() for t in tensors), tuple(tuple(t.shape) for t in tensors), dims,
+           torch.cuda.current_stream().cuda_stream)
+    ver = tuple(t._version for t in tensors)
+    hit = _SHADOWS.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = build()
+    if len(_SHADOWS) >= _SHADOW_SLOTS:
+        _SHADOWS.pop(next(iter(_SHADOWS)))
+    _SHADOWS[key] = (ver, val)
+    return val
+
+
+def invalidate_shadows():
+    """Forget every cached shadow: for writers that change parameters behind PyTorch's back (the fused
+    engine updates its arena through the C ABI, which does not touch the tensors' version counters)."""
+    _SHADOWS.clear()
+
+
+def weight_shadow(W, rows_p, cols_p):
+    return _shadow("w", (W,), (rows_p, cols_p), lambda: cast_pad(W.detach(), rows_p, cols_p))
+
+
+def bias_shadow(b, n_p):
+    return _shadow("b", (b,), (n_p,), lambda: _pad_bias(b, n_p))
+
+
+def heads_shadow(W21, W22, b21, b22, Lp, Hp):
+    """fc21 | fc22 as ONE [2 Lp, Hp] bf16 weight and one [2 Lp] fp32 bias (the two heads are one GEMM)."""
+    def build():
+        Ld = W21.shape[0]
+        Whb = _bf16_empty(2 * Lp, Hp, W21.device)
+        cast_pad(W21.detach(), Lp, Hp, out=Whb[:Lp], ld_dst=Hp)
+        cast_pad(W22.detach(), Lp, Hp, out=Whb[Lp:], ld_dst=Hp)
+        bh = torch.zeros(2 * Lp, dtype=torch.float32, device=W21.device)
+        bh[:Ld].copy_(b21.detach())
+        bh[Lp:Lp + Ld].copy_(b22.detach())
+        return Whb, bh
+    return _shadow("h", (W21, W22, b21, b22), (Lp, Hp), build)
+
+
 def _slab_sum(slabs, splits, rows_p, ld, rows, cols, row0=0, col0=0):
     """Sum `splits` fp32 slabs [rows_p, ld] and crop to an exact [rows, cols] tensor."""
     out = torch.empty((rows, cols), dtype=torch.float32, device=slabs.device)
@@ -102,15 +152,10 @@ class EncodeFn(torch.autograd.Function):
         Bp, Sp, Hp, Lp = pad_dims(B, S, H, Ld)
         st = stream_ptr()
         xb = cast_pad(x, Bp, Sp)
-        W1b = cast_pad(W1.detach(), Hp, Sp)
-        Whb = _bf16_empty(2 * Lp, Hp, x.device)
-        cast_pad(W21.detach(), Lp, Hp, out=Whb[:Lp], ld_dst=Hp)
-        cast_pad(W22.detach(), Lp, Hp, out=Whb[Lp:], ld_dst=Hp)
-        bh = torch.zeros(2 * Lp, dtype=torch.float32, device=x.device)
-        bh[:Ld].copy_(b21.detach())
-        bh[Lp:Lp + Ld].copy_(b22.detach())
+        W1b = weight_shadow(W1, Hp, Sp)
+        Whb, bh = heads_shadow(W21, W22, b21, b22, Lp, Hp)
         h1 = _bf16_empty(Bp, Hp, x.device)
-        L_.rv_linear_fwd(ptr(xb), Sp, ptr(W1b), Sp, ptr(_pad_bias(b1, Hp)), Bp, Hp, Sp, ACT_RELU, ptr(h1), Hp, st)
+        L_.rv_linear_fwd(ptr(xb), Sp, ptr(W1b), Sp, ptr(bias_shadow(b1, Hp)), Bp, Hp, Sp, ACT_RELU, ptr(h1), Hp, st)
         mulv = torch.empty((Bp, 2 * Lp), dtype=torch.float32, device=x.device)
         L_.rv_linear_fwd_f32(ptr(h1), Hp, ptr(Whb), Hp, ptr(bh), Bp, 2 * Lp, Hp, 1, ptr(mulv), 2 * Lp, st)
         ctx.save_for_backward(xb, h1, Whb)
@@ -186,12 +231,12 @@ class DecodeFn(torch.autograd.Function):
         Bp, Sp, Hp, Lp = pad_dims(B, S, H, Ld)
         st = stream_ptr()
         zb = cast_pad(z, Bp, Lp)
-        W3b = cast_pad(W3.detach(), Hp, Lp)
-        W4b = cast_pad(W4.detach(), Sp, Hp)
+        W3b = weight_shadow(W3, Hp, Lp)
+        W4b = weight_shadow(W4, Sp, Hp)
         h3 = _bf16_empty(Bp, Hp, z.device)
-        L_.rv_linear_fwd(ptr(zb), Lp, ptr(W3b), Lp, ptr(_pad_bias(b3, Hp)), Bp, Hp, Lp, ACT_RELU, ptr(h3), Hp, st)
+        L_.rv_linear_fwd(ptr(zb), Lp, ptr(W3b), Lp, ptr(bias_shadow(b3, Hp)), Bp, Hp, Lp, ACT_RELU, ptr(h3), Hp, st)
         recon = torch.empty((B, S), dtype=torch.float32, device=z.device)
-        L_.rv_decode_out_loss_fwd(ptr(h3), Hp, ptr(W4b), Hp, ptr(_pad_bias(b4, Sp)), Bp, Sp, Hp, B, S,
+        L_.rv_decode_out_loss_fwd(ptr(h3), Hp, ptr(W4b), Hp, ptr(bias_shadow(b4, Sp)), Bp, Sp, Hp, B, S,
                                   None, 0, ptr(recon), S, None, 0, None, None, st)
         ctx.save_for_backward(zb, h3, W3b, W4b, recon)
         ctx.dims = (B, S, H, Ld, Bp, Sp, Hp, Lp)

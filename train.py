@@ -80,9 +80,26 @@ class DataParallel:
             else:
                 dist.init_process_group(backend)
             if backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch":
+                # The library-driven RCCL step (one host call per batch).  All ranks use it or none does: a
+                # rank whose communicator or self-test fails must not leave the others inside a collective,
+                # so the outcome is agreed on over the torch.distributed group (as bench.py does) and a
+                # failure anywhere moves every rank to the torch.distributed exchange (ddp.ddp_step).
                 from rawaudiovae_kelsey_amd import ddp
-                self.comm = ddp.RcclComm()
-                self.comm.self_test(device)
+                ok, why = 1, ""
+                try:
+                    self.comm = ddp.RcclComm()
+                    self.comm.self_test(device)
+                except Exception as exc:
+                    ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if why or self.rank == 0:
+                        print("rank %d: library-driven RCCL step unavailable%s; all ranks use the torch.distributed "
+                              "exchange" % (self.rank, " (" + why + ")" if why else " on another rank"), flush=True)
+                    if self.comm is not None and ok:
+                        self.comm.destroy()
+                    self.comm = None
 
     @property
     def main(self):
@@ -289,6 +306,10 @@ def main(argv=None):
     step_tail = dp.prepare(tail_engine) if tail_engine is not None else None
     # the data-parallel step forks its collectives from the caller's stream: it needs a non-default one
     train_stream = torch.cuda.Stream(device) if dp.active else None
+    if train_stream is not None:
+        # the engines' arenas, shadows and workspaces were filled on the default stream, which a fresh
+        # stream does not wait for
+        train_stream.wait_stream(torch.cuda.current_stream(device))
     shuffle_gen = torch.Generator().manual_seed(seed)   # the same permutation on every rank
 
     def checkpoint_state(epoch):

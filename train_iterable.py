@@ -163,7 +163,10 @@ def main(argv=None):
                     print("Loss did not improve.")
         drain()
 
-        print('Last Checkpoint - Epoch {}'.format(batch_id))
+        # the reference increments batch_id at the end of every iteration (train_iterable.py:266-267), so
+        # its final checkpoint carries batch_id == total_num_batches
+        batch_id = total_num_batches
+        print('Last Checkpoint - batch_id {}'.format(batch_id))
         state = {'batch_id': batch_id, 'state_dict': model.state_dict(), 'optimizer': engine.optimizer_state_dict()}
         if generate_test:
             audio_out = audio_log_dir / 'test_reconst_{:05d}.wav'.format(total_num_batches)
