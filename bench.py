@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
     ap.add_argument("--sched", type=int, default=0,
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
+    ap.add_argument("--fp8", action="store_true",
+                    help="also time the step with fc1 / fc4 forward on fp8 (e4m3) operands and report it as the side "
+                         "line `alt_fp8` (BASELINE configs[4]); the headline stays bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--repeats", type=int, default=0,
@@ -279,6 +282,26 @@ def main():
             finally:
                 runner.set_payload("fp32")
         kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
+        alt_fp8 = None
+        if args.fp8 and world == 1:
+            eng8 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, fp8=True)
+            eng8.load_params(make_params(S, H, L, 0))
+            for i in range(args.warmup + 5):
+                eng8.step(pool[i % POOL], stream=comp)
+            torch.cuda.synchronize()
+            reps8 = []
+            for r in range(max(5, min(len(passes), 50))):
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    eng8.step(pool[(r * args.steps + i) % POOL], stream=comp)
+                torch.cuda.synchronize()
+                reps8.append(time.perf_counter() - t0)
+            reps8.sort()
+            m8 = reps8[len(reps8) // 2]
+            alt_fp8 = {"what": "fc1 and fc4 forward on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor "
+                               "scales, delayed activation scaling); backward and everything else bf16",
+                       "ms_per_step": m8 / args.steps * 1e3, "value": float(B) * args.steps / m8,
+                       "final_loss": eng8.losses(1)[-1], "repeats": len(reps8)}
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
         print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)
@@ -318,6 +341,7 @@ def main():
                        "timed_seconds_total": sum(passes)},
             "host_us_per_step": host_dt / args.steps * 1e6,
             **({"alt_bf16_payload": alt} if alt else {}),
+            **({"alt_fp8": alt_fp8} if alt_fp8 else {}),
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None)}
                if world > 1 or force_ddp else {}),

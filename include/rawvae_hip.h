@@ -232,6 +232,8 @@ typedef struct rv_param_desc {
   void* shadow_bf16;       /* padded bf16 copy refreshed with the new weight (or NULL) */
   float* shadow_f32;       /* padded fp32 copy (biases as read by GEMM epilogues), or NULL */
   long shadow_ld;
+  void* shadow_fp8;        /* padded fp8 (e4m3) copy fp8(w * *fp8_scale), leading dim shadow_ld, or NULL */
+  const float* fp8_scale;  /* device scalar */
 } rv_param_desc;
 
 /* torch.optim.Adam(lr) step (train.py:163,193: betas 0.9/0.999, eps 1e-8, no weight
@@ -265,6 +267,34 @@ int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out
 int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
                            float* exp_avg_sq, const void* grad_bf16, float lr, float grad_scale,
                            const long long* step_counter, void* stream);
+
+/* ---- fp8 (e4m3, OCP) operand path for the two large forward GEMMs (BASELINE configs[4]; a build extension,
+ * the reference has no reduced-precision path).  Operands are quantised per tensor:
+ * q = fp8(value * scale), the GEMM accumulates in fp32 on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
+ * scales) and multiplies the accumulator by *dq = 1 / (scale_A * scale_B) before bias / activation.
+ * K extents and leading dims are in fp8 elements (multiples of 128 / 16). ---- */
+/* fp32 [rows, cols] -> zero-padded fp8 [rows_p, cols_p]: fp8(src * *scale), saturating at +-448. */
+int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* dst_fp8, long rows_p, long cols_p,
+                    long ld_dst, const float* scale, void* stream);
+/* rv_cast_pad_bf16 that also writes the fp8 operand (dst_fp8 may be NULL) and, when `fp8_state` is given, latches
+ * the delayed activation scale for this step in its first wave from the previous step's per-block maxima
+ * `amax_part[n_amax]` (see rv_plan_set_fp8 for the state block's layout). */
+int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long rows_p,
+                        long cols_p, long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state,
+                        const float* amax_part, int n_amax, long long* step_counter, void* stream);
+/* rv_linear_fwd that can also store its output as fp8(y * *q_scale) (the next layer's fp8 operand) and write
+ * max|y| of every block to amax_part[block] (rv_gemm_tile gives the block count: (Mp/bm)*(Np/bn)), from which the
+ * next step derives its scale (delayed scaling). */
+int rv_linear_fwd_q8(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp, long Np,
+                     long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
+                     float* amax_part, void* stream);
+/* rv_linear_fwd / rv_decode_out_loss_fwd on fp8 operands. */
+int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
+                      long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
+int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
+                               const float* dq, long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx,
+                               float* recon, long ld_recon, void* dP4_bf16, long ld_dp4, float* mse_partial,
+                               float* db4_partial, void* stream);
 
 /* ---- whole-step plan: one call enqueues forward, loss, backward (and Adam) ---- */
 typedef struct rv_plan rv_plan;
@@ -314,6 +344,15 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *    join sits on the critical path and it measures slower than 0 at C2).
  * rv_plan_step_ddp refuses to run while a non-zero schedule is set (see there). */
 int rv_plan_set_concurrency(rv_plan*, int enable);
+/* fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay bf16).
+ * The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
+ *   [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
+ *   [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
+ *       "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
+ *   [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
+ *   [7] non-zero: keep [3] fixed (parity runs).
+ * Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them. */
+int rv_plan_set_fp8(rv_plan*, int enable);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);
 /* Enqueue the selected phases of one training step (train.py:184-193) on `stream`.

@@ -28,19 +28,41 @@ def bf16_round(a):
     return out.astype(a.dtype if hasattr(a, "dtype") else np.float32)
 
 
+def fp8_e4m3_round(a):
+    """Round to OCP fp8 e4m3 (4 exponent bits, bias 7; 3 mantissa bits; max 448, no infinities), round to
+    nearest even, saturating; subnormals (step 2^-9 below 2^-6) kept.  Returns float64/32 values."""
+    a = np.asarray(a)
+    mag = np.minimum(np.abs(a.astype(np.float64)), 448.0)
+    e = np.floor(np.log2(np.where(mag > 0, mag, 1.0)))
+    e = np.maximum(e, -6.0)
+    step = np.exp2(e - 3.0)
+    q = np.rint(mag / step) * step          # np.rint rounds half to even
+    q = np.minimum(q, 448.0)
+    return (np.sign(a) * q).astype(a.dtype)
+
+
 def _q(a, quant):
-    return bf16_round(a) if quant == "bf16" else a
+    return bf16_round(a) if quant in ("bf16", "fp8") else a
+
+
+def _q8(a, scale):
+    """fp8 operand as the GEMM sees it: fp8(a * scale) / scale."""
+    return fp8_e4m3_round(np.asarray(a, dtype=np.float32) * np.float32(scale)).astype(np.float64) / scale
 
 
 def cast_params(params, dtype):
     return {k: np.asarray(params[k], dtype=dtype) for k in PARAM_NAMES}
 
 
-def encode(params, x, quant=None):
+def encode(params, x, quant=None, fp8_scales=None):
     """h1 = relu(x W1^T + b1); mu, logvar = two heads on h1.
-    Reference: rawvae/model.py:19-21."""
-    xq = _q(x, quant)
-    h1 = np.maximum(xq @ _q(params["fc1.weight"], quant).T + params["fc1.bias"], 0)
+    Reference: rawvae/model.py:19-21.  quant="fp8": fc1's two operands are fp8(x * s_x), fp8(W1 * s_w1)."""
+    if quant == "fp8":
+        h1 = np.maximum((_q8(x, fp8_scales["x"]) @ _q8(params["fc1.weight"], fp8_scales["w1"]).T).astype(x.dtype)
+                        + params["fc1.bias"], 0)
+    else:
+        xq = _q(x, quant)
+        h1 = np.maximum(xq @ _q(params["fc1.weight"], quant).T + params["fc1.bias"], 0)
     h1 = _q(h1, quant)
     mu = h1 @ _q(params["fc21.weight"], quant).T + params["fc21.bias"]
     logvar = h1 @ _q(params["fc22.weight"], quant).T + params["fc22.bias"]
@@ -54,23 +76,30 @@ def reparameterize(mu, logvar, eps):
     return mu + eps * std, std
 
 
-def decode(params, z, quant=None):
+def decode(params, z, quant=None, fp8_scales=None):
     """h3 = relu(z W3^T + b3); recon = tanh(h3 W4^T + b4).
-    Reference: rawvae/model.py:28-30."""
+    Reference: rawvae/model.py:28-30.  quant="fp8": fc4 reads fp8(h3 * s_h3) (quantised from the fp32 value, as
+    the producing epilogue does) and fp8(W4 * s_w4); h3 itself is kept in bf16 for the backward."""
     zq = _q(z, quant)
-    h3 = np.maximum(zq @ _q(params["fc3.weight"], quant).T + params["fc3.bias"], 0)
-    h3 = _q(h3, quant)
-    recon = np.tanh(h3 @ _q(params["fc4.weight"], quant).T + params["fc4.bias"])
+    h3f = np.maximum(zq @ _q(params["fc3.weight"], quant).T + params["fc3.bias"], 0)
+    h3 = _q(h3f, quant)
+    if quant == "fp8":
+        pre = (_q8(h3f, fp8_scales["h3"]) @ _q8(params["fc4.weight"], fp8_scales["w4"]).T).astype(z.dtype)
+        recon = np.tanh(pre + params["fc4.bias"])
+    else:
+        recon = np.tanh(h3 @ _q(params["fc4.weight"], quant).T + params["fc4.bias"])
     return h3, recon
 
 
-def forward(params, x, eps, quant=None):
-    """Reference: rawvae/model.py:32-35.  Returns every intermediate."""
+def forward(params, x, eps, quant=None, fp8_scales=None):
+    """Reference: rawvae/model.py:32-35.  Returns every intermediate.
+    quant="fp8" (fp8_scales = {"x", "w1", "w4", "h3"}): the HIP path's fp8 mode -- fc1 and fc4 forward on
+    e4m3 operands, everything else (and the whole backward) at the bf16 rounding points."""
     S = params["fc1.weight"].shape[1]
     x = x.reshape(-1, S)
-    h1, mu, logvar = encode(params, x, quant)
+    h1, mu, logvar = encode(params, x, quant, fp8_scales)
     z, std = reparameterize(mu, logvar, eps)
-    h3, recon = decode(params, z, quant)
+    h3, recon = decode(params, z, quant, fp8_scales)
     return dict(x=x, h1=h1, mu=mu, logvar=logvar, std=std, eps=eps, z=_q(z, quant),
                 h3=h3, recon=recon)
 

@@ -21,7 +21,7 @@ class ParamDesc(C.Structure):
     _fields_ = [("offset", c_long), ("rows", c_long), ("cols", c_long),
                 ("grad_slabs", c_void_p), ("grad_ld", c_long), ("grad_split_stride", c_long),
                 ("grad_splits", c_int), ("shadow_bf16", c_void_p), ("shadow_f32", c_void_p),
-                ("shadow_ld", c_long)]
+                ("shadow_ld", c_long), ("shadow_fp8", c_void_p), ("fp8_scale", c_void_p)]
 
 
 class PlanBuffers(C.Structure):
@@ -55,6 +55,17 @@ _SIGS = {
                                           c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
+    "rv_cast_pad_fp8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
+    "rv_cast_pad_bf16_q8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long,
+                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rv_linear_fwd_q8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
+                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "rv_linear_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
+                                  c_void_p, c_long, c_void_p]),
+    "rv_decode_out_loss_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
+                                           c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
+                                           c_void_p, c_void_p, c_void_p]),
+    "rv_plan_set_fp8": (c_int, [c_void_p, c_int]),
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_tanh_bwd_pack": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p]),
     "rv_colsum_partial": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),

@@ -54,6 +54,21 @@ __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long
   return g;
 }
 
+// fp8(w * scale) for up to 4 consecutive elements of one row of the padded fp8 shadow.
+__device__ __forceinline__ void store_fp8x4(const rv_param_desc& d, long r, long c, const float (&wv)[4], int nvalid) {
+  const float sc = *d.fp8_scale;
+  float q[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = fminf(fmaxf(wv[j] * sc, -448.f), 448.f);
+  unsigned w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
+  unsigned char* sp = reinterpret_cast<unsigned char*>(d.shadow_fp8) + r * d.shadow_ld + c;
+  if (nvalid == 4 && (d.shadow_ld & 3) == 0) *reinterpret_cast<unsigned*>(sp) = w;
+  else
+    for (int j = 0; j < nvalid; ++j) sp[j] = (unsigned char)(w >> (8 * j));
+}
+
 __host__ __device__ inline bool adam_coop(const rv_param_desc& d) { return d.rows == 1 && d.grad_splits >= 16; }
 
 // One virtual block of 256 threads (`vblock` of tab.blk_start[tab.n], thread `tid` of it).  Each thread owns
@@ -176,6 +191,7 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
     }
     if (d.shadow_f32)
       for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
+    if (d.shadow_fp8) store_fp8x4(d, r, c, wv, nvalid);
   }
 }
 
@@ -267,6 +283,7 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
         const bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(d.shadow_bf16) + it[u].r * d.shadow_ld + it[u].c) = b4;
       }
+      if (d.shadow_fp8) store_fp8x4(d, it[u].r, it[u].c, wv, 4);
     }
     return;
   }

@@ -93,12 +93,46 @@ __global__ void __launch_bounds__(256) k_randn(float* out, long n, uint64_t seed
 // ------------------------------------------------------------------ cast + pad
 // One thread per 8 output bf16 (16 B store).  Source rows are read as two float4
 // when in range and aligned, scalar at the ragged edge.
+// fp32 x 8 -> 8 fp8 (e4m3) bytes of v * sc, saturating
+__device__ __forceinline__ unsigned long long q8x8(const float (&v)[8], float sc) {
+  float c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c[e] = fminf(fmaxf(v[e] * sc, -448.f), 448.f);
+  unsigned lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// fp8 state block (rv_plan_set_fp8): thread 0 of the step's first kernel latches the delayed h3 scale
+__device__ __forceinline__ void fp8_latch(float* st, const float* amax_part, int n_amax, int lane) {
+  float m = 0.f;
+  for (int i = lane; i < n_amax; i += 64) m = fmaxf(m, amax_part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) {
+    st[4] = m;
+    if (st[7] == 0.f && m > 0.f) st[3] = 224.f / m;
+    st[5] = 1.f / (st[0] * st[1]);
+    st[6] = 1.f / (st[3] * st[2]);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__ src, long rows,
                                                        long cols, long ld_src,
                                                        bf16_t* __restrict__ dst, long rows_p,
                                                        long cols_p, long ld_dst,
-                                                       long long* step_counter) {
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
+                                                       long long* step_counter,
+                                                       unsigned char* __restrict__ dst_fp8, long ld_fp8,
+                                                       float* fp8_state, const float* __restrict__ fp8_scale,
+                                                       const float* __restrict__ amax_part, int n_amax) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (step_counter && threadIdx.x == 0) *step_counter += 1;
+    if (fp8_state) fp8_latch(fp8_state, amax_part, n_amax, threadIdx.x);
+  }
+  const float qs = dst_fp8 ? *fp8_scale : 0.f;   // the x / weight scale is constant across the latch
   const long cpr = cols_p / 8;
   const long total = rows_p * cpr;
   const bool vec_ok = (ld_src % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -120,10 +154,13 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
           if (c + j < cols) v[j] = s[j];
       }
     }
-    bf16x8 o;
+    if (dst) {
+      bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-    *reinterpret_cast<bf16x8*>(dst + r * ld_dst + c) = o;
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x8*>(dst + r * ld_dst + c) = o;
+    }
+    if (dst_fp8) *reinterpret_cast<unsigned long long*>(dst_fp8 + r * ld_fp8 + c) = q8x8(v, qs);
   }
 }
 
@@ -503,7 +540,40 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
              RV_ERR_SHAPE, "rv_cast_pad_bf16: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
   const long total = rows_p * (cols_p / 8);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter);
+                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
+                     (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst, long rows_p, long cols_p,
+                        long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part, int n_amax,
+                        long long* step_counter, void* stream) {
+  RV_REQUIRE(src && dst, RV_ERR_NULL, "rv_cast_pad_bf16_q8: null pointer");
+  RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols &&
+                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst & 15) == 0,
+             RV_ERR_SHAPE, "rv_cast_pad_bf16_q8: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
+  RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_cast_pad_bf16_q8: the fp8 output needs the state block and 8-byte aligned rows");
+  const long total = rows_p * (cols_p / 8);
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
+                     (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state /* [0] = scale of x */,
+                     amax_part, amax_part ? n_amax : 0);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* dst_fp8, long rows_p, long cols_p,
+                    long ld_dst, const float* scale, void* stream) {
+  RV_REQUIRE(src && dst_fp8 && scale, RV_ERR_NULL, "rv_cast_pad_fp8: null pointer");
+  RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols &&
+                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0,
+             RV_ERR_SHAPE, "rv_cast_pad_fp8: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
+  const long total = rows_p * (cols_p / 8);
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     src, rows, cols, ld_src, (bf16_t*)nullptr, rows_p, cols_p, ld_dst, (long long*)nullptr,
+                     (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -59,6 +59,13 @@ struct GemmArgs {
   float* colsum;    // [grid.y][grid.x*BN] per-row-tile column sums of the bf16 output
   float* blocksum;  // [grid.y*grid.x] per-block sum of (recon-x)^2
   float scale;      // 2/(B*S)
+  // fp8 (e4m3) operand path: A and B point at fp8 bytes viewed as bf16 pairs (lda/ldb and the K extent count
+  // PAIRS), so one staged "64-deep" tile is 128 fp8 values per row and all tile geometry is unchanged
+  const float* dq;       // device scalar: 1 / (scale_A * scale_B), applied to the accumulator; null = 1
+  unsigned char* out_fp8;  // EPI_BIAS_ACT_BF16: also store the output as fp8(out * *q_scale) (next layer's operand)
+  long ld_fp8;
+  const float* q_scale;  // device scalar
+  float* amax_part;      // [number of blocks]: max|out| of each block (delayed scaling: reduced by the next step's first kernel), or null
   int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
                     // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
 };
@@ -140,6 +147,34 @@ __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int k
 // s_nop covers the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside an asm.
 __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// One accumulate step on a pair of 16-byte fragments.  bf16: 16x16x32.  fp8: the two fragments of a staged tile
+// (kk = 0, 1: 2 x 16 fp8 values per lane) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
+// (E8M0 127): twice the MFMA rate of bf16 per k.  A and B fragments take their bytes from the same k positions,
+// so the instruction's internal k order does not matter.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_fp8_k128(const bf16x8 f0, const bf16x8 f1, const bf16x8 s0, const bf16x8 s1,
+                                               const f32x4 c) {
+  const i32x4 a0 = __builtin_bit_cast(i32x4, f0), a1 = __builtin_bit_cast(i32x4, f1);
+  const i32x4 b0 = __builtin_bit_cast(i32x4, s0), b1 = __builtin_bit_cast(i32x4, s1);
+  const i32x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+  const i32x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// fp32 x 8 -> 8 fp8 (e4m3, OCP) bytes, saturating at +-448 (v_cvt_pk_fp8_f32 rounds to nearest even).
+__device__ __forceinline__ unsigned long long pack_fp8x8(const float (&v)[8]) {
+  float c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c[e] = fminf(fmaxf(v[e], -448.f), 448.f);
+  unsigned lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // Wait until at most `tiles` staged tiles (GL LDS-DMA instructions each) are still in flight.
@@ -306,8 +341,9 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 //     before its consumer, and the DMA refill has NSTAGE-1 tiles of MFMA time to land.
 // The barrier publishes every wave's share of tile kt+1 and orders the refill after all
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
-template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
+  static_assert(!FP8 || (A_KMAJ && B_KMAJ && NSTAGE != 8), "fp8 operands: K-major (forward) GEMMs on the ring loop");
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -394,18 +430,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     for (int mi = 0; mi < MI; ++mi) a1[mi] = load_frag<BM, A_KMAJ>(cur, wm * WTM + mi * 16, 1, lane);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b1[ni] = load_frag<BN, B_KMAJ>(cur + A_BYTES, wn * WTN + ni * 16, 1, lane);
+    if constexpr (!FP8) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-    // issue order: MFMA, then {k ds_reads, MFMA} ...
-    constexpr int K1 = (NRD + NMF - 2) / (NMF - 1);  // reads per MFMA gap
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-    for (int i = 0; i < NRD; i += K1) {
-      __builtin_amdgcn_sched_group_barrier(0x100, K1, 0);
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+    }
+    // issue order: MFMA, then {k ds_reads, MFMA} ...  (fp8: no MFMA in this half -- a K = 128 instruction
+    // takes both fragments of the tile, in the second half)
+    if constexpr (!FP8) {
+      constexpr int K1 = (NRD + NMF - 2) / (NMF - 1);  // reads per MFMA gap
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+      for (int i = 0; i < NRD; i += K1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, K1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -420,19 +461,36 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       sa.stage(Ag + (long)(kt + NSTAGE) * a_step, rf, wave);
       sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + A_BYTES, wave);
     }
+    // fp8: this tile's first-half fragments are still needed by the MFMAs below, so the next tile's go to a
+    // second register set and are moved over afterwards
+    bf16x8 a0n[FP8 ? MI : 1], b0n[FP8 ? NI : 1];
     if constexpr (NEXT) {
       const lds_char* nxt = smem + nslot * STAGE;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(nxt, wm * WTM + mi * 16, 0, lane);
+      for (int mi = 0; mi < MI; ++mi) {
+        const bf16x8 f = load_frag<BM, A_KMAJ>(nxt, wm * WTM + mi * 16, 0, lane);
+        if constexpr (FP8) a0n[mi] = f; else a0[mi] = f;
+      }
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(nxt + A_BYTES, wn * WTN + ni * 16, 0, lane);
+      for (int ni = 0; ni < NI; ++ni) {
+        const bf16x8 f = load_frag<BN, B_KMAJ>(nxt + A_BYTES, wn * WTN + ni * 16, 0, lane);
+        if constexpr (FP8) b0n[ni] = f; else b0[ni] = f;
+      }
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-    if constexpr (NEXT) {
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (FP8) acc[mi][ni] = mfma_fp8_k128(b0[ni], b1[ni], a0[mi], a1[mi], acc[mi][ni]);
+        else acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      }
+    if constexpr (FP8 && NEXT) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a0[mi] = a0n[mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+    }
+    if constexpr (NEXT && !FP8) {
       constexpr int NV = REFILL ? GL : 0;
       constexpr int K2 = (NV + NRD + NMF - 2) / (NMF - 1);  // memory instructions per MFMA gap
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -538,6 +596,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       }
     }
   }
+  const float dq = (FP8 && p.dq) ? *p.dq : 1.f;   // fp8 operands: undo the operand scales on the accumulator
+  const float qs = (EPI == EPI_BIAS_ACT_BF16 && p.out_fp8) ? *p.q_scale : 0.f;
+  float amax = 0.f;
   const bool x_al = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
 #pragma unroll
@@ -560,6 +621,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[it][e] = lo[e]; v[it][4 + e] = hi[e]; }
+        if constexpr (FP8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] *= dq;
+        }
         rowi[it] = roww + 16 * (c0 + cm);
         coli[it] = colw + 32 * t;
       }
@@ -568,14 +633,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         bf16x8 o;
+        float q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float tt = v[it][e] + bias[it % NP][e];
           if (p.relu) tt = fmaxf(tt, 0.f);
           o[e] = (bf16_t)tt;
+          q8[e] = tt * qs;
+          amax = fmaxf(amax, fabsf(tt));
         }
         if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         else asm volatile("" ::"v"(o));
+        if (p.out_fp8) *(unsigned long long*)(p.out_fp8 + rowi[it] * p.ld_fp8 + coli[it]) = pack_fp8x8(q8);
       }
     } else if constexpr (EPI == EPI_F32) {
       float* out = p.out_f32 + split * p.split_stride_f32;
@@ -670,6 +739,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
   }
 
+  if constexpr (EPI == EPI_BIAS_ACT_BF16) {
+    if (p.amax_part) {   // one plain store per block (2048 atomics on one word cost 25 us)
+      float m_ = amax;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m_ = fmaxf(m_, __shfl_xor(m_, o, 64));
+      float* red = (float*)smem_generic;
+      if (lane == 0) red[wave] = m_;
+      __syncthreads();
+      if (tid == 0) {
+        float b_ = red[0];
+        for (int w = 1; w < NW; ++w) b_ = fmaxf(b_, red[w]);
+        p.amax_part[bid] = b_;
+      }
+    }
+  }
   if constexpr (EPI == EPI_TANH_LOSS || EPI == EPI_MASK_BF16) {
     if (p.colsum) {
       // lanes with equal (lane >> 4) own the same columns: butterfly over the 16 row lanes, then across
@@ -710,10 +794,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  gemm_body<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI, NSTAGE>(p, blockIdx.x, smem_dyn);
+  gemm_body<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI, NSTAGE, FP8>(p, blockIdx.x, smem_dyn);
 }
 
 // Two independent GEMMs in ONE launch (blocks [0, n_first) run the first): neither of the

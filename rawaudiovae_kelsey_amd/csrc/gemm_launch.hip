@@ -20,7 +20,7 @@ int g_force_tile = -1;
 int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
 int g_pair_only = 0;  // paired launch: 1 = dgrad blocks only, 2 = wgrad blocks only (diagnostics: 300 + v)
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE;  // NSTAGE 8 = ping-pong main loop on two buffers
   constexpr int smem_max = RING * (BM + BN) * 128;
@@ -30,7 +30,7 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   constexpr int epi_bytes = WGM * BN * 4 + 256;  // column-sum / block-sum reductions of the epilogue
   const int used = (NSTAGE == 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
-  auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE>;
+  auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE, FP8>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
@@ -114,6 +114,21 @@ gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable t
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // wave-uniform
     for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += 2 * stride)
       adam_pair(tab, vb, vb + stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter);
+  }
+}
+
+// fp8 (e4m3) forward GEMMs: operands are fp8 bytes viewed as bf16 pairs, `Kp2` = K / 2 in such pairs (so a staged
+// 64-pair tile holds 128 fp8 values per row and every tile / swizzle / ring rule of the bf16 kernels carries over).
+template <int EPI>
+int launch_tile_fp8(int tile, const GemmArgs& a, long Mp, long Np, long Kp2, hipStream_t st) {
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp2 > 0 && Kp2 % 64 == 0, RV_ERR_SHAPE, "fp8 gemm: K must be a multiple of 128 (got %ld)", 2 * Kp2);
+  RV_REQUIRE(tile_fits(tile, Mp, Np), RV_ERR_SHAPE, "fp8 gemm: tile %d does not divide %ld x %ld", tile, Mp, Np);
+  RV_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0, RV_ERR_SHAPE, "fp8 gemm: leading dims must be multiples of 16 bytes");
+  RV_REQUIRE((((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0, RV_ERR_SHAPE, "fp8 gemm: operands must be 16-byte aligned");
+  switch (tile) {
+    case 0: return launch<64, 64, 2, 2, 4, true, true, EPI, true>(a, Mp, Np, 1, st);
+    case 2: return launch<256, 128, 4, 2, 3, true, true, EPI, true>(a, Mp, Np, 1, st);
+    default: return launch<128, 128, 2, 4, 4, true, true, EPI, true>(a, Mp, Np, 1, st);
   }
 }
 
@@ -254,6 +269,50 @@ int rv_linear_fwd(const void* x, long ldx, const void* w, long ldw, const float*
   a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
   return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
+}
+
+int rv_linear_fwd_q8(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp, long Np, long Kp,
+                     int act, void* y, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale, float* amax_part,
+                     void* stream) {
+  RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd_q8: null operand");
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_q8: act %d", act);
+  RV_REQUIRE(!y_fp8 || (q_scale && ldy_fp8 % 8 == 0 && ((uintptr_t)y_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_linear_fwd_q8: fp8 output needs a scale and 8-byte aligned rows");
+  GemmArgs a{};
+  a.A = (const bf16_t*)x; a.lda = ldx; a.B = (const bf16_t*)w; a.ldb = ldw;
+  a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
+  a.out_fp8 = (unsigned char*)y_fp8; a.ld_fp8 = ldy_fp8; a.q_scale = q_scale; a.amax_part = amax_part;
+  return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
+}
+
+int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
+                      long Mp, long Np, long Kp, int act, void* y, long ldy, void* stream) {
+  RV_REQUIRE(x_fp8 && w_fp8 && y && dq, RV_ERR_NULL, "rv_linear_fwd_fp8: null operand");
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_fp8: act %d", act);
+  RV_REQUIRE(Kp % 128 == 0 && ldx % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_linear_fwd_fp8: K and leading dims must be multiples of 128 / 16 fp8 elements");
+  GemmArgs a{};
+  a.A = (const bf16_t*)x_fp8; a.lda = ldx / 2; a.B = (const bf16_t*)w_fp8; a.ldb = ldw / 2;
+  a.k_tiles = (int)(Kp / 128); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy; a.dq = dq;
+  return launch_tile_fp8<EPI_BIAS_ACT_BF16>(choose_tile(Mp, Np, 1), a, Mp, Np, Kp / 2, (hipStream_t)stream);
+}
+
+int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4, const float* dq,
+                               long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx, float* recon,
+                               long ld_recon, void* dP4, long ld_dp4, float* mse_partial, float* db4_partial,
+                               void* stream) {
+  RV_REQUIRE(h3_fp8 && w4_fp8 && dq, RV_ERR_NULL, "rv_decode_out_loss_fwd_fp8: null operand");
+  RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_fp8: B,S exceed padded extents");
+  RV_REQUIRE(!x || dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd_fp8: x given without dP4 output");
+  RV_REQUIRE(Hp % 128 == 0 && ldh % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_fp8: K and leading dims must be multiples of 128 / 16 fp8 elements");
+  GemmArgs a{};
+  a.A = (const bf16_t*)h3_fp8; a.lda = ldh / 2; a.B = (const bf16_t*)w4_fp8; a.ldb = ldw / 2;
+  a.k_tiles = (int)(Hp / 128); a.M_valid = (int)B; a.N_valid = (int)S;
+  a.bias = b4; a.x = x; a.ld_x = ldx; a.recon = recon; a.ld_recon = ld_recon;
+  a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
+  a.scale = 2.0f / ((float)B * (float)S); a.dq = dq;
+  return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
 }
 
 int rv_linear_fwd_f32(const void* x, long ldx, const void* w, long ldw, const float* bias,

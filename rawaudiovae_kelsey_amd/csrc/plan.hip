@@ -57,6 +57,7 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+  int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
   int payload_bf16 = 0;
   void* grad_bf16 = nullptr;   // flat bf16 payload arena (allocated when the bf16 payload is first selected)
 
@@ -144,6 +145,12 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
   p->add("db4p", (long)p->n_mt4 * Sp * 4);
+  p->add("xq", Bp * Sp);          // fp8 operands of the fp8 forward path (rv_plan_set_fp8)
+  p->add("W1q", Hp * Sp);
+  p->add("W4q", Sp * Hp);
+  p->add("h3q", Bp * Hp);
+  p->add("fp8_state", 8 * 4);
+  p->add("h3_amax", 4096 * 4);    // per-block max|h3| of the fc3 forward (zero until it has run)
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
   p->bound = false;
@@ -168,6 +175,18 @@ void rv_plan_destroy(rv_plan* p) {
 int rv_plan_set_concurrency(rv_plan* p, int enable) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
   p->concurrent = enable;
+  return RV_OK;
+}
+
+int rv_plan_set_fp8(rv_plan* p, int enable) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_fp8: plan not bound");
+  p->fp8 = enable ? 1 : 0;
+  float* st = (float*)p->ws("fp8_state");
+  // Adam keeps the fp8 shadows of fc1.weight / fc4.weight current (descriptor 0 and 8)
+  for (rv_param_desc* d : {p->d_slab, p->d_flat}) {
+    d[0].shadow_fp8 = enable ? p->ws("W1q") : nullptr; d[0].fp8_scale = st + 1;
+    d[8].shadow_fp8 = enable ? p->ws("W4q") : nullptr; d[8].fp8_scale = st + 2;
+  }
   return RV_OK;
 }
 
@@ -239,6 +258,10 @@ int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
       else rows_p = p->Lp;
       int rc = rv_cast_pad_bf16(src, d.rows, d.cols, d.cols, d.shadow_bf16, rows_p, cols_p, cols_p, nullptr, stream);
       if (rc) return rc;
+      if (d.shadow_fp8) {
+        rc = rv_cast_pad_fp8(src, d.rows, d.cols, d.cols, d.shadow_fp8, rows_p, cols_p, cols_p, d.fp8_scale, stream);
+        if (rc) return rc;
+      }
     } else {
       long pad = (i == 3 || i == 5) ? p->Lp : d.shadow_ld;
       RV_HIP(hipMemsetAsync(d.shadow_f32, 0, pad * sizeof(float), st));
@@ -263,15 +286,34 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
   if (phases & RV_PHASE_FWD) {
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
-    RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
-    RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+    float* f8 = (float*)p->ws("fp8_state");
+    if (p->fp8) {
+      int bm3 = 128, bn3 = 128;
+      rv_gemm_tile(Bp, Hp, 1, &bm3, &bn3);
+      const int n_amax = (int)((Bp / bm3) * (Hp / bn3));
+      RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 4096 fc3 output tiles (got %d)", n_amax);
+      RV_TRY(rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
+                                 p->b.step_counter, stream));
+      RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                               h1, Hp, stream));
+    } else {
+      RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
+      RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+    }
     RV_TRY(rv_linear_fwd_f32(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, L2p, Hp, p->s_heads,
                              mulv_slabs, L2p, stream));
     RV_TRY(rv_reparam_fwd(mulv_slabs, p->s_heads, Bp, Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z,
                           kl_part, stream));
-    RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
-    RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
-                                  recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+    if (p->fp8) {
+      RV_TRY(rv_linear_fwd_q8(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                              p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+      RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
+                                        x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+    } else {
+      RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
+      RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
+                                    recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+    }
   }
   const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
                               (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&

@@ -38,7 +38,7 @@ class TrainEngine:
     """Owns the arenas + workspace of one (S, H, L, B) training configuration."""
 
     def __init__(self, segment_length, n_units, latent_dim, batch_size, device="cuda",
-                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None):
+                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None, fp8=False):
         """share: another TrainEngine of the same (S, H, L) whose parameter / Adam / gradient
         arenas, step counter and loss ring this one uses (a second batch size, e.g. the ragged
         last batch of an epoch -- DataLoader keeps it, train.py:134)."""
@@ -83,6 +83,12 @@ class TrainEngine:
                                  ptr(self.loss_ring), self.ring)
         L_.rv_plan_bind(self._plan, C.byref(self._bufs))
         self.host_steps = 0
+        # fp8 (e4m3) operands for the fc1 / fc4 forward GEMMs (BASELINE configs[4]; build extension)
+        self.fp8 = bool(fp8)
+        self.fp8_x_scale = 256.0        # frames are in [-1, 1]
+        self.fp8_h3_scale = 16.0        # first step only; afterwards 224 / max|h3| of the previous step
+        if self.fp8:
+            L_.rv_plan_set_fp8(self._plan, 1)
 
     def __del__(self):
         try:
@@ -122,8 +128,32 @@ class TrainEngine:
         onto a side stream beside the fc1 weight-gradient GEMM (measured slower at C2: 224 vs 217 us)."""
         lib().rv_plan_set_concurrency(self._plan, int(enable))
 
+    def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
+        """Write entries of the fp8 state block (include/rawvae_hip.h, rv_plan_set_fp8).  Weight scales are
+        normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""
+        st = self.buffer("fp8_state", torch.float32, (8,))
+        for i, v in ((0, x), (1, w1), (2, w4), (3, h3)):
+            if v is not None:
+                st[i] = float(v)
+        if freeze_h3 is not None:
+            st[7] = 1.0 if freeze_h3 else 0.0
+
+    def fp8_state(self):
+        return self.buffer("fp8_state", torch.float32, (8,)).tolist()
+
     def refresh_shadows(self, stream=None):
         """Rebuild this engine's bf16/padded weight shadows from the fp32 arena."""
+        if self.fp8:
+            with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+                st = self.buffer("fp8_state", torch.float32, (8,))
+                cur = st.tolist()
+                amax1 = float(self.view(self.param, "fc1.weight").abs().max())
+                amax4 = float(self.view(self.param, "fc4.weight").abs().max())
+                st[0] = self.fp8_x_scale
+                st[1] = 224.0 / max(amax1, 1e-12)
+                st[2] = 224.0 / max(amax4, 1e-12)
+                if cur[3] == 0.0:
+                    st[3] = self.fp8_h3_scale
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
         self._shadow_version = self._shared["version"]
 

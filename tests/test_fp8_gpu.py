@@ -1,0 +1,109 @@
+"""fp8 (e4m3) forward path for fc1 / fc4 (BASELINE configs[4]; a build extension, SURVEY D4 -- the reference
+has no reduced-precision mode, so the contract is the build's own oracle with the fp8 rounding points,
+`oracle/vae_oracle.py` quant="fp8", exactly as quant="bf16" is for the bf16 path).
+
+Stated tolerances:
+  * vs the fp8-quantised oracle (same rounding points, fp32 accumulation): loss 2e-5 rel.  Per element the
+    comparison is statistical: a last-bit difference in an fp32 sum (MFMA vs numpy order) that crosses an e4m3
+    rounding boundary moves that h3 element by a whole fp8 step (6-12 %) and with it every output of its row,
+    so recon is held to 3e-2 abs everywhere with 90 % of the elements within 1e-3, gradients to 3e-2 rel-L2;
+  * vs the reference's fp32 golden vectors: loss within 2e-3 rel at the smoke and benchmark shapes (e4m3 carries
+    3 mantissa bits: ~3 % rms per element, averaged over 1024- / 2048-deep contractions), 20-step trajectory 5e-3.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN  # noqa: E402
+from oracle import vae_oracle as O  # noqa: E402
+from oracle.inputs import PARAM_NAMES, make_eps, make_frames, make_params  # noqa: E402
+
+KL, LR = 1e-4, 1e-4
+
+
+def _engine(S, H, L, B, **kw):
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    e = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, fp8=True, **kw)
+    e.load_params(make_params(S, H, L, 0))
+    return e
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def test_fp8_cast_matches_e4m3_rounding():
+    """rv_cast_pad_fp8 == numpy e4m3 rounding == torch.float8_e4m3fn, incl. saturation and subnormals."""
+    from rawaudiovae_kelsey_amd._lib import lib, stream_ptr
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.normal(0, 60, 4000), rng.uniform(-0.05, 0.05, 4000),
+                        [0, 448, 500, -500, 2 ** -9, 2 ** -10, 0.0156, 464, 465, -447.9] + [0.0] * 22]).astype(np.float32)
+    a = a.reshape(-1, 16)
+    rows, cols = a.shape
+    src = torch.from_numpy(a).cuda()
+    dst = torch.zeros((rows, cols), dtype=torch.uint8, device="cuda")
+    scale = torch.tensor([1.0], device="cuda")
+    lib().rv_cast_pad_fp8(src.data_ptr(), rows, cols, cols, dst.data_ptr(), rows, cols, cols, scale.data_ptr(), stream_ptr())
+    got = dst.view(torch.float8_e4m3fn).float().cpu().numpy()
+    np.testing.assert_array_equal(got, O.fp8_e4m3_round(a))
+    np.testing.assert_array_equal(got, torch.from_numpy(np.clip(a, -448, 448)).to(torch.float8_e4m3fn).float().numpy())
+
+
+@pytest.mark.parametrize("shape", [(512, 2048, 8, 32), (256, 384, 100, 130), (1024, 2048, 64, 4096)])
+def test_fp8_step_vs_fp8_oracle(shape):
+    from rawaudiovae_kelsey_amd import engine as E
+    S, H, L, B = shape
+    e = _engine(S, H, L, B)
+    e.set_fp8_scales(h3=32.0, freeze_h3=True)
+    st = e.fp8_state()
+    scales = {"x": st[0], "w1": st[1], "w4": st[2], "h3": 32.0}
+    x, eps = make_frames(B, S, 1234), make_eps(B, L, 4321)
+    recon = torch.zeros(B, S, device="cuda")
+    e.step(torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda(), recon,
+           phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B)
+    torch.cuda.synchronize()
+    p = O.cast_params(make_params(S, H, L, 0), np.float32)
+    c = O.forward(p, x, eps, quant="fp8", fp8_scales=scales)
+    loss = O.loss_function(c["recon"].astype(np.float64), x.astype(np.float64), c["mu"].astype(np.float64),
+                           c["logvar"].astype(np.float64), KL)[0]
+    g = O.backward(p, c, KL, quant="bf16")
+    got = e.last_loss()[0]
+    assert abs(got - loss) <= 2e-5 * abs(loss), (got, loss)
+    err = np.abs(recon.cpu().numpy().astype(np.float64) - c["recon"])
+    assert float(err.max()) < 3e-2 and float((err > 1e-3).mean()) < 0.1, (err.max(), (err > 1e-3).mean())
+    gv = e.grad_views()
+    for k in PARAM_NAMES:
+        assert _rel_l2(gv[k].cpu().numpy(), g[k]) < 3e-2, (k, _rel_l2(gv[k].cpu().numpy(), g[k]))
+    # the fp8 operand images themselves: W1q is fp8(W1 * s_w1) zero-padded
+    Bp, Sp, Hp, Lp = e.padded()
+    w1q = e.buffer("W1q", torch.uint8, (Hp, Sp)).view(torch.float8_e4m3fn).float().cpu().numpy()
+    np.testing.assert_array_equal(w1q[:H, :S], O.fp8_e4m3_round(p["fc1.weight"] * np.float32(st[1])))
+    assert not w1q[H:].any() and not w1q[:, S:].any()
+
+
+@pytest.mark.parametrize("case", ["smoke_f32", "c2_f32"])
+def test_fp8_trajectory_vs_reference_golden(case):
+    """20 full steps (delayed h3 scaling live, Adam rewriting the fp8 weight shadows) against the reference's
+    fp32 loss trajectory."""
+    with open(os.path.join(GOLDEN, "summary.json")) as f:
+        cs = json.load(f)["cases"][case]
+    S, H, L, B = cs["shape"]
+    e = _engine(S, H, L, B)
+    for i in range(20):
+        e.step(torch.from_numpy(make_frames(B, S, 1234 + i)).cuda(), torch.from_numpy(make_eps(B, L, 4321 + i)).cuda())
+    got, ref = np.array(e.losses(20)), np.array(cs["traj"])
+    rel = np.abs(got - ref) / ref
+    assert rel[0] <= 2e-3 and rel.max() <= 5e-3, rel
+    st = e.fp8_state()
+    assert st[3] != 16.0 and 1.0 < st[3] < 4096.0     # the activation scale has been latched from a measured max
+    # Adam kept the fp8 shadow of fc4.weight equal to fp8(W4 * s_w4)
+    Bp, Sp, Hp, Lp = e.padded()
+    w4q = e.buffer("W4q", torch.uint8, (Sp, Hp)).view(torch.float8_e4m3fn).float().cpu().numpy()
+    w4 = e.view(e.param, "fc4.weight").cpu().numpy()
+    np.testing.assert_array_equal(w4q[:S, :H], O.fp8_e4m3_round(w4 * np.float32(st[2])))
