@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="also time the step with fc1 / fc4 forward on fp8 (e4m3) operands and report it as the side "
                          "line `alt_fp8` (BASELINE configs[4]); the headline stays bf16")
+    ap.add_argument("--n128-loop", type=int, default=0,
+                    help="experiment: main loop of the 256x128 GEMM tile (3 one-barrier ring = default, 9 ping-pong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--repeats", type=int, default=0,
@@ -127,6 +129,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.n128_loop:
+        from rawaudiovae_kelsey_amd._lib import lib as _rvlib
+        _rvlib().rv_gemm_force_tile(100 + args.n128_loop)
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
     eng.load_params(make_params(S, H, L, 0))
     eng.set_concurrency(0 if args.serial else args.sched)

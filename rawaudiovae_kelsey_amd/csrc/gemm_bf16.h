@@ -329,6 +329,107 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same ping-pong structure for the 256 x 128 tile (NSTAGE == 9; 8 waves as 2 x 4 of 128 x 32): the tile
+// every full-chip GEMM of the C2 step gets (256 of them), where the one-barrier ring loop below is bound by
+// how fast one CU can fill its LDS and loses a third of its time on MN-major (transposing) operands.
+// Two phases per 64-deep K tile, one 64 x 32 half of the wave's output per phase (16 MFMAs each):
+//      phase 0: read B + A(m0)   MFMA (m0)   stage A-half 0 and B of tile kt+2   wait: A-half 1 of tile kt landed
+//      phase 1: read A(m1)       MFMA (m1)   stage A-half 1 of tile kt+2         wait: A-half 0 and B of tile kt+1 landed
+// LDS: 3 buffers x {A half 0, A half 1, B} x 16 KiB (tile kt lives in buffer kt % 3), so the LDS-DMA runs two
+// K tiles (four phases) ahead.  Hazards, as in the 256 x 256 loop: a piece is restaged two phases after its last
+// fragment read (A-half 0 / B of tile kt-1: read in its phase 0, restaged in phase 0 of tile kt; A-half 1: phase 1
+// -> phase 1) and read one phase after the counted vmcnt that retires its LDS-DMA; the two wave rows run one
+// barrier apart.  Each piece is 2 LDS-DMA instructions per wave, issued in the order
+// ... A1(kt) | A0(kt+1) B(kt+1) | A1(kt+1) | A0(kt+2) B(kt+2) | A1(kt+2) ..., which fixes the vmcnt counts below.
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mainloop_pingpong_n128(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
+                                                       const long lda, const long ldb, const int nk, lds_char* smem,
+                                                       const int wave, const int lane, f32x4 (&acc)[8][2]) {
+  constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k piece
+  constexpr int BUF = 3 * HALF;          // A0 A1 B
+  const int wr = wave >> 2, wc = wave & 3;
+  StageOffsets<128, A_KMAJ, 8> sa;
+  StageOffsets<128, B_KMAJ, 8> sb;
+  sa.init(lda, wave, lane);
+  sb.init(ldb, wave, lane);
+  const long a_step = A_KMAJ ? 64 : 64 * lda, b_step = B_KMAJ ? 64 : 64 * ldb;
+  const long a_half = A_KMAJ ? 128 * lda : 128;
+  auto buf_of = [&](int t) { return smem + (t % 3) * BUF; };
+  auto stage_a = [&](int h, int t) {
+    if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, buf_of(t) + h * HALF, wave);
+  };
+  auto stage_b = [&](int t) {
+    if (t < nk) sb.stage(Bg + (long)t * b_step, buf_of(t) + 2 * HALF, wave);
+  };
+  bf16x8 a[4][2], b[2][2];
+  auto rd_a = [&](const lds_char* buf, int mq) {
+    const lds_char* base = buf + wr * HALF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) a[i][kk] = load_frag<128, A_KMAJ>(base, mq * 64 + i * 16, kk, lane);
+  };
+  auto rd_b = [&](const lds_char* buf) {
+    const lds_char* base = buf + 2 * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b[j][kk] = load_frag<128, B_KMAJ>(base, wc * 32 + j * 16, kk, lane);
+  };
+  auto mma = [&](auto mq_c) {
+    constexpr int MQ = decltype(mq_c)::value;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[MQ * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[MQ * 4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // prologue: tiles 0 and 1 staged in the steady-state order; A-half 0 and B of tile 0 landed
+  stage_a(0, 0); stage_b(0); stage_a(1, 0);
+  stage_a(0, 1); stage_b(1); stage_a(1, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const lds_char* cur = buf_of(kt);
+    // phase 0
+    rd_b(cur);
+    rd_a(cur, 0);
+    stage_a(0, kt + 2);
+    stage_b(kt + 2);
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mma(I0{});
+    // phase 1
+    rd_a(cur, 1);
+    stage_a(1, kt + 2);
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mma(I1{});
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Block tile BM x BN computed by a WGM x WGN grid of waves (wave tile BM/WGM x BN/WGN).
 //
 // NSTAGE-deep LDS ring, software-pipelined so it also runs at one wave per SIMD:
@@ -343,15 +444,17 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
 template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
-  static_assert(!FP8 || (A_KMAJ && B_KMAJ && NSTAGE != 8), "fp8 operands: K-major (forward) GEMMs on the ring loop");
+  static_assert(!FP8 || (A_KMAJ && B_KMAJ && NSTAGE < 8), "fp8 operands: K-major (forward) GEMMs on the ring loop");
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
   constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
-  constexpr bool PINGPONG = NSTAGE == 8;  // 256x256 ping-pong main loop (2 LDS buffers)
-  static_assert(PINGPONG || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
+  constexpr bool PINGPONG = NSTAGE == 8;    // 256x256 ping-pong main loop (2 LDS buffers)
+  constexpr bool PINGPONG_N128 = NSTAGE == 9;  // 256x128 ping-pong main loop (3 LDS buffers)
+  static_assert(PINGPONG || PINGPONG_N128 || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
   static_assert(!PINGPONG || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4), "ping-pong loop: 256x256, 2x4 waves");
+  static_assert(!PINGPONG_N128 || (BM == 256 && BN == 128 && WGM == 2 && WGN == 4), "ping-pong loop: 256x128, 2x4 waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,6 +498,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     // diagnostic: epilogue only
   } else if constexpr (PINGPONG) {
     mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
+  } else if constexpr (PINGPONG_N128) {
+    mainloop_pingpong_n128<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;

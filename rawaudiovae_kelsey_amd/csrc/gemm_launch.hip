@@ -17,18 +17,22 @@ namespace {
 //   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring); only
 //      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
 int g_force_tile = -1;
+// Main loop of the 256x128 tile: 3 = one-barrier ring (default), 9 = ping-pong on three buffers.  Measured stand-alone
+// at C2 (tools/gemm_bench.py, same box, interleaved): NT 19.7 vs 21.5 us, TN 28.7 vs 29.5, NN 27.3 vs 25.4 -- at this
+// tile the loop is bound by how fast one CU fills its LDS (~60 GB/s), which the phase structure does not change.
+int g_n128_loop = 3;
 int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
 int g_pair_only = 0;  // paired launch: 1 = dgrad blocks only, 2 = wgrad blocks only (diagnostics: 300 + v)
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
-  constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE;  // NSTAGE 8 = ping-pong main loop on two buffers
+  constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE == 9 ? 3 : NSTAGE;  // NSTAGE 8 / 9 = ping-pong main loops on 2 / 3 buffers
   constexpr int smem_max = RING * (BM + BN) * 128;
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
   constexpr int stage_bytes = (BM + BN) * 128;
   constexpr int epi_bytes = WGM * BN * 4 + 256;  // column-sum / block-sum reductions of the epilogue
-  const int used = (NSTAGE == 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
+  const int used = (NSTAGE >= 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE, FP8>;
   static bool attr_done = false;
@@ -82,7 +86,9 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
   switch (tile) {
     case 0: return launch<64, 64, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 1: return launch<128, 128, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
-    case 2: return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 2:
+      if (g_n128_loop == 3) return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
+      return launch<256, 128, 2, 4, 9, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 4: return launch<128, 128, 2, 4, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 5: return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 7:
@@ -245,6 +251,7 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 
 extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
+  if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }  // experiment hook: 256x128 main loop
   if (tile >= 200 && tile < 208) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
   if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
   g_force_tile = tile;

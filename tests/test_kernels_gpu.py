@@ -80,12 +80,18 @@ def test_linear_dgrad_f32(L, M, N, K, splits):
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7], ids=["auto", "t64", "t128w4", "t256x128w8", "t256x128w4", "t128w8", "t256x256", "t256x256pp"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7, 1002], ids=["auto", "t64", "t128w4", "t256x128w8", "t256x128w4", "t128w8", "t256x256", "t256x256pp", "t256x128pp"])
 def tile(request, L):
-    """Pin each block-tile configuration in turn (256-row tiles only apply when M % 256 == 0)."""
-    L.rv_gemm_force_tile(request.param)
-    yield request.param
+    """Pin each block-tile configuration in turn (256-row tiles only apply when M % 256 == 0).  1002 = the
+    256x128 tile on its ping-pong main loop (an experiment kept behind rv_gemm_force_tile(109))."""
+    t = request.param
+    if t == 1002:
+        L.rv_gemm_force_tile(109)
+        t = 2
+    L.rv_gemm_force_tile(t)
+    yield t
     L.rv_gemm_force_tile(-1)
+    L.rv_gemm_force_tile(103)
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(256, 128, 256, 1), (512, 256, 192, 1), (256, 256, 512, 4)])

@@ -17,6 +17,8 @@ if os.environ.get('RV_TILE'):
     Lb.rv_gemm_force_tile(int(os.environ['RV_TILE']))
 if os.environ.get('RV_PAIR_LOOP'):   # 2: two-slot ring, 8: ping-pong main loop of the paired 256x256 kernel
     Lb.rv_gemm_force_tile(100 + int(os.environ['RV_PAIR_LOOP']))
+if os.environ.get('RV_N128'):        # 3: one-barrier ring, 9: ping-pong main loop of the 256x128 tile
+    Lb.rv_gemm_force_tile(100 + int(os.environ['RV_N128']))
 st = torch.cuda.current_stream().cuda_stream or None
 
 
