@@ -171,9 +171,15 @@ def main():
                 dist.all_gather_object(reasons, my_reason)
                 native_fallback_reason = "; ".join(r for r in reasons if r) or "another rank failed"
         if ok:
-            runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1")
-            ddp_mode = "fp32, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its own stream, " \
-                       "overlapped with backward" + (", hipGraph" if runner.use_graph else "")
+            # RV_DDP_MODE=sharded (default): sharded optimizer -- reduce-scatter gradients, Adam on 1/world of the
+            # arena per rank, all-gather parameters; =allreduce: all-reduce + the full update on every rank
+            sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
+            runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1", sharded=sharded)
+            ddp_mode = ("sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the arena -> "
+                        "fp32 all-gather of the parameters, all issued by rv_plan_step_ddp on its own stream" % world) \
+                if sharded else ("fp32, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its own "
+                                 "stream, overlapped with backward")
+            ddp_mode += ", hipGraph" if runner.use_graph else ""
         else:
             # eager launches: six hipGraph segments per step measured slower (292 vs 263 us on one rank)
             runner = ddp.DdpRunner(eng, sync, comp, use_graphs=False)
@@ -261,7 +267,34 @@ def main():
         # Not the headline: the same K steps again with the bf16 gradient payload (half the all-reduce
         # bytes), so that one run shows what the exchange costs at this GPU count.
         alt = None
-        if isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
+        if isinstance(runner, ddp.NativeDdpRunner) and runner.sharded and os.environ.get("RV_DDP_ALT", "1") == "1":
+            # Not the headline: the same K steps with the all-reduce + full-update schedule on a second engine
+            # (the sharded engine's moments are shard-local, so it cannot simply switch modes)
+            try:
+                eng2 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
+                eng2.load_params(make_params(S, H, L, 0))
+                run2 = ddp.NativeDdpRunner(eng2, comm, comp, sharded=False)
+                for i in range(5):
+                    run2.step(pool[i % POOL])
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    run2.step(pool[i % POOL])
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                adt = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([adt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    adt = float(t.item())
+                alt = {"grad_allreduce": "fp32 all-reduce, full Adam on every rank", "ms_per_step": adt / args.steps * 1e3,
+                       "value": float(B) * world * args.steps / adt}
+            except Exception as exc:   # the headline above is already measured: report, do not lose it
+                alt = {"grad_allreduce": "fp32 all-reduce, full Adam on every rank", "error": str(exc)[:200]}
+        elif isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
             try:
                 runner.set_payload("bf16")
                 for i in range(5):
@@ -345,7 +378,7 @@ def main():
             "timing": {"repeats": len(passes), "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
                        "timed_seconds_total": sum(passes)},
             "host_us_per_step": host_dt / args.steps * 1e6,
-            **({"alt_bf16_payload": alt} if alt else {}),
+            **({("alt_allreduce" if getattr(runner, "sharded", False) else "alt_bf16_payload"): alt} if alt else {}),
             **({"alt_fp8": alt_fp8} if alt_fp8 else {}),
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None)}

@@ -259,6 +259,16 @@ int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, lon
                          float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
                          const long long* step_counter, int n_adam_blocks, void* stream);
 
+/* Sharded data-parallel optimizer (rv_plan_step_ddp in sharded mode; also callable on their own):
+ * rv_adam_flat: the Adam update of elements [lo, lo + n) of the flat arenas, gradient element i of the shard at
+ *   grad_shard[i] (a reduce-scatter's output), multiplied by grad_scale first.
+ * rv_params_from_flat: parameters AND every operand shadow of the `descs` tensors from a flat fp32 source (an
+ *   all-gather's output): arena element o is flat[o - flat_base]. */
+int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
+                 float grad_scale, const long long* step_counter, void* stream);
+int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
+                        void* stream);
+
 /* bf16 variants for the data-parallel exchange (halves the all-reduce bytes; the in-rank sums stay
  * fp32): rv_grad_finalize_bf16 rounds the summed gradient to a flat bf16 arena (same element offsets
  * as the fp32 arenas); rv_adam_multi_bf16grad takes the gradient from such an arena (after its
@@ -353,6 +363,10 @@ int rv_plan_set_concurrency(rv_plan*, int enable);
  *   [7] non-zero: keep [3] fixed (parity runs).
  * Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them. */
 int rv_plan_set_fp8(rv_plan*, int enable);
+/* The plan's ten parameter descriptors (PARAM order): gradient slabs of its own workspace (from_flat = 0) or the
+ * bound flat gradient arena (1), and the operand shadows Adam must refresh.  For callers that drive
+ * rv_adam_multi / rv_params_from_flat themselves. */
+int rv_plan_descs(const rv_plan*, rv_param_desc* out10, int from_flat);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);
 /* Enqueue the selected phases of one training step (train.py:184-193) on `stream`.
@@ -374,6 +388,22 @@ int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* 
 typedef int (*rv_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
                                void* comm, void* stream);
 int rv_plan_attach_comm(rv_plan*, rv_allreduce_fn allreduce, void* comm, int world);
+/* Sharded mode of rv_plan_step_ddp (optimizer state and update sharded over the ranks): per gradient bucket
+ * (0: fc4 = arena elements [offset of fc4.weight, n_params); 1: everything before it) the flat fp32 gradients are
+ * REDUCE-SCATTERED (each rank receives the sum of its `rv_plan_shard_count` elements), the rank runs Adam on its shard
+ * only (rv_adam_flat), the updated fp32 parameters are ALL-GATHERED and every rank rebuilds its parameters and bf16
+ * shadows from the gathered buffer (rv_params_from_flat).  Per rank: 1/world of Adam's 30 B/param instead of all of
+ * it, the same bytes on the links as an all-reduce.  exp_avg / exp_avg_sq are valid on their owner rank only.
+ * `reduce_scatter` / `all_gather` have RCCL's ncclReduceScatter / ncclAllGather signatures.  The caller owns
+ * rs_buf (sum over the buckets of rv_plan_shard_count floats) and ag_buf (world times that), and its param / grad
+ * arenas must extend 4 * world elements past n_params (a bucket is cut into `world` equal shards of a multiple of 4
+ * elements, so the last shard can overhang its bucket). */
+typedef int (*rv_reduce_scatter_fn)(const void* sendbuf, void* recvbuf, size_t recvcount, int dtype, int op, void* comm,
+                                    void* stream);
+typedef int (*rv_all_gather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, void* stream);
+long rv_plan_shard_count(const rv_plan*, int bucket, int world);
+int rv_plan_attach_comm_sharded(rv_plan*, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
+                                int world, int rank, float* rs_buf, float* ag_buf);
 /* Payload of the gradient all-reduces: 0 = fp32 (default, exact mean of the ranks' fp32 gradients),
  * 1 = bf16 (each rank's summed gradient rounded to bf16, summed by the collective in bf16). */
 int rv_plan_set_ddp_payload(rv_plan*, int bf16);

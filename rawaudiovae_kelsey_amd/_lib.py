@@ -109,10 +109,15 @@ _SIGS = {
     "rv_plan_workspace_bytes": (c_long, [c_void_p]),
     "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
+    "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_attach_comm": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "rv_plan_shard_count": (c_long, [c_void_p, c_int, c_int]),
+    "rv_plan_attach_comm_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rv_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_float, c_float, c_void_p, c_void_p]),
+    "rv_params_from_flat": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_plan_set_ddp_payload": (c_int, [c_void_p, c_int]),
     "rv_grad_finalize_bf16": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
     "rv_adam_multi_bf16grad": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,

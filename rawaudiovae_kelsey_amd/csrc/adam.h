@@ -54,6 +54,18 @@ __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long
   return g;
 }
 
+// The Adam update of one element (torch.optim.Adam, single-tensor form; train.py:163,193).  Every kernel that
+// updates parameters goes through this one function with floating-point contraction OFF, so that the stand-alone
+// kernel, the optimizer blocks of the weight-gradient launch and the sharded flat kernel (vector and scalar paths)
+// round identically whatever the surrounding code looks like -- replicas and schedules stay bit-equal.
+__device__ __forceinline__ void adam_update(float& m, float& v, float& w, const float g, const float step_size,
+                                            const float bc2s) {
+#pragma clang fp contract(off)
+  m = 0.9f * m + 0.1f * g;
+  v = 0.999f * v + (0.001f * g) * g;
+  w = w - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
+}
+
 // fp8(w * scale) for up to 4 consecutive elements of one row of the padded fp8 shadow.
 __device__ __forceinline__ void store_fp8x4(const rv_param_desc& d, long r, long c, const float (&wv)[4], int nvalid) {
   const float sc = *d.fp8_scale;
@@ -164,11 +176,7 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
     const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));  // log2(0.999)
     const float step_size = lr / bc1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
-      vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
-      wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
-    }
+    for (int j = 0; j < 4; ++j) adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
     if (vec) {
       *reinterpret_cast<float4*>(m_arena + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4*>(v_arena + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -272,9 +280,7 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         gv[j] *= grad_scale;
-        mv[j] = 0.9f * mv[j] + 0.1f * gv[j];
-        vv[j] = 0.999f * vv[j] + 0.001f * gv[j] * gv[j];
-        wv[j] -= step_size * (mv[j] / (sqrtf(vv[j]) / bc2s + 1e-8f));
+        adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
       }
       *reinterpret_cast<float4*>(m_arena + it[u].o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4*>(v_arena + it[u].o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -291,6 +297,37 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
     adam_block<true>(tab, vb0, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
   if (it[1].state)
     adam_block<true>(tab, vb1, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
+}
+
+// Parameters and every operand shadow of the table's tensors from a flat fp32 source (the all-gather's output):
+// element at flat arena offset o is flat[o - flat_base].  One virtual block = 256 threads, 4 elements each.
+__device__ __forceinline__ void refresh_block(const DescTable& tab, const long vblock, const int tid,
+                                              const float* __restrict__ flat, const long flat_base,
+                                              float* __restrict__ param) {
+  int t = 0;
+  while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
+  t = __builtin_amdgcn_readfirstlane(t);
+  const rv_param_desc d = tab.d[t];
+  const long gpr = (d.cols + 3) / 4;
+  const bool coop = adam_coop(d);   // the table's block layout gives such rows one WAVE per group
+  const long blk = vblock - tab.blk_start[t];
+  const long grp = coop ? blk * 4 + (tid >> 6) : blk * 256 + tid;
+  if (grp >= gpr * d.rows || (coop && (tid & 63) != 0)) return;
+  const long r = grp / gpr, c = (grp % gpr) * 4;
+  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
+  const long o = d.offset + r * d.cols + c;
+  float wv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < nvalid; ++j) {
+    wv[j] = flat[o - flat_base + j];
+    param[o + j] = wv[j];
+  }
+  if (d.shadow_bf16) {
+    bf16_t* sp = reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c;
+    for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
+  }
+  if (d.shadow_f32)
+    for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
+  if (d.shadow_fp8) store_fp8x4(d, r, c, wv, nvalid);
 }
 
 template <bool UPDATE>

@@ -504,6 +504,47 @@ k_gather_frames(const float* __restrict__ audio, long n_samples, const long long
 }
 
 
+// ---- sharded data-parallel optimizer (rv_plan_step_ddp, sharded mode) ----
+// Adam on one rank's contiguous shard [lo, lo + n) of the flat arenas; the gradient comes from the reduce-scatter's
+// output buffer (element i of the shard at grad_shard[i]).  Same arithmetic, in the same order, as adam_block.
+__global__ void __launch_bounds__(256)
+k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __restrict__ v_arena,
+            const float* __restrict__ grad_shard, const long lo, const long n, const float lr, const float grad_scale,
+            const long long* __restrict__ step_counter) {
+  const float tt = (float)(*step_counter);
+  const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);
+  const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));
+  const float step_size = lr / bc1;
+  const bool vec = (lo & 3) == 0 && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m_arena) |
+                                      reinterpret_cast<uintptr_t>(v_arena) | reinterpret_cast<uintptr_t>(grad_shard)) & 15) == 0;
+  const long n4 = vec ? n >> 2 : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 g4 = reinterpret_cast<const float4*>(grad_shard)[i];
+    float4 m4 = reinterpret_cast<float4*>(m_arena + lo)[i], v4 = reinterpret_cast<float4*>(v_arena + lo)[i];
+    float4 w4 = reinterpret_cast<float4*>(param + lo)[i];
+    float gv[4] = {g4.x * grad_scale, g4.y * grad_scale, g4.z * grad_scale, g4.w * grad_scale};
+    float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
+    reinterpret_cast<float4*>(m_arena + lo)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    reinterpret_cast<float4*>(v_arena + lo)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    reinterpret_cast<float4*>(param + lo)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = grad_shard[i] * grad_scale;
+    float m_ = m_arena[lo + i], v_ = v_arena[lo + i], w_ = param[lo + i];
+    adam_update(m_, v_, w_, g, step_size, bc2s);
+    m_arena[lo + i] = m_;
+    v_arena[lo + i] = v_;
+    param[lo + i] = w_;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_params_from_flat(const DescTable tab, const float* __restrict__ flat, const long flat_base, float* __restrict__ param) {
+  refresh_block(tab, (long)blockIdx.x, (int)threadIdx.x, flat, flat_base, param);
+}
+
 inline unsigned grid_for(long n_threads, long cap = 2048) {
   long g = (n_threads + 255) / 256;
   if (g < 1) g = 1;
@@ -722,6 +763,31 @@ int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param,
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, (float*)nullptr, lr, grad_scale,
                      step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
+                 float grad_scale, const long long* step_counter, void* stream) {
+  RV_REQUIRE(param && exp_avg && exp_avg_sq && grad_shard && step_counter, RV_ERR_NULL, "rv_adam_flat: null pointer");
+  RV_REQUIRE(lo >= 0 && n >= 0, RV_ERR_SHAPE, "rv_adam_flat: bad range %ld + %ld", lo, n);
+  if (n == 0) return RV_OK;
+  hipLaunchKernelGGL(k_adam_flat, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, param, exp_avg,
+                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
+                        void* stream) {
+  RV_REQUIRE(flat && param, RV_ERR_NULL, "rv_params_from_flat: null pointer");
+  DescTable tab;
+  int rc = adam_build_table(descs, n_desc, &tab);
+  if (rc) return rc;
+  for (int i = 0; i < n_desc; ++i)
+    RV_REQUIRE(descs[i].offset >= flat_base, RV_ERR_SHAPE, "rv_params_from_flat: tensor %d starts before the flat source", i);
+  hipLaunchKernelGGL(k_params_from_flat, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0, (hipStream_t)stream, tab,
+                     flat, flat_base, param);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

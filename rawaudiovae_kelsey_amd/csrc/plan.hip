@@ -57,6 +57,13 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+  // sharded optimizer (rv_plan_attach_comm_sharded)
+  rv_reduce_scatter_fn reduce_scatter = nullptr;
+  rv_all_gather_fn all_gather = nullptr;
+  int rank = 0;
+  float* rs_buf = nullptr;
+  float* ag_buf = nullptr;
+  hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
   int payload_bf16 = 0;
   void* grad_bf16 = nullptr;   // flat bf16 payload arena (allocated when the bf16 payload is first selected)
@@ -166,6 +173,10 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_done)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_upd)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_gath)
+    if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
   if (p->grad_bf16) (void)hipFree(p->grad_bf16);
@@ -241,6 +252,12 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
       p->d_flat[i].grad_splits = 1;
     }
   }
+  return RV_OK;
+}
+
+int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
+  RV_REQUIRE(p && p->bound && out10, RV_ERR_STATE, "rv_plan_descs: plan not bound");
+  for (int i = 0; i < 10; ++i) out10[i] = from_flat ? p->d_flat[i] : p->d_slab[i];
   return RV_OK;
 }
 
@@ -472,6 +489,105 @@ int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int w
   return RV_OK;
 }
 
+static long shard_count(long lo, long hi, int world) { return ((hi - lo + world - 1) / world + 3) / 4 * 4; }
+
+long rv_plan_shard_count(const rv_plan* p, int bucket, int world) {
+  if (!p || world < 1 || bucket < 0 || bucket > 1) return 0;
+  return bucket == 0 ? shard_count(p->off[8], p->n_params, world) : shard_count(0, p->off[8], world);
+}
+
+int rv_plan_attach_comm_sharded(rv_plan* p, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
+                                int world, int rank, float* rs_buf, float* ag_buf) {
+  RV_REQUIRE(p && reduce_scatter && all_gather && comm && rs_buf && ag_buf, RV_ERR_NULL, "rv_plan_attach_comm_sharded: null argument");
+  RV_REQUIRE(world >= 1 && rank >= 0 && rank < world, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: rank %d of %d", rank, world);
+  RV_REQUIRE((((uintptr_t)rs_buf | (uintptr_t)ag_buf) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: buffers must be 16-byte aligned");
+  if (!p->comm_stream) {
+    int lo = 0, hi = 0;
+    RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RV_HIP(hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, hi));
+    for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (!p->ev_upd[0]) {
+    for (hipEvent_t& e : p->ev_upd) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : p->ev_gath) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  p->reduce_scatter = reduce_scatter; p->all_gather = all_gather; p->comm = comm;
+  p->world = world; p->rank = rank; p->rs_buf = rs_buf; p->ag_buf = ag_buf;
+  return RV_OK;
+}
+
+// One sharded data-parallel step (see rv_plan_attach_comm_sharded in the header).  Collectives run on the internal
+// stream in the order RS(fc4) RS(rest) AG(fc4) AG(rest); it forks from and joins into the caller's stream only.
+static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
+                            unsigned long long seed, void* stream) {
+  const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
+  void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
+  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
+  float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
+  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const float* eps_used = eps ? eps : (float*)p->ws("eps");
+  hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
+  const float scale = 1.0f / (float)p->world;
+  const long lo_b[2] = {p->off[8], 0}, hi_b[2] = {p->n_params, p->off[8]};
+  const int t0_b[2] = {8, 0}, nt_b[2] = {2, 8};
+  const long cnt[2] = {shard_count(lo_b[0], hi_b[0], p->world), shard_count(lo_b[1], hi_b[1], p->world)};
+  float* rs[2] = {p->rs_buf, p->rs_buf + cnt[0]};
+  float* ag[2] = {p->ag_buf, p->ag_buf + (long)p->world * cnt[0]};
+  int rc;
+#define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+  // Every cross-stream edge costs ~6 us on this runtime, so the step has five: a fork per gradient bucket, ONE
+  // join for both reduce-scatters, one fork for both all-gathers and one join for them.
+  auto scatter_bucket = [&](int b) -> int {
+    RV_TRY(rv_grad_finalize(p->d_slab + t0_b[b], nt_b[b], p->b.grad, stream));
+    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
+    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
+    const int nrc = p->reduce_scatter(p->b.grad + lo_b[b], rs[b], (size_t)cnt[b], /*ncclFloat32*/ 7, /*ncclSum*/ 0, p->comm, (void*)sc);
+    if (nrc != 0) return rv_fail(RV_ERR_HIP, "reduce-scatter of gradient bucket %d failed (collective library code %d)", b, nrc);
+    return RV_OK;
+  };
+  // this rank's shard of a bucket: [own, own + n) with n clipped to the bucket's end
+  auto own_of = [&](int b, long* own, long* n) {
+    *own = lo_b[b] + (long)p->rank * cnt[b];
+    *n = hi_b[b] - *own;
+    if (*n > cnt[b]) *n = cnt[b];
+    if (*n < 0) *n = 0;
+  };
+  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
+  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                               (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+  RV_TRY(scatter_bucket(0));   // fc4's 8.4 MB travel behind the rest of backward
+  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
+                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
+  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
+  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
+                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
+  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+  RV_TRY(scatter_bucket(1));
+  RV_HIP(hipEventRecord(p->ev_done[1], sc));           // both reduce-scatters (the collective stream is in order)
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
+  for (int b = 0; b < 2; ++b) {
+    long own, n;
+    own_of(b, &own, &n);
+    RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, stream));
+  }
+  RV_HIP(hipEventRecord(p->ev_upd[0], s0));
+  RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
+  for (int b = 0; b < 2; ++b) {
+    long own, n;
+    own_of(b, &own, &n);
+    const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)sc);
+    if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
+  }
+  RV_HIP(hipEventRecord(p->ev_gath[0], sc));
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
+  for (int b = 0; b < 2; ++b)
+    RV_TRY(rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, stream));
+#undef RV_TRY
+  return RV_OK;
+}
+
 int rv_plan_set_ddp_payload(rv_plan* p, int bf16) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_ddp_payload: null plan");
   if (bf16 && !p->grad_bf16) RV_HIP(hipMalloc(&p->grad_bf16, (size_t)p->n_params * 2));
@@ -482,13 +598,14 @@ int rv_plan_set_ddp_payload(rv_plan* p, int bf16) {
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                      unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
-  RV_REQUIRE(p->allreduce && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
+  RV_REQUIRE((p->allreduce || p->reduce_scatter) && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
   // the collective stream must fork from / join into the caller's stream only: a second helper stream in the same
   // capture has made hipStreamEndCapture recurse without end (unrecoverable), so the two modes exclude each other
   RV_REQUIRE(p->concurrent == 0, RV_ERR_STATE, "rv_plan_step_ddp: not available while rv_plan_set_concurrency(%d) is set",
              p->concurrent);
+  if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
   void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");

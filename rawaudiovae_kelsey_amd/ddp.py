@@ -58,6 +58,66 @@ class GradSync:
         return 1.0 / self.world
 
 
+ARENA_SLACK = 1024   # elements every flat arena extends past n_params (shards of 4-element multiples can overhang)
+
+
+class ShardPlan:
+    """Who owns what in the sharded optimizer (`rv_plan_step_ddp`, sharded mode; include/rawvae_hip.h).
+
+    The flat arena is exchanged in two buckets, in the order backward completes them: bucket 0 = fc4
+    ([offset of fc4.weight, n_params)), bucket 1 = everything before it.  A bucket is cut into `world` equal
+    shards of `count` elements, count = ceil(len / world) rounded up to a multiple of 4 (16-byte vector
+    accesses), so the last shards can be ragged or empty and the last one can overhang its bucket: collectives
+    move `count` elements per rank, the optimizer touches only [own_lo, own_hi)."""
+
+    def __init__(self, fc4_offset, n_params, world):
+        self.world = int(world)
+        self.buckets = [(int(fc4_offset), int(n_params)), (0, int(fc4_offset))]
+        self.counts = [self.shard_count(lo, hi, self.world) for lo, hi in self.buckets]
+        if self.world * 4 > ARENA_SLACK:
+            raise ValueError("world %d needs more arena slack than %d elements" % (world, ARENA_SLACK))
+
+    @staticmethod
+    def shard_count(lo, hi, world):
+        return ((hi - lo + world - 1) // world + 3) // 4 * 4
+
+    def own(self, bucket, rank):
+        """(lo, hi) of rank's shard of `bucket`, clipped to the bucket (hi == lo: empty)."""
+        lo, hi = self.buckets[bucket]
+        a = lo + rank * self.counts[bucket]
+        return min(a, hi), min(a + self.counts[bucket], hi)
+
+    @property
+    def rs_elems(self):
+        return sum(self.counts)
+
+    @property
+    def ag_elems(self):
+        return self.world * sum(self.counts)
+
+    def gather_offset(self, bucket):
+        """Start of `bucket`'s gathered parameters in the all-gather buffer."""
+        return 0 if bucket == 0 else self.world * self.counts[0]
+
+
+def gather_sharded_moments(engine, group=None):
+    """Sharded optimizer: exp_avg / exp_avg_sq are current on their owner rank only.  Before a checkpoint every
+    rank calls this; afterwards each rank's arenas hold the complete, current moments (an all-gather of the
+    shards over torch.distributed -- any backend; a few MB, checkpoint time only)."""
+    sp = getattr(engine, "shard_plan", None)
+    if sp is None or sp.world == 1 or not dist.is_initialized():
+        return
+    rank = dist.get_rank(group)
+    for arena in (engine._arena_full[1], engine._arena_full[2]):
+        for b in (0, 1):
+            lo, hi = sp.buckets[b]
+            cnt = sp.counts[b]
+            mine = arena[lo + rank * cnt: lo + (rank + 1) * cnt].clone()
+            parts = [torch.empty_like(mine) for _ in range(sp.world)]
+            dist.all_gather(parts, mine, group=group)
+            arena[lo:hi].copy_(torch.cat(parts)[:hi - lo])
+
+
 def engine_buckets(engine):
     """Buckets in the order their gradients become available in backward:
     fc4 (after the paired fc4 backward), fc1 (end of the dependent chain), then fc21/fc22/fc3."""
@@ -201,6 +261,10 @@ class RcclComm:
         self._check(self._lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
         self.handle = comm
         self.allreduce_addr = C.cast(self._lib.ncclAllReduce, C.c_void_p)
+        self.reduce_scatter_addr = C.cast(self._lib.ncclReduceScatter, C.c_void_p)
+        self.all_gather_addr = C.cast(self._lib.ncclAllGather, C.c_void_p)
+        self._lib.ncclReduceScatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         self._lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
     def _check(self, rc, what):
@@ -221,6 +285,18 @@ class RcclComm:
         want = self.world * (self.world + 1) / 2.0
         if not bool((t == want).all()):
             raise RuntimeError("RCCL self-test: expected %g everywhere, got [%g, %g]" % (want, t.min().item(), t.max().item()))
+        # the sharded optimizer's two collectives: reduce-scatter (rank r receives the sum of slice r) and all-gather
+        n = 1 << 12
+        src = torch.arange(self.world * n, dtype=torch.float32, device=device) + float(self.rank)
+        out = torch.empty(n, dtype=torch.float32, device=device)
+        s = torch.cuda.current_stream().cuda_stream or None
+        self._check(self._lib.ncclReduceScatter(src.data_ptr(), out.data_ptr(), n, 7, 0, self.handle, s), "ncclReduceScatter")
+        gat = torch.empty(self.world * n, dtype=torch.float32, device=device)
+        self._check(self._lib.ncclAllGather(out.data_ptr(), gat.data_ptr(), n, 7, self.handle, s), "ncclAllGather")
+        torch.cuda.synchronize(device)
+        base = torch.arange(self.world * n, dtype=torch.float32, device=device) * self.world + want - self.world
+        if not bool((gat == base).all()):
+            raise RuntimeError("RCCL self-test: reduce-scatter + all-gather returned wrong sums")
 
     def destroy(self):
         if getattr(self, "handle", None):
@@ -233,14 +309,20 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32"):
+    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32", sharded=False):
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
-        engine.attach_comm(comm)
+        self.sharded = bool(sharded)
+        engine.attach_comm(comm, sharded=self.sharded)
         self._graphs = {}
-        self.set_payload(payload)
+        if not self.sharded:
+            self.set_payload(payload)
+        else:
+            self.payload = "fp32"
 
     def set_payload(self, payload):
         """"fp32" or "bf16" gradient exchange (captured graphs are dropped: the payload is baked in)."""
+        if self.sharded:
+            raise RuntimeError("the sharded optimizer exchanges fp32 gradients and parameters only")
         self.engine.set_ddp_payload(payload)
         self.payload = payload
         self._graphs = {}

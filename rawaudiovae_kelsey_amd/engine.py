@@ -67,10 +67,12 @@ class TrainEngine:
             self.step_counter, self.loss_ring, self.ring = share.step_counter, share.loss_ring, share.ring
             self._shared = share._shared
         else:
-            self.param = torch.zeros(o, **f32)
-            self.exp_avg = torch.zeros(o, **f32)
-            self.exp_avg_sq = torch.zeros(o, **f32)
-            self.grad = torch.zeros(o, **f32) if grad_arena else None
+            # every arena extends ARENA_SLACK elements past n_params: the sharded data-parallel optimizer cuts
+            # buckets into equal shards of 4-element multiples, so a collective's last shard can overhang
+            from .ddp import ARENA_SLACK
+            self._arena_full = [torch.zeros(o + ARENA_SLACK, **f32) for _ in range(4 if grad_arena else 3)]
+            self.param, self.exp_avg, self.exp_avg_sq = (t[:o] for t in self._arena_full[:3])
+            self.grad = self._arena_full[3][:o] if grad_arena else None
             self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
             self.loss_ring = torch.zeros(self.ring, 4, **f32)
             self._shared = {"version": 0, "drained": 0}   # parameter version, losses already drained
@@ -194,10 +196,24 @@ class TrainEngine:
             self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
             _ops_invalidate()
 
-    def attach_comm(self, comm):
-        """Data-parallel mode with the collective issued by the library itself: `comm` is a
-        `ddp.RcclComm` (RCCL communicator + the address of its ncclAllReduce)."""
-        lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
+    def attach_comm(self, comm, sharded=False):
+        """Data-parallel mode with the collectives issued by the library itself: `comm` is a `ddp.RcclComm`
+        (RCCL communicator + the addresses of its collectives).  sharded: optimizer state and update sharded
+        over the ranks (reduce-scatter gradients, Adam on the own shard, all-gather parameters) instead of an
+        all-reduce followed by the full update on every rank."""
+        if sharded:
+            from .ddp import ShardPlan
+            self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
+            for b in (0, 1):
+                if lib().rv_plan_shard_count(self._plan, b, comm.world) != self.shard_plan.counts[b]:
+                    raise _lib.RvError("shard bookkeeping of ddp.ShardPlan and the library disagree")
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._rs_buf = torch.zeros(self.shard_plan.rs_elems, **f32)
+            self._ag_buf = torch.zeros(self.shard_plan.ag_elems, **f32)
+            lib().rv_plan_attach_comm_sharded(self._plan, comm.reduce_scatter_addr, comm.all_gather_addr, comm.handle,
+                                              comm.world, comm.rank, ptr(self._rs_buf), ptr(self._ag_buf))
+        else:
+            lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
         self._comm = comm   # keep the communicator alive as long as the plan can use it
 
     def set_ddp_payload(self, payload):
@@ -224,6 +240,12 @@ class TrainEngine:
         self._shared["version"] += 1
         self._shadow_version = self._shared["version"]
         _ops_invalidate()
+
+    def plan_descs(self, from_flat=False):
+        """The plan's ten `ParamDesc`s (gradient slabs or the flat arena, shadows to refresh)."""
+        arr = (_lib.ParamDesc * 10)()
+        lib().rv_plan_descs(self._plan, arr, int(bool(from_flat)))
+        return list(arr)
 
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""

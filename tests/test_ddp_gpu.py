@@ -98,9 +98,87 @@ assert not torch.equal(bf.param, ref.param)
 for a, b in zip(bf.losses(4), ref.losses(4)):
     assert abs(a - b) <= 1e-4 * abs(b)
 bf.set_ddp_payload("fp32")
+# sharded optimizer (reduce-scatter / Adam on the own shard / all-gather / rebuild parameters and shadows) with the
+# one-rank communicator: the shard is the whole bucket and both collectives are copies, so eager and graph-replayed
+# it must equal the local fused step bit for bit -- parameters, both moments, and the loss ring
+ref = fresh()
+with torch.cuda.stream(st):
+    for _ in range(5):
+        ref.step(x, stream=st)
+st.synchronize()
+sh = fresh(); sh.attach_comm(comm, sharded=True)
+with torch.cuda.stream(st):
+    for _ in range(5):
+        sh.step_ddp(x, stream=st)
+st.synchronize()
+assert torch.equal(sh.param, ref.param) and torch.equal(sh.exp_avg, ref.exp_avg) and torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
+assert sh.losses(5) == ref.losses(5)
+for name in ("W1b", "Whb", "W3b", "W4b", "b1p", "b4p"):
+    dt = torch.bfloat16 if name.startswith("W") else torch.float32
+    a, b = sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))
+    assert torch.equal(a, b), name
+shg = fresh()
+run = ddp.NativeDdpRunner(shg, comm, st, use_graph=True, sharded=True)
+with torch.cuda.stream(st):
+    for _ in range(5):
+        run.step(x)
+st.synchronize()
+assert torch.equal(shg.param, ref.param), "graph-replayed sharded step differs"
 comm.destroy()
 dist.destroy_process_group()
 print("NATIVE_OK")
 ''' % REPO
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0 and "NATIVE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_adam_kernels_equal_full_adam(world):
+    """rv_adam_flat on every rank's shard (ragged, overhanging: ddp.ShardPlan) + rv_params_from_flat, all ranks
+    emulated one after the other on this GPU, against rv_adam_multi over the whole arena: bit-equal parameters,
+    moments, bf16 shadows and padded bias shadows (C2-shaped and an odd-sized model)."""
+    import numpy as np
+    from oracle.inputs import make_frames, make_params
+    from rawaudiovae_kelsey_amd import engine as E
+    from rawaudiovae_kelsey_amd._lib import lib, ptr, stream_ptr
+    from rawaudiovae_kelsey_amd.ddp import ARENA_SLACK, ShardPlan
+    L_ = lib()
+    for (S, H, Ld, B) in ((256, 512, 16, 128), (100, 200, 5, 37)):
+        x = torch.from_numpy(make_frames(B, S, 1)).cuda()
+        ph = E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B
+        ref = E.TrainEngine(S, H, Ld, B, seed=3); ref.load_params(make_params(S, H, Ld, 0))
+        sh = E.TrainEngine(S, H, Ld, B, seed=3); sh.load_params(make_params(S, H, Ld, 0))
+        sp = ShardPlan(sh.offsets["fc4.weight"], sh.n_params, world)
+        for step in range(2):
+            ref.step(x)                      # forward, backward, Adam over the slabs
+            sh.step(x, phases=ph)            # forward, backward, gradients summed into the flat arena
+            gathered = torch.zeros(sp.ag_elems, device="cuda")
+            full_grad = sh._arena_full[3]
+            for b in (0, 1):
+                lo, hi = sp.buckets[b]
+                cnt = sp.counts[b]
+                for r in range(world):
+                    a, e = sp.own(b, r)
+                    shard = full_grad[lo + r * cnt: lo + (r + 1) * cnt].clone()   # reduce-scatter output of rank r
+                    L_.rv_adam_flat(ptr(sh.param), ptr(sh.exp_avg), ptr(sh.exp_avg_sq), ptr(shard), a, e - a, sh.lr, 1.0,
+                                    ptr(sh.step_counter), stream_ptr())
+                    go = sp.gather_offset(b) + r * cnt
+                    gathered[go:go + cnt] = sh._arena_full[0][lo + r * cnt: lo + (r + 1) * cnt]   # all-gather
+            torch.cuda.synchronize()
+            sh.param.zero_()                 # the parameters must come back from the gathered buffer alone
+            from rawaudiovae_kelsey_amd import _lib as P
+            descs = sh.plan_descs()
+            for b, (t0, nt) in ((0, (8, 2)), (1, (0, 8))):
+                arr = (P.ParamDesc * nt)(*descs[t0:t0 + nt])
+                L_.rv_params_from_flat(arr, nt, gathered[sp.gather_offset(b):].data_ptr(), sp.buckets[b][0], ptr(sh.param),
+                                       stream_ptr())
+            torch.cuda.synchronize()
+        diag = {k: (float((sh.view(sh.exp_avg, k) - ref.view(ref.exp_avg, k)).abs().max()),
+                    float((sh.view(sh.param, k) - ref.view(ref.param, k)).abs().max())) for k in E.PARAM_NAMES}
+        diag = str({k: v for k, v in diag.items() if v != (0.0, 0.0)}) + " world %d shape %r" % (world, (S, H, Ld, B))
+        assert torch.equal(sh.exp_avg, ref.exp_avg), diag
+        assert torch.equal(sh.param, ref.param), diag
+        assert torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
+        for name, dt in (("W1b", torch.bfloat16), ("Whb", torch.bfloat16), ("W3b", torch.bfloat16),
+                         ("W4b", torch.bfloat16), ("b1p", torch.float32), ("bhp", torch.float32), ("b4p", torch.float32)):
+            assert torch.equal(sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))), name

@@ -73,6 +73,7 @@ class DataParallel:
         self.active = self.world > 1
         self.device = device
         self.comm = None
+        self.sharded = False
         if self.active:
             backend = os.environ.get("RV_DIST_BACKEND", "nccl")
             if backend == "nccl":
@@ -118,11 +119,22 @@ class DataParallel:
         if not self.active:
             return engine.step
         if self.comm is not None:
-            engine.attach_comm(self.comm)
+            # RV_DDP_MODE=sharded (default): reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
+            # all-gather the parameters; =allreduce: all-reduce and the full update on every rank
+            self.sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
+            engine.attach_comm(self.comm, sharded=self.sharded)
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
         sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
         return lambda x: ddp.ddp_step(engine, sync, x)
+
+    def sync_optimizer_state(self, engine):
+        """Before a checkpoint (every rank calls it): with the sharded optimizer the Adam moments live on their
+        owner ranks; gather them so that rank 0's optimizer_state_dict() is complete."""
+        if self.active and self.sharded:
+            from rawaudiovae_kelsey_amd import ddp
+            torch.cuda.synchronize(self.device)
+            ddp.gather_sharded_moments(engine)
 
     def mean(self, value):
         """Mean over ranks of a host scalar."""
@@ -363,6 +375,8 @@ def main(argv=None):
             for name, param in model.named_parameters():
                 writer.add_histogram(name, param, epoch)
 
+        if epoch % checkpoint_interval == 0 and epoch != 0:
+            dp.sync_optimizer_state(engine)      # every rank: the sharded optimizer's moments travel to rank 0
         if epoch % checkpoint_interval == 0 and epoch != 0 and dp.main:
             print('Checkpoint - Epoch {}'.format(epoch))
             if generate_test:
@@ -379,6 +393,7 @@ def main(argv=None):
         final_loss = train_loss
 
     dp.check_replicas(engine)
+    dp.sync_optimizer_state(engine)
     if dp.main:
         print('Last Checkpoint - Epoch {}'.format(epoch))
         if generate_test:
