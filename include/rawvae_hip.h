@@ -200,6 +200,10 @@ int rv_reparameterize_bwd(const float* dz, const float* eps, const float* logvar
 int rv_tanh_bwd_pack(const float* d_recon, const float* recon, long B, long S, void* dP4_bf16,
                      long Bp, long Sp, void* stream);
 
+/* fp32 elementwise steps of the strict-fp32 training mode (rawaudiovae_kelsey_amd/strict.py; autograd of
+ * model.py:20,29,30): op 0: out = a*(1-b*b) (tanh backward), 1: out = b>0 ? a : 0 (ReLU backward), 2: out = a+b. */
+int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* stream);
+
 /* Partial column sums (bias gradients): out[rb][c] = sum of rows [256 rb, 256 rb+256) of
  * column c; src is fp32 or bf16 [rows, cols] with leading dim ld.  ceil(rows/256) slabs,
  * summed by rv_grad_finalize / rv_adam_multi. */
@@ -376,6 +380,23 @@ int rv_plan_refresh_shadows(rv_plan*, void* stream);
 int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* recon_out,
                  float kl_beta, float lr, float grad_scale, int adam_from_flat,
                  unsigned long long seed, void* stream);
+/* rv_plan_step whose batch is B hop-strided frames of a waveform resident in HBM (AudioDataset semantics,
+ * rawvae/dataset.py:99-121; frame i = audio[f*hop : f*hop + S], f = frame_index ? frame_index[i] : first_frame + i,
+ * samples past n_samples read as 0): fc1's bf16 operand is cast straight from the waveform
+ * (rv_gather_cast_frames) and fc4's loss epilogue reads its fp32 target there too
+ * (rv_decode_out_loss_fwd_frames), so no framed copy of the batch is ever written. */
+int rv_plan_step_frames(rv_plan*, int phases, const float* audio, long n_samples, const long long* frame_index,
+                        long first_frame, long hop, const float* eps, float* recon_out, float kl_beta, float lr,
+                        float grad_scale, int adam_from_flat, unsigned long long seed, void* stream);
+int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
+                          long n_frames, long S, long hop, void* dst_bf16, long rows_p, long cols_p, long ld_dst,
+                          void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part, int n_amax,
+                          long long* step_counter, void* stream);
+int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4, const float* dq,
+                                  long Bp, long Sp, long Hp, long B, long S, const float* audio, long n_samples,
+                                  const long long* frame_index, long first_frame, long hop, float* recon, long ld_recon,
+                                  void* dP4_bf16, long ld_dp4, float* mse_partial, float* db4_partial, void* stream);
+
 /* ---- data-parallel step with the collective driven from here (no reference code:
  * the reference is single-process).  `allreduce` is the collective library's in-place-capable
  * all-reduce with RCCL's ncclAllReduce signature -- (sendbuf, recvbuf, count, dtype, op, comm, stream),

@@ -69,6 +69,7 @@ _SIGS = {
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_tanh_bwd_pack": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p]),
     "rv_colsum_partial": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
+    "rv_ew_f32": (c_int, [c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_scale_by": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                               c_int, c_void_p, c_long, c_void_p]),
@@ -113,6 +114,13 @@ _SIGS = {
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
+    "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,
+                                    c_float, c_float, c_int, c_u64, c_void_p]),
+    "rv_gather_cast_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_long, c_long,
+                                      c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rv_decode_out_loss_fwd_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
+                                              c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long,
+                                              c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_plan_attach_comm": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "rv_plan_shard_count": (c_long, [c_void_p, c_int, c_int]),
     "rv_plan_attach_comm_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

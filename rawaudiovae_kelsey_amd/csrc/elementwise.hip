@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
                                                        long long* step_counter,
                                                        unsigned char* __restrict__ dst_fp8, long ld_fp8,
                                                        float* fp8_state, const float* __restrict__ fp8_scale,
-                                                       const float* __restrict__ amax_part, int n_amax) {
+                                                       const float* __restrict__ amax_part, int n_amax,
+                                                       const long long* __restrict__ frame_idx, long first_frame,
+                                                       long hop, long n_samples) {
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     if (step_counter && threadIdx.x == 0) *step_counter += 1;
     if (fp8_state) fp8_latch(fp8_state, amax_part, n_amax, threadIdx.x);
@@ -141,7 +143,22 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (r < rows) {
+    if (r < rows && hop) {
+      // row r is frame f of the resident waveform `src` (AudioDataset.__getitem__, dataset.py:108-118)
+      const long start = (frame_idx ? (long)frame_idx[r] : first_frame + r) * hop + c;
+      if ((hop & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && c + 8 <= cols && start >= 0 && start + 8 <= n_samples) {
+        const float4 a = *reinterpret_cast<const float4*>(src + start);
+        const float4 b = *reinterpret_cast<const float4*>(src + start + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long a_ = start + j;
+          if (c + j < cols && a_ >= 0 && a_ < n_samples) v[j] = src[a_];
+        }
+      }
+    } else if (r < rows) {
       const float* s = src + r * ld_src + c;
       if (vec_ok && c + 8 <= cols) {
         const float4 a = *reinterpret_cast<const float4*>(s);
@@ -471,6 +488,19 @@ k_reparameterize_bwd(const float* __restrict__ dz, const float* __restrict__ eps
   }
 }
 
+// fp32 elementwise steps of the strict-fp32 training mode (strict.py): the activations' backward and sums,
+// exactly as autograd computes them for model.py:20,29,30 (threshold_backward, tanh_backward, add).
+//   op 0: out = a * (1 - b*b)      d(pre-tanh) from d(recon), recon
+//   op 1: out = b > 0 ? a : 0      ReLU backward from d(out), out
+//   op 2: out = a + b
+__global__ void __launch_bounds__(256)
+k_ew_f32(int op, const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = a[i], y = b[i];
+    out[i] = op == 0 ? x * (1.f - y * y) : op == 1 ? (y > 0.f ? x : 0.f) : x + y;
+  }
+}
+
 // out = a * scalar[0] (upstream gradient of the 0-dim loss applied to a saved gradient).
 __global__ void __launch_bounds__(256)
 k_scale_by(const float* __restrict__ a, const float* __restrict__ scalar, long n, float* __restrict__ out) {
@@ -582,7 +612,8 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
   const long total = rows_p * (cols_p / 8);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
-                     (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
+                     (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                     (const long long*)nullptr, 0L, 0L, 0L);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -600,7 +631,25 @@ int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, voi
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state /* [0] = scale of x */,
-                     amax_part, amax_part ? n_amax : 0);
+                     amax_part, amax_part ? n_amax : 0, (const long long*)nullptr, 0L, 0L, 0L);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame, long n_frames,
+                          long S, long hop, void* dst_bf16, long rows_p, long cols_p, long ld_dst, void* dst_fp8, long ld_fp8,
+                          float* fp8_state, const float* amax_part, int n_amax, long long* step_counter, void* stream) {
+  RV_REQUIRE(audio && dst_bf16, RV_ERR_NULL, "rv_gather_cast_frames: null pointer");
+  RV_REQUIRE(n_samples > 0 && n_frames >= 0 && S > 0 && hop > 0 && n_frames <= rows_p && S <= cols_p && cols_p % 8 == 0 &&
+                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst_bf16 & 15) == 0,
+             RV_ERR_SHAPE, "rv_gather_cast_frames: bad extents %ld frames of %ld -> %ld x %ld", n_frames, S, rows_p, cols_p);
+  RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_gather_cast_frames: the fp8 output needs the state block and 8-byte aligned rows");
+  const long total = rows_p * (cols_p / 8);
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     audio, n_frames, S, 0L, (bf16_t*)dst_bf16, rows_p, cols_p, ld_dst, step_counter,
+                     (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state, amax_part,
+                     amax_part ? n_amax : 0, frame_index, first_frame, hop, n_samples);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -614,7 +663,8 @@ int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* d
   const long total = rows_p * (cols_p / 8);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)nullptr, rows_p, cols_p, ld_dst, (long long*)nullptr,
-                     (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0);
+                     (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0,
+                     (const long long*)nullptr, 0L, 0L, 0L);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -727,6 +777,15 @@ int rv_reparameterize_bwd(const float* dz, const float* eps, const float* logvar
   if (n == 0) return RV_OK;
   hipLaunchKernelGGL(k_reparameterize_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dz, eps,
                      logvar, n, dmu, dlv);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* stream) {
+  RV_REQUIRE(a && b && out, RV_ERR_NULL, "rv_ew_f32: null pointer");
+  RV_REQUIRE(op >= 0 && op <= 2, RV_ERR_UNSUPPORTED, "rv_ew_f32: op %d", op);
+  if (n <= 0) return RV_OK;
+  hipLaunchKernelGGL(k_ew_f32, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, n, out);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -54,6 +54,11 @@ struct GemmArgs {
   long ld_mask;
   const float* x;  // EPI_TANH_LOSS target frames, exact [M_valid, N_valid]
   long ld_x;
+  // ... or, when x_hop != 0, hop-strided frames of a waveform: `x` is the waveform (x_nsamples samples, zero past
+  // them) and row r is x[f*x_hop : f*x_hop + N_valid] with f = x_idx ? x_idx[r] : x_first + r (AudioDataset,
+  // rawvae/dataset.py:108-118) -- the target is read where the audio lives, no framed copy of the batch exists
+  const long long* x_idx;
+  long x_first, x_hop, x_nsamples;
   float* recon;  // optional exact-shape fp32 reconstruction
   long ld_recon;
   float* colsum;    // [grid.y][grid.x*BN] per-row-tile column sums of the bf16 output
@@ -778,7 +783,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         for (int it = 0; it < CH; ++it) {
           const long r = rowi[it], col = coli[it];
           const long rc = r < p.M_valid ? r : p.M_valid - 1;
-          if (x_al && col + 8 <= p.N_valid) {
+          if (p.x_hop) {   // frame rc of the resident waveform
+            const long start = (p.x_idx ? (long)p.x_idx[rc] : p.x_first + rc) * p.x_hop + col;
+            if ((p.x_hop & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && col + 8 <= p.N_valid && start >= 0 &&
+                start + 8 <= p.x_nsamples) {
+              const f32x4 lo = *(const f32x4*)(p.x + start);
+              const f32x4 hi = *(const f32x4*)(p.x + start + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { xin[it][e] = lo[e]; xin[it][4 + e] = hi[e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const long a_ = start + e;
+                xin[it][e] = (col + e < p.N_valid && a_ >= 0 && a_ < p.x_nsamples) ? p.x[a_] : 0.f;
+              }
+            }
+          } else if (x_al && col + 8 <= p.N_valid) {
             const f32x4 lo = *(const f32x4*)(p.x + rc * p.ld_x + col);
             const f32x4 hi = *(const f32x4*)(p.x + rc * p.ld_x + col + 4);
 #pragma unroll

@@ -348,6 +348,29 @@ int rv_decode_out_loss_fwd(const void* h3, long ldh, const void* w4, long ldw, c
   return launch_auto<true, true, EPI_TANH_LOSS>(a, Bp, Sp, Hp, 1, (hipStream_t)stream);
 }
 
+// rv_decode_out_loss_fwd (bf16 or fp8 operands: h3/w4 fp8 when `dq` is given) with the target frames read from the
+// resident waveform: frame r = audio[f*hop : f*hop + S], f = frame_index ? frame_index[r] : first_frame + r.
+int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4, const float* dq,
+                                  long Bp, long Sp, long Hp, long B, long S, const float* audio, long n_samples,
+                                  const long long* frame_index, long first_frame, long hop, float* recon, long ld_recon,
+                                  void* dP4, long ld_dp4, float* mse_partial, float* db4_partial, void* stream) {
+  RV_REQUIRE(h3 && w4 && audio && dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd_frames: null operand");
+  RV_REQUIRE(B <= Bp && S <= Sp && hop > 0 && n_samples > 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_frames: bad extents");
+  GemmArgs a{};
+  a.M_valid = (int)B; a.N_valid = (int)S;
+  a.bias = b4; a.x = audio; a.ld_x = 0; a.x_idx = frame_index; a.x_first = first_frame; a.x_hop = hop; a.x_nsamples = n_samples;
+  a.recon = recon; a.ld_recon = ld_recon;
+  a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
+  a.scale = 2.0f / ((float)B * (float)S);
+  if (dq) {
+    RV_REQUIRE(Hp % 128 == 0 && ldh % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_frames: fp8 K and leading dims must be multiples of 128 / 16");
+    a.A = (const bf16_t*)h3; a.lda = ldh / 2; a.B = (const bf16_t*)w4; a.ldb = ldw / 2; a.k_tiles = (int)(Hp / 128); a.dq = dq;
+    return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
+  }
+  a.A = (const bf16_t*)h3; a.lda = ldh; a.B = (const bf16_t*)w4; a.ldb = ldw; a.k_tiles = (int)(Hp / 64);
+  return launch_auto<true, true, EPI_TANH_LOSS>(a, Bp, Sp, Hp, 1, (hipStream_t)stream);
+}
+
 int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp, long Np, long Kp,
                     const void* mask, long ldmask, void* dx, long lddx, float* colsum,
                     float* dx32, long lddx32, int splits, void* stream) {

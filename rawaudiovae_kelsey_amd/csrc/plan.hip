@@ -65,6 +65,9 @@ struct rv_plan {
   float* ag_buf = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
+  // frame source of the step in flight (rv_plan_step_frames): `x` is then the resident waveform
+  const long long* fr_idx = nullptr;
+  long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
   int payload_bf16 = 0;
   void* grad_bf16 = nullptr;   // flat bf16 payload arena (allocated when the bf16 payload is first selected)
 
@@ -304,11 +307,24 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (phases & RV_PHASE_FWD) {
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
     float* f8 = (float*)p->ws("fp8_state");
+    int n_amax = 0;
     if (p->fp8) {
       int bm3 = 128, bn3 = 128;
       rv_gemm_tile(Bp, Hp, 1, &bm3, &bn3);
-      const int n_amax = (int)((Bp / bm3) * (Hp / bn3));
+      n_amax = (int)((Bp / bm3) * (Hp / bn3));
       RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 4096 fc3 output tiles (got %d)", n_amax);
+    }
+    if (p->fr_hop) {
+      // frames come straight from the resident waveform: waveform -> bf16 (and fp8) operand in one kernel
+      RV_TRY(rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb, Bp, Sp, Sp,
+                                   p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
+                                   p->b.step_counter, stream));
+      if (p->fp8)
+        RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                                 h1, Hp, stream));
+      else
+        RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+    } else if (p->fp8) {
       RV_TRY(rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
                                  p->b.step_counter, stream));
       RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
@@ -321,7 +337,17 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                              mulv_slabs, L2p, stream));
     RV_TRY(rv_reparam_fwd(mulv_slabs, p->s_heads, Bp, Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z,
                           kl_part, stream));
-    if (p->fp8) {
+    if (p->fr_hop) {
+      if (p->fp8)
+        RV_TRY(rv_linear_fwd_q8(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+      else
+        RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
+      RV_TRY(rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
+                                           (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
+                                           p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
+                                           mse_part, (float*)p->ws("db4p"), stream));
+    } else if (p->fp8) {
       RV_TRY(rv_linear_fwd_q8(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                               p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
@@ -470,6 +496,17 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   }
 #undef RV_TRY
   return RV_OK;
+}
+
+int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, long n_samples, const long long* frame_index,
+                        long first_frame, long hop, const float* eps, float* recon_out, float kl_beta, float lr,
+                        float grad_scale, int adam_from_flat, unsigned long long seed, void* stream) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_frames: plan not bound");
+  RV_REQUIRE(audio && n_samples > 0 && hop > 0, RV_ERR_SHAPE, "rv_plan_step_frames: bad waveform / hop");
+  p->fr_idx = frame_index; p->fr_first = first_frame; p->fr_hop = hop; p->fr_nsamples = n_samples;
+  const int rc = rv_plan_step(p, phases, audio, eps, recon_out, kl_beta, lr, grad_scale, adam_from_flat, seed, stream);
+  p->fr_idx = nullptr; p->fr_first = 0; p->fr_hop = 0; p->fr_nsamples = 0;
+  return rc;
 }
 
 // ------------------------------------------------------------ data-parallel step

@@ -130,6 +130,17 @@ class DeviceAudio:
             yield self.gather(perm[lo:lo + batch_size])
 
 
+    def index_batches(self, batch_size, shuffle=True, generator=None):
+        """One epoch as device int64 index tensors (what `batches` gathers): for `TrainEngine.step_frames`, which
+        reads the frames where the waveform lives instead of from a gathered copy."""
+        n = len(self)
+        if shuffle:
+            perm = torch.randperm(n, generator=generator).to(self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        for lo in range(0, n, batch_size):
+            yield perm[lo:lo + batch_size].contiguous()
+
     def sharded_batches(self, batch_size, rank, world, shuffle=True, generator=None):
         """One data-parallel epoch.  The epoch's permutation (the same `generator` state on every rank) is
         cut into global batches of world * batch_size frames and rank r takes the r-th slice of each; the

@@ -196,6 +196,29 @@ class TrainEngine:
             self._shadow_version = self._shared["version"]   # Adam refreshed this engine's shadows
             _ops_invalidate()
 
+    def step_frames(self, audio, index=None, first_frame=0, eps=None, recon_out=None, phases=PHASE_ALL_LOCAL,
+                    grad_scale=1.0, adam_from_flat=False, stream=None):
+        """One step on B hop-strided frames of a `data.DeviceAudio` (waveform resident in HBM): `index` is an
+        int64 device tensor of B frame numbers (one slice of the epoch's shuffle) or None for the B consecutive
+        frames from `first_frame`.  No framed copy of the batch is made (`rv_plan_step_frames`)."""
+        if audio.segment_length != self.S:
+            raise _lib.RvError("step_frames: dataset frames are %d samples, the engine's %d" % (audio.segment_length, self.S))
+        if index is not None and (index.dtype != torch.int64 or not index.is_contiguous() or index.numel() != self.B):
+            raise _lib.RvError("step_frames: index must be a contiguous int64 tensor of %d frame numbers" % self.B)
+        if eps is not None and (eps.dtype != torch.float32 or not eps.is_contiguous() or eps.numel() != self.B * self.L):
+            raise _lib.RvError("step_frames: eps must be contiguous fp32 [B, L]")
+        if (phases & PHASE_FWD) and self._shadow_version != self._shared["version"]:
+            self.refresh_shadows(stream)
+        lib().rv_plan_step_frames(self._plan, int(phases), ptr(audio.audio), audio.padded, ptr(index), int(first_frame),
+                                  audio.hop_size, ptr(eps), ptr(recon_out), self.kl_beta, self.lr, float(grad_scale),
+                                  int(bool(adam_from_flat)), self.seed, stream_ptr(stream))
+        if phases & PHASE_FWD:
+            self.host_steps += 1
+        if phases & PHASE_ANY_ADAM:
+            self._shared["version"] += 1
+            self._shadow_version = self._shared["version"]
+            _ops_invalidate()
+
     def attach_comm(self, comm, sharded=False):
         """Data-parallel mode with the collectives issued by the library itself: `comm` is a `ddp.RcclComm`
         (RCCL communicator + the addresses of its collectives).  sharded: optimizer state and update sharded

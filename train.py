@@ -353,15 +353,20 @@ def main(argv=None):
                 train_loss += v
                 seen += 1
 
-        if dp.active:
-            epoch_batches = training_dataset.sharded_batches(full, dp.rank, dp.world, shuffle=True, generator=shuffle_gen)
-        else:
-            epoch_batches = training_dataset.batches(batch_size, shuffle=True, generator=shuffle_gen)
         with torch.cuda.stream(train_stream) if train_stream is not None else contextlib.nullcontext():
-            for i, batch in enumerate(epoch_batches):
-                (step_full if batch.shape[0] == full else step_tail)(batch)
-                if (i + 1) % ring == 0:
-                    drain()
+            if dp.active:
+                epoch_batches = training_dataset.sharded_batches(full, dp.rank, dp.world, shuffle=True, generator=shuffle_gen)
+                for i, batch in enumerate(epoch_batches):
+                    (step_full if batch.shape[0] == full else step_tail)(batch)
+                    if (i + 1) % ring == 0:
+                        drain()
+            else:
+                # one GPU: the step reads its frames where the waveform lives (rv_plan_step_frames): the epoch is a
+                # shuffled list of frame numbers, no framed copy of a batch is written
+                for i, idx in enumerate(training_dataset.index_batches(batch_size, shuffle=True, generator=shuffle_gen)):
+                    (engine if idx.numel() == full else tail_engine).step_frames(training_dataset, idx)
+                    if (i + 1) % ring == 0:
+                        drain()
             drain()
         if train_stream is not None:
             train_stream.synchronize()     # evaluation / checkpoints below read the parameters on the default stream
