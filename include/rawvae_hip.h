@@ -303,6 +303,19 @@ int rv_linear_fwd_q8(const void* x_bf16, long ldx, const void* w_bf16, long ldw,
                      long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
                      float* amax_part, void* stream);
 /* rv_linear_fwd / rv_decode_out_loss_fwd on fp8 operands. */
+/* The general forms: every optional output of a bias/ReLU forward GEMM (NULL = not wanted).  `maskbits`:
+ * [Mp][ld_maskbits >= Np/8] bytes, bit e of byte (r, c/8) = (y(r, c+e) > 0), the ReLU mask a later
+ * rv_linear_dgrad_wgrad_mb reads instead of the 16x larger bf16 activation. */
+int rv_linear_fwd_ex(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp, long Np,
+                     long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
+                     float* amax_part, void* maskbits, long ld_maskbits, void* stream);
+int rv_linear_fwd_fp8_ex(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
+                         long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* maskbits, long ld_maskbits,
+                         void* stream);
+/* rv_linear_dgrad_wgrad with the ReLU mask given as bits (x is still the weight gradient's operand). */
+int rv_linear_dgrad_wgrad_mb(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
+                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
+                             float* colsum_partial, float* dw_slabs, long lddw, int splits, void* stream);
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
 int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,

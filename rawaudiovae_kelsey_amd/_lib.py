@@ -60,6 +60,12 @@ _SIGS = {
                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rv_linear_fwd_q8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
                                  c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "rv_linear_fwd_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
+                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "rv_linear_fwd_fp8_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
+                                     c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "rv_linear_dgrad_wgrad_mb": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+                                         c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rv_linear_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
                                   c_void_p, c_long, c_void_p]),
     "rv_decode_out_loss_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
@@ -160,7 +166,10 @@ def _wrap(fn, name):
 class _Lib:
     def __init__(self, path):
         self._cdll = C.CDLL(path)
+        lax = os.environ.get("RV_LIB_LAX") == "1"   # A/B runs against an older experiment build (RV_LIB)
         for name, (res, args) in _SIGS.items():
+            if lax and not hasattr(self._cdll, name):
+                continue
             fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args

@@ -52,6 +52,13 @@ struct GemmArgs {
   const float* bias;  // [N] (padded), may be null
   const bf16_t* mask;
   long ld_mask;
+  // ReLU masks as bits: [rows][ld] bytes, bit e of byte (r, c/8) = (relu output (r, c + e) > 0).  A producing
+  // EPI_BIAS_ACT_BF16 GEMM writes them (out_maskbits); a consuming EPI_MASK_BF16 GEMM reads them instead of the
+  // 16x larger bf16 activation (`maskbits` wins over `mask`).
+  const unsigned char* maskbits;
+  long ld_maskbits;
+  unsigned char* out_maskbits;
+  long ld_out_maskbits;
   const float* x;  // EPI_TANH_LOSS target frames, exact [M_valid, N_valid]
   long ld_x;
   // ... or, when x_hop != 0, hop-strided frames of a waveform: `x` is the waveform (x_nsamples samples, zero past
@@ -72,7 +79,7 @@ struct GemmArgs {
   const float* q_scale;  // device scalar
   float* amax_part;      // [number of blocks]: max|out| of each block (delayed scaling: reduced by the next step's first kernel), or null
   int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
-                    // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
+                    // 2 = no epilogue at all, 4 = no main loop, 8 = half-width split-K slab stores; results are wrong whenever it is non-zero
 };
 
 template <int ROWS>
@@ -752,6 +759,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           q8[e] = tt * qs;
           amax = fmaxf(amax, fabsf(tt));
         }
+        if (p.out_maskbits) {   // from the ROUNDED output: exactly what a consumer of the bf16 activation would test
+          unsigned mb = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mb |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+          p.out_maskbits[rowi[it] * p.ld_out_maskbits + (coli[it] >> 3)] = (unsigned char)mb;
+        }
         if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         else asm volatile("" ::"v"(o));
         if (p.out_fp8) *(unsigned long long*)(p.out_fp8 + rowi[it] * p.ld_fp8 + coli[it]) = pack_fp8x8(q8);
@@ -763,7 +776,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[it % NP][e]; hi[e] = v[it][4 + e] + bias[it % NP][4 + e]; }
-        if (mem) {
+        if (p.dbg & 8) {   // diagnostic: half the slab bytes (what 16-bit partials would move)
+          *(f32x4*)(out + rowi[it] * (p.ld_f32 / 2) + coli[it] / 2) = lo + hi;
+        } else if (mem) {
           *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
           *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;
         } else {
@@ -846,15 +861,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       }
     } else {  // EPI_MASK_BF16
       bf16x8 mk[CH];
+      unsigned mbits[CH];
+      const bool by_bits = p.maskbits != nullptr;
 #pragma unroll
-      for (int it = 0; it < CH; ++it)
-        mk[it] = mem ? *(const bf16x8*)(p.mask + rowi[it] * p.ld_mask + coli[it]) : bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
+      for (int it = 0; it < CH; ++it) {
+        mbits[it] = 0xFFu;
+        mk[it] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1};
+        if (mem) {
+          if (by_bits) mbits[it] = p.maskbits[rowi[it] * p.ld_maskbits + (coli[it] >> 3)];
+          else mk[it] = *(const bf16x8*)(p.mask + rowi[it] * p.ld_mask + coli[it]);
+        }
+      }
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float tt = (float)mk[it][e] > 0.f ? v[it][e] : 0.f;
+          const bool keep = by_bits ? ((mbits[it] >> e) & 1u) != 0u : (float)mk[it][e] > 0.f;
+          const float tt = keep ? v[it][e] : 0.f;
           cs[it % NP][e] += tt;
           o[e] = (bf16_t)tt;
         }

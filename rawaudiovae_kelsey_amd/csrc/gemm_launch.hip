@@ -252,7 +252,7 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
   if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }  // experiment hook: 256x128 main loop
-  if (tile >= 200 && tile < 208) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
+  if (tile >= 200 && tile < 216) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
   if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
   g_force_tile = tile;
   return RV_OK;
@@ -281,7 +281,14 @@ int rv_linear_fwd(const void* x, long ldx, const void* w, long ldw, const float*
 int rv_linear_fwd_q8(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp, long Np, long Kp,
                      int act, void* y, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale, float* amax_part,
                      void* stream) {
+  return rv_linear_fwd_ex(x, ldx, w, ldw, bias, Mp, Np, Kp, act, y, ldy, y_fp8, ldy_fp8, q_scale, amax_part, nullptr, 0, stream);
+}
+
+int rv_linear_fwd_ex(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp, long Np, long Kp,
+                     int act, void* y, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale, float* amax_part,
+                     void* maskbits, long ld_maskbits, void* stream) {
   RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd_q8: null operand");
+  RV_REQUIRE(!maskbits || ld_maskbits >= Np / 8, RV_ERR_SHAPE, "rv_linear_fwd_ex: mask rows are Np/8 bytes");
   RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_q8: act %d", act);
   RV_REQUIRE(!y_fp8 || (q_scale && ldy_fp8 % 8 == 0 && ((uintptr_t)y_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_linear_fwd_q8: fp8 output needs a scale and 8-byte aligned rows");
@@ -290,11 +297,18 @@ int rv_linear_fwd_q8(const void* x, long ldx, const void* w, long ldw, const flo
   a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
   a.out_fp8 = (unsigned char*)y_fp8; a.ld_fp8 = ldy_fp8; a.q_scale = q_scale; a.amax_part = amax_part;
+  a.out_maskbits = (unsigned char*)maskbits; a.ld_out_maskbits = ld_maskbits;
   return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
 }
 
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y, long ldy, void* stream) {
+  return rv_linear_fwd_fp8_ex(x_fp8, ldx, w_fp8, ldw, bias, dq, Mp, Np, Kp, act, y, ldy, nullptr, 0, stream);
+}
+
+int rv_linear_fwd_fp8_ex(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
+                         long Mp, long Np, long Kp, int act, void* y, long ldy, void* maskbits, long ld_maskbits,
+                         void* stream) {
   RV_REQUIRE(x_fp8 && w_fp8 && y && dq, RV_ERR_NULL, "rv_linear_fwd_fp8: null operand");
   RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_fp8: act %d", act);
   RV_REQUIRE(Kp % 128 == 0 && ldx % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_linear_fwd_fp8: K and leading dims must be multiples of 128 / 16 fp8 elements");
@@ -302,6 +316,7 @@ int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, 
   a.A = (const bf16_t*)x_fp8; a.lda = ldx / 2; a.B = (const bf16_t*)w_fp8; a.ldb = ldw / 2;
   a.k_tiles = (int)(Kp / 128); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy; a.dq = dq;
+  a.out_maskbits = (unsigned char*)maskbits; a.ld_out_maskbits = ld_maskbits;
   return launch_tile_fp8<EPI_BIAS_ACT_BF16>(choose_tile(Mp, Np, 1), a, Mp, Np, Kp / 2, (hipStream_t)stream);
 }
 
@@ -490,7 +505,15 @@ int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, i
 int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
                           long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
                           float* dw_slabs, long lddw, int splits, void* stream) {
+  return rv_linear_dgrad_wgrad_mb(dy, lddy, w, ldw, x, ldx, nullptr, 0, Mp, Np, Kp, dx_bf16, lddx, colsum_partial, dw_slabs,
+                                  lddw, splits, stream);
+}
+
+int rv_linear_dgrad_wgrad_mb(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
+                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
+                             float* colsum_partial, float* dw_slabs, long lddw, int splits, void* stream) {
   RV_REQUIRE(dy && w && x && dx_bf16 && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad: null operand");
+  RV_REQUIRE(!maskbits || ld_maskbits >= Np / 8, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_mb: mask rows are Np/8 bytes");
   int paired, bm, sp;
   int rc = rv_dgrad_wgrad_pick(Mp, Np, Kp, &paired, &bm, &sp);
   if (rc) return rc;
@@ -502,6 +525,7 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
     d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
     d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
     d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+    d.maskbits = (const unsigned char*)maskbits; d.ld_maskbits = ld_maskbits;
     g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
     g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
     g.out_f32 = dw_slabs; g.ld_f32 = lddw; g.split_stride_f32 = Kp * lddw;
@@ -519,6 +543,7 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
   d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
   d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+  d.maskbits = (const unsigned char*)maskbits; d.ld_maskbits = ld_maskbits;
   d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1;
   g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
   g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;

@@ -320,18 +320,20 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                    p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
                                    p->b.step_counter, stream));
       if (p->fp8)
-        RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
-                                 h1, Hp, stream));
+        RV_TRY(rv_linear_fwd_fp8_ex(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                                    h1, Hp, nullptr, 0, stream));
       else
-        RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+        RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
+                                nullptr, nullptr, nullptr, 0, stream));
     } else if (p->fp8) {
       RV_TRY(rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
                                  p->b.step_counter, stream));
-      RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
-                               h1, Hp, stream));
+      RV_TRY(rv_linear_fwd_fp8_ex(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                                    h1, Hp, nullptr, 0, stream));
     } else {
       RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
-      RV_TRY(rv_linear_fwd(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, stream));
+      RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
+                                nullptr, nullptr, nullptr, 0, stream));
     }
     RV_TRY(rv_linear_fwd_f32(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, L2p, Hp, p->s_heads,
                              mulv_slabs, L2p, stream));
@@ -339,21 +341,23 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                           kl_part, stream));
     if (p->fr_hop) {
       if (p->fp8)
-        RV_TRY(rv_linear_fwd_q8(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), nullptr, 0, stream));
       else
-        RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
+        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+                                nullptr, nullptr, nullptr, 0, stream));
       RV_TRY(rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
                                            (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
                                            p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
                                            mse_part, (float*)p->ws("db4p"), stream));
     } else if (p->fp8) {
-      RV_TRY(rv_linear_fwd_q8(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                              p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+      RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), nullptr, 0, stream));
       RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
                                         x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     } else {
-      RV_TRY(rv_linear_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, stream));
+      RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+                                nullptr, nullptr, nullptr, 0, stream));
       RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     }

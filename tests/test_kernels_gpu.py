@@ -445,3 +445,41 @@ def test_bf16_gradient_payload_kernels(L):
         outs.append((p.clone(), m.clone(), v.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 1024), (384, 256, 128), (128, 128, 192)])
+def test_relu_mask_bits_equal_activation_mask(L, M, N, K):
+    """rv_linear_fwd_ex writes the ReLU mask of its output as bits; rv_linear_dgrad_wgrad_mb reading those bits gives
+    bit for bit the dX / bias-gradient partials / dW slabs that rv_linear_dgrad_wgrad gives reading the bf16
+    activation itself (16x the bytes).  Shapes: the paired 256x256 launch, a dual launch, a 128-tile fallback."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(M, 64, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, 64, device="cuda", generator=g) * 0.2).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    bits = torch.zeros(M, N // 8, dtype=torch.uint8, device="cuda")
+    L.rv_linear_fwd_ex(x.data_ptr(), 64, w.data_ptr(), 64, b.data_ptr(), M, N, 64, 1, h.data_ptr(), N, None, 0, None, None,
+                       bits.data_ptr(), N // 8, sp())
+    torch.cuda.synchronize()
+    want = (h.float() > 0).view(M, N // 8, 8).to(torch.int32)
+    packed = (want * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, packed)
+    assert 0.2 < float(want.float().mean()) < 0.8
+    dy = (torch.randn(M, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wk = (torch.randn(K, N, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
+    paired, bm, splits = dgrad_wgrad_pick(M, N, K)
+    outs = []
+    for use_bits in (False, True):
+        dx = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        cs = torch.zeros((M // bm) * N, dtype=torch.float32, device="cuda")
+        dw = torch.zeros(splits * K * N, dtype=torch.float32, device="cuda")
+        L.rv_linear_dgrad_wgrad_mb(dy.data_ptr(), K, wk.data_ptr(), N, h.data_ptr(), N,
+                                   bits.data_ptr() if use_bits else None, N // 8, M, N, K, dx.data_ptr(), N, cs.data_ptr(),
+                                   dw.data_ptr(), N, splits, sp())
+        torch.cuda.synchronize()
+        outs.append((dx, cs, dw))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+    ref = (dy.float() @ wk.float()) * (h.float() > 0)
+    assert float((outs[1][0].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())

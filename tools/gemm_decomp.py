@@ -54,7 +54,7 @@ def timeit(fn, reps=20, rounds=5):
     return best[len(best) // 2]
 
 
-modes = [(0, "whole"), (1, "epi w/o global"), (2, "no epilogue"), (4, "no main loop"), (6, "empty launch")]
+modes = [(0, "whole"), (8, "half slab bytes"), (1, "epi w/o global"), (2, "no epilogue"), (4, "no main loop")]
 print("%-24s" % "us per launch" + "".join("%16s" % m[1] for m in modes))
 for name, fn in cases.items():
     row = []
