@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="also time the step with fc1 / fc4 forward on fp8 (e4m3) operands and report it as the side "
                          "line `alt_fp8` (BASELINE configs[4]); the headline stays bf16")
+    ap.add_argument("--slab-dtype", default=None, choices=["fp32", "fp16"],
+                    help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
     ap.add_argument("--n128-loop", type=int, default=0,
                     help="experiment: main loop of the 256x128 GEMM tile (3 one-barrier ring = default, 9 ping-pong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +134,8 @@ def main():
     if args.n128_loop:
         from rawaudiovae_kelsey_amd._lib import lib as _rvlib
         _rvlib().rv_gemm_force_tile(100 + args.n128_loop)
-    eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
+    ekw = {"slab_dtype": args.slab_dtype} if args.slab_dtype else {}
+    eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **ekw)
     eng.load_params(make_params(S, H, L, 0))
     eng.set_concurrency(0 if args.serial else args.sched)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
@@ -372,7 +375,7 @@ def main():
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
-                       "schedule": int(0 if args.serial else args.sched),
+                       "schedule": int(0 if args.serial else args.sched), "wgrad_slabs": eng.slab_dtype,
                        "grad_allreduce": ddp_mode},
             # `value` / `ms_per_step` are the MEDIAN over `repeats` passes of exactly `steps` steps each
             "timing": {"repeats": len(passes), "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),

@@ -21,7 +21,8 @@ class ParamDesc(C.Structure):
     _fields_ = [("offset", c_long), ("rows", c_long), ("cols", c_long),
                 ("grad_slabs", c_void_p), ("grad_ld", c_long), ("grad_split_stride", c_long),
                 ("grad_splits", c_int), ("shadow_bf16", c_void_p), ("shadow_f32", c_void_p),
-                ("shadow_ld", c_long), ("shadow_fp8", c_void_p), ("fp8_scale", c_void_p)]
+                ("shadow_ld", c_long), ("shadow_fp8", c_void_p), ("fp8_scale", c_void_p),
+                ("grad_half", c_int), ("grad_unscale", c_float)]
 
 
 class PlanBuffers(C.Structure):
@@ -92,10 +93,16 @@ _SIGS = {
     "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
                                 c_void_p, c_long, c_void_p]),
     "rv_linear_wgrad_tile": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int,
-                                     c_void_p, c_long, c_void_p]),
+                                     c_void_p, c_long, c_int, c_float, c_void_p]),
+    "rv_linear_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
+                                   c_int, c_float, c_void_p]),
+    "rv_linear_dgrad_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+                                         c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int,
+                                         c_float, c_void_p]),
+    "rv_plan_set_slab_dtype": (c_int, [c_void_p, c_int]),
     "rv_wgrad_adam_fits": (c_int, [c_long, c_long, c_long, c_int]),
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
-                                     C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_int, c_float, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_int, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -16,23 +16,39 @@ struct DescTable {
 };
 
 
+// 4 consecutive elements of one slab: fp32, or fp16 slabs holding value * 2^k (grad_half; `grad_unscale` = 2^-k
+// undoes it exactly).  `off` is in elements either way.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_slab4(const rv_param_desc& d, long off) {
+  if (d.grad_half) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(d.grad_slabs) + off);
+    return make_float4((float)h[0] * d.grad_unscale, (float)h[1] * d.grad_unscale, (float)h[2] * d.grad_unscale,
+                       (float)h[3] * d.grad_unscale);
+  }
+  return *reinterpret_cast<const float4*>(d.grad_slabs + off);
+}
+__device__ __forceinline__ float load_slab1(const rv_param_desc& d, long off) {
+  if (d.grad_half) return (float)reinterpret_cast<const _Float16*>(d.grad_slabs)[off] * d.grad_unscale;
+  return d.grad_slabs[off];
+}
+
 // Sum of the gradient slabs for 4 consecutive elements of one row.
 template <bool VEC>
 __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long c, int nvalid) {
-  const float* base = d.grad_slabs + r * d.grad_ld + c;
+  const long base = r * d.grad_ld + c;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int s = 0;
   if constexpr (VEC) {
-    for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent 16-B loads in flight
-      const float4 a = *reinterpret_cast<const float4*>(base + (long)(s + 0) * d.grad_split_stride);
-      const float4 b = *reinterpret_cast<const float4*>(base + (long)(s + 1) * d.grad_split_stride);
-      const float4 e = *reinterpret_cast<const float4*>(base + (long)(s + 2) * d.grad_split_stride);
-      const float4 f = *reinterpret_cast<const float4*>(base + (long)(s + 3) * d.grad_split_stride);
+    for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent vector loads in flight
+      const float4 a = load_slab4(d, base + (long)(s + 0) * d.grad_split_stride);
+      const float4 b = load_slab4(d, base + (long)(s + 1) * d.grad_split_stride);
+      const float4 e = load_slab4(d, base + (long)(s + 2) * d.grad_split_stride);
+      const float4 f = load_slab4(d, base + (long)(s + 3) * d.grad_split_stride);
       g.x += (a.x + b.x) + (e.x + f.x); g.y += (a.y + b.y) + (e.y + f.y);
       g.z += (a.z + b.z) + (e.z + f.z); g.w += (a.w + b.w) + (e.w + f.w);
     }
     for (; s < d.grad_splits; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(base + (long)s * d.grad_split_stride);
+      const float4 a = load_slab4(d, base + (long)s * d.grad_split_stride);
       g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
     }
   } else {
@@ -41,14 +57,15 @@ __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < nvalid) {
-          const float* q = base + j + (long)s * d.grad_split_stride;
-          t[j] += (q[0] + q[d.grad_split_stride]) + (q[2 * d.grad_split_stride] + q[3 * d.grad_split_stride]);
+          const long q = base + j + (long)s * d.grad_split_stride;
+          t[j] += (load_slab1(d, q) + load_slab1(d, q + d.grad_split_stride)) +
+                  (load_slab1(d, q + 2 * d.grad_split_stride) + load_slab1(d, q + 3 * d.grad_split_stride));
         }
     }
     for (; s < d.grad_splits; ++s)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nvalid) t[j] += base[j + (long)s * d.grad_split_stride];
+        if (j < nvalid) t[j] += load_slab1(d, base + j + (long)s * d.grad_split_stride);
     g = make_float4(t[0], t[1], t[2], t[3]);
   }
   return g;
@@ -106,7 +123,7 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
   const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
   const long o = d.offset + r * d.cols + c;
   const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
+                   ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);   // (fp16 slabs need 8: implied)
   // issue the optimizer-state loads first so they are in flight under the slab sums
   float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
   if constexpr (UPDATE) {
@@ -144,10 +161,10 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
     const int lane = tid & 63;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = lane; s < d.grad_splits; s += 64) {
-      const float* q = d.grad_slabs + (long)s * d.grad_split_stride + r * d.grad_ld + c;
+      const long q = (long)s * d.grad_split_stride + r * d.grad_ld + c;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nvalid) tsum[j] += q[j];
+        if (j < nvalid) tsum[j] += load_slab1(d, q + j);
     }
     g = make_float4(wave_sum(tsum[0]), wave_sum(tsum[1]), wave_sum(tsum[2]), wave_sum(tsum[3]));
     if (lane != 0) return;
@@ -250,10 +267,10 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
       m4[u] = *reinterpret_cast<const float4*>(m_arena + it[u].o);
       v4[u] = *reinterpret_cast<const float4*>(v_arena + it[u].o);
       w4[u] = *reinterpret_cast<const float4*>(param + it[u].o);
-      const float* base = d.grad_slabs + it[u].r * d.grad_ld + it[u].c;
+      const long base = it[u].r * d.grad_ld + it[u].c;
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
-        sl[u][s_] = s_ < d.grad_splits ? *reinterpret_cast<const float4*>(base + (long)s_ * d.grad_split_stride)
+        sl[u][s_] = s_ < d.grad_splits ? load_slab4(d, base + (long)s_ * d.grad_split_stride)
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float tt = (float)(*step_counter);

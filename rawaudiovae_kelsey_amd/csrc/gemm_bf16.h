@@ -47,6 +47,11 @@ struct GemmArgs {
   int relu;              // EPI_BIAS_ACT_BF16: apply ReLU
   float* out_f32;
   long ld_f32, split_stride_f32;
+  // EPI_F32 with fp16 split-K slabs: same element strides, values stored as fp16(value * f16_scale) (a power of two:
+  // weight-gradient partials are ~1e-6..1e-2 and fp16's exponent range is narrow).  Halves the slab bytes that a
+  // split-K weight gradient writes and that Adam reads back; the sum over slabs stays fp32.
+  void* out_f16;
+  float f16_scale;
   bf16_t* out_bf16;
   long ld_bf16;
   const float* bias;  // [N] (padded), may be null
@@ -79,7 +84,7 @@ struct GemmArgs {
   const float* q_scale;  // device scalar
   float* amax_part;      // [number of blocks]: max|out| of each block (delayed scaling: reduced by the next step's first kernel), or null
   int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
-                    // 2 = no epilogue at all, 4 = no main loop, 8 = half-width split-K slab stores; results are wrong whenever it is non-zero
+                    // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
 };
 
 template <int ROWS>
@@ -776,8 +781,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { lo[e] = v[it][e] + bias[it % NP][e]; hi[e] = v[it][4 + e] + bias[it % NP][4 + e]; }
-        if (p.dbg & 8) {   // diagnostic: half the slab bytes (what 16-bit partials would move)
-          *(f32x4*)(out + rowi[it] * (p.ld_f32 / 2) + coli[it] / 2) = lo + hi;
+        if (p.out_f16) {
+          typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+          f16x8 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * p.f16_scale); h[4 + e] = (_Float16)(hi[e] * p.f16_scale); }
+          *(f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]) = h;
         } else if (mem) {
           *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
           *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;

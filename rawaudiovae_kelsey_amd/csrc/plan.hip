@@ -65,6 +65,8 @@ struct rv_plan {
   float* ag_buf = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
+  int slab_dtype = RV_SLAB_F32;   // element type of the dW1 / dW4 split-K slabs (rv_plan_set_slab_dtype)
+  float slab_scale = 4096.f;      // fp16 slabs hold fp16(partial * 2^12)
   // frame source of the step in flight (rv_plan_step_frames): `x` is then the resident waveform
   const long long* fr_idx = nullptr;
   long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
@@ -200,6 +202,17 @@ int rv_plan_set_fp8(rv_plan* p, int enable) {
   for (rv_param_desc* d : {p->d_slab, p->d_flat}) {
     d[0].shadow_fp8 = enable ? p->ws("W1q") : nullptr; d[0].fp8_scale = st + 1;
     d[8].shadow_fp8 = enable ? p->ws("W4q") : nullptr; d[8].fp8_scale = st + 2;
+  }
+  return RV_OK;
+}
+
+int rv_plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_slab_dtype: plan not bound");
+  RV_REQUIRE(slab_dtype == RV_SLAB_F32 || slab_dtype == RV_SLAB_F16, RV_ERR_UNSUPPORTED, "rv_plan_set_slab_dtype: %d", slab_dtype);
+  p->slab_dtype = slab_dtype;
+  for (rv_param_desc* d : {p->d_slab + 0, p->d_slab + 8}) {   // fc1.weight, fc4.weight: the two 8 MB gradients
+    d->grad_half = slab_dtype == RV_SLAB_F16;
+    d->grad_unscale = 1.0f / p->slab_scale;
   }
   return RV_OK;
 }
@@ -385,15 +398,15 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // half the chip, so its launch also carries the optimizer step of every tensor whose gradient is already
     // complete on the other CUs (fc3 and fc4, below); fc1's and the heads' updates are the step's last launch.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
     // fc3 + fc4 ride along (92 MB at C2): an optimizer block streams ~25 GB/s from its CU, so half the chip
     // moves ~3 TB/s -- about what the GEMM blocks take to finish; the heads' update on top made the launch wait
     // for the optimizer (43 us against 36)
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, p->d_slab + 6, 4,
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, p->d_slab + 6, 4,
                                 p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter,
                                 256 - n_gemm, stream));
     RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
@@ -412,14 +425,15 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                            stream));
     RV_HIP(hipEventRecord(p->ev[1], s0));
     RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, (float*)p->ws("dW4"), Hp, (void*)s1));
+    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, p->ws("dW4"), Hp, p->slab_dtype, p->slab_scale,
+                                (void*)s1));
     RV_TRY(rv_adam_multi(p->d_slab + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, (void*)s1));
     RV_HIP(hipEventRecord(p->ev[3], s1));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
     RV_TRY(rv_adam_multi(p->d_slab, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join: the caller's stream owns the whole step again
@@ -429,8 +443,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // One fork: everything on the caller's stream except the fc3/fc4 half of Adam, which runs on the side
     // stream beside the fc1 weight-gradient GEMM (each cross-stream edge costs 6-10 us on this runtime).
     hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
     RV_TRY(latent_bwd(stream));
     RV_HIP(hipEventRecord(p->ev[1], s0));  // dW4, db4, dW3, db3 ready; W3b, W4b no longer read
     RV_TRY(reparam_bwd(stream));
@@ -439,7 +453,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                          p->b.step_counter, (void*)s1));
     RV_HIP(hipEventRecord(p->ev[3], s1));
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
     RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join
     RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
@@ -452,8 +466,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const bool do_chain_b = old_b || (phases & RV_PHASE_BWD_CHAIN);   // heads dgrad + wgrad (one launch), fc1 wgrad
   const bool do_w3 = old_a || (phases & RV_PHASE_BWD_REST);         // fc3 wgrad
   if (do_pair)
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                 (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
   if (do_chain_a && do_w3) {
     RV_TRY(latent_bwd(stream));
   } else if (do_chain_a) {
@@ -463,7 +477,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
   }
   if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
 
@@ -595,8 +609,8 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     if (*n < 0) *n = 0;
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                               (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
   RV_TRY(scatter_bucket(0));   // fc4's 8.4 MB travel behind the rest of backward
   RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
                                    (float*)p->ws("dW3"), Lp, p->s_w3, stream));
@@ -604,7 +618,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
   RV_TRY(scatter_bucket(1));
   RV_HIP(hipEventRecord(p->ev_done[1], sc));           // both reduce-scatters (the collective stream is in order)
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
@@ -684,8 +698,8 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                               (float*)p->ws("dW4"), Hp, p->s_w4, stream));
+  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
   RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
   // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
   // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
@@ -695,7 +709,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, (float*)p->ws("dW1"), Sp, stream));
+  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
   RV_TRY(reduce_bucket(1, 0, 8));          // fc1, fc21, fc22, fc3: contiguous in the arena
   // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));

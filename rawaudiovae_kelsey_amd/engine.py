@@ -38,7 +38,8 @@ class TrainEngine:
     """Owns the arenas + workspace of one (S, H, L, B) training configuration."""
 
     def __init__(self, segment_length, n_units, latent_dim, batch_size, device="cuda",
-                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None, fp8=False):
+                 kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None, fp8=False,
+                 slab_dtype="fp32"):
         """share: another TrainEngine of the same (S, H, L) whose parameter / Adam / gradient
         arenas, step counter and loss ring this one uses (a second batch size, e.g. the ragged
         last batch of an epoch -- DataLoader keeps it, train.py:134)."""
@@ -91,6 +92,11 @@ class TrainEngine:
         self.fp8_h3_scale = 16.0        # first step only; afterwards 224 / max|h3| of the previous step
         if self.fp8:
             L_.rv_plan_set_fp8(self._plan, 1)
+        # element type of the fc1 / fc4 weight-gradient split-K slabs ("fp16": half the bytes written and re-read)
+        if slab_dtype not in ("fp32", "fp16"):
+            raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
+        self.slab_dtype = slab_dtype
+        L_.rv_plan_set_slab_dtype(self._plan, int(slab_dtype == "fp16"))
 
     def __del__(self):
         try:

@@ -224,3 +224,19 @@ def test_sharded_batches_cover_the_epoch_once():
             seen += [int(v) for b in got for v in b]
         assert all(s == sizes[0] for s in sizes)
         assert len(seen) == len(set(seen)) and n - len(seen) < world
+
+
+def test_kelsey_iterable_ini_parses_like_the_reference():
+    """The reference's only working streaming config (kelsey_iterable.ini: free-text [notes] lines are keys
+    without values, train_iterable.py:40 allow_no_value=True) goes through this build's parser with the run
+    length the reference derives from it (train_iterable.py:70-74)."""
+    import train as T
+    from conftest import REPO
+    cfg = T.read_config(os.path.join(REPO, "kelsey_iterable.ini"))
+    assert cfg["training"].getint("batch_size") == 4096
+    assert cfg["training"].getint("checkpoint_interval") == 754
+    total = int(cfg["training"].getint("total_num_frames") / cfg["training"].getint("batch_size"))
+    assert total == 37674 and total // 754 == 49   # int(154314100 / 4096); the notes in the reference say 37676
+    notes = dict(cfg["notes"])
+    assert notes["additional_notes"] == "" and sum(v is None for v in notes.values()) >= 2   # lines without "=" or ":" are valueless keys
+    assert cfg["VAE"].getint("latent_dim") == 256 and cfg["audio"].getint("hop_length") == 128

@@ -61,7 +61,7 @@ def main():
     full = args.batch
     eng = TrainEngine(1024, 2048, 64, full)
     tail = TrainEngine(1024, 2048, 64, len(ds) % full, share=eng) if len(ds) % full else None
-    gen = torch.Generator().manual_seed(0)
+    gen = torch.Generator(device="cuda").manual_seed(0)
     for warm in range(2):
         for idx in ds.index_batches(full, generator=gen):
             (eng if idx.numel() == full else tail).step_frames(ds, idx)

@@ -322,7 +322,9 @@ def main(argv=None):
         # the engines' arenas, shadows and workspaces were filled on the default stream, which a fresh
         # stream does not wait for
         train_stream.wait_stream(torch.cuda.current_stream(device))
-    shuffle_gen = torch.Generator().manual_seed(seed)   # the same permutation on every rank
+    # the same permutation on every rank: a device generator with the same seed (the permutation is drawn on the GPU;
+    # torch's CPU randperm costs more than an epoch of training steps at 2e5 frames)
+    shuffle_gen = torch.Generator(device=device).manual_seed(seed)
 
     def checkpoint_state(epoch):
         return {'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': engine.optimizer_state_dict()}
