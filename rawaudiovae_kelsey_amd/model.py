@@ -90,6 +90,31 @@ class VAE(nn.Module):
         return eng
 
 
+class Encoder(nn.Module):
+    """The encoder half of a `VAE` as a module of its own: `Encoder(vae)(x) -> (mu, logvar)`.
+    BASELINE.json's north_star names an Encoder/Decoder/VAE surface; the reference has only `VAE`
+    (rawvae/model.py:5-35), so these are views: they own no parameters (the VAE is held
+    unregistered), `state_dict()` of the VAE keeps exactly the keys fc{1,21,22,3,4}.{weight,bias}."""
+
+    def __init__(self, vae):
+        super().__init__()
+        object.__setattr__(self, "vae", vae)
+
+    def forward(self, x):
+        return self.vae.encode(x)
+
+
+class Decoder(nn.Module):
+    """The decoder half of a `VAE`: `Decoder(vae)(z) -> recon` (see `Encoder`)."""
+
+    def __init__(self, vae):
+        super().__init__()
+        object.__setattr__(self, "vae", vae)
+
+    def forward(self, z):
+        return self.vae.decode(z)
+
+
 def loss_function(recon_x, x, mu, logvar, kl_beta, segment_length):
     """mean squared reconstruction error + kl_beta * KL(q(z|x) || N(0,1)), both `mean`
     reductions, returned as a 0-dim tensor (model.py:38-47)."""

@@ -162,3 +162,21 @@ def test_engine_adopts_module_parameters():
     with torch.no_grad():
         recon, mu, logvar = m(x)   # API path reads the updated weights
     assert torch.isfinite(recon).all()
+
+
+def test_encoder_decoder_views_share_the_vae():
+    """`Encoder(vae)` / `Decoder(vae)` (north_star's class surface; the reference has only VAE) own no
+    parameters, leave the VAE's state_dict keys untouched and compute what `vae.encode` / `vae.decode` compute."""
+    from rawvae.model import VAE, Decoder, Encoder
+    m = VAE(64, 96, 8).cuda()
+    keys = list(m.state_dict().keys())
+    enc, dec = Encoder(m), Decoder(m)
+    assert list(enc.parameters()) == [] and list(dec.parameters()) == [] and list(m.state_dict().keys()) == keys
+    assert keys == ["fc1.weight", "fc1.bias", "fc21.weight", "fc21.bias", "fc22.weight", "fc22.bias",
+                    "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias"]
+    x = torch.rand(5, 64, device="cuda") * 2 - 1
+    with torch.no_grad():
+        mu, lv = enc(x)
+        mu2, lv2 = m.encode(x)
+        assert torch.equal(mu, mu2) and torch.equal(lv, lv2)
+        assert torch.equal(dec(mu), m.decode(mu))
