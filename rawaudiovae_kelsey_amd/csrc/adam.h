@@ -75,12 +75,26 @@ __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long
 // updates parameters goes through this one function with floating-point contraction OFF, so that the stand-alone
 // kernel, the optimizer blocks of the weight-gradient launch and the sharded flat kernel (vector and scalar paths)
 // round identically whatever the surrounding code looks like -- replicas and schedules stay bit-equal.
+// `inv_bc2s` = 1 / sqrt(1 - beta2^t).  The square root and the reciprocal are the hardware's 1-ulp instructions
+// (v_sqrt_f32, v_rcp_f32), not the correctly rounded library sequences (~10 instructions each): the update differs
+// from torch's by ~3e-7 relative, far inside the 1e-5 the Adam tests allow, and an optimizer block that shares a CU
+// with nothing else (rv_linear_wgrad_adam) is bound by the length of this dependency chain.
 __device__ __forceinline__ void adam_update(float& m, float& v, float& w, const float g, const float step_size,
-                                            const float bc2s) {
+                                            const float inv_bc2s) {
 #pragma clang fp contract(off)
   m = 0.9f * m + 0.1f * g;
   v = 0.999f * v + (0.001f * g) * g;
-  w = w - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
+  const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2s + 1e-8f;
+  w = w - step_size * (m * __builtin_amdgcn_rcpf(denom));
+}
+
+// Bias corrections of step t = *step_counter: (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)), through the hardware exp2.
+__device__ __forceinline__ void adam_step_consts(const long long* step_counter, float lr, float* step_size, float* inv_bc2s) {
+  const float tt = (float)(*step_counter);
+  const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);          // log2(0.9)
+  const float bc2 = 1.0f - exp2f(tt * -0.0014434168696687f);           // log2(0.999)
+  *step_size = lr / bc1;
+  *inv_bc2s = 1.0f / sqrtf(bc2);
 }
 
 // fp8(w * scale) for up to 4 consecutive elements of one row of the padded fp8 shadow.
@@ -119,7 +133,9 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
   const long blk = vblock - tab.blk_start[t];
   const long grp = coop ? blk * 4 + (tid >> 6) : blk * 256 + tid;
   if (grp >= gpr * d.rows) return;
-  const long r = grp / gpr, c = (grp % gpr) * 4;
+  // 32-bit division (adam_build_table checks that a tensor has fewer than 2^31 groups): the 64-bit one is ~4x the code
+  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
+  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
   const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
   const long o = d.offset + r * d.cols + c;
   const bool vec = nvalid == 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
@@ -187,13 +203,10 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
     }
   }
   if constexpr (UPDATE) {
-    // bias corrections 1-b^t through the hardware exp2 (b^t = 2^(t log2 b)); relative error ~1e-6
-    const float tt = (float)(*step_counter);
-    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);      // log2(0.9)
-    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));  // log2(0.999)
-    const float step_size = lr / bc1;
+    float step_size, inv_bc2s;
+    adam_step_consts(step_counter, lr, &step_size, &inv_bc2s);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
+    for (int j = 0; j < 4; ++j) adam_update(mv[j], vv[j], wv[j], gv[j], step_size, inv_bc2s);
     if (vec) {
       *reinterpret_cast<float4*>(m_arena + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4*>(v_arena + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -244,8 +257,9 @@ __device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long
   const long gpr = (d.cols + 3) / 4;
   const long grp = (vblock - tab.blk_start[t]) * 256 + tid;
   if (grp >= gpr * d.rows) return it;
-  it.r = grp / gpr;
-  it.c = (grp % gpr) * 4;
+  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
+  it.r = r32;
+  it.c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
   it.o = d.offset + it.r * d.cols + it.c;
   const bool vec = d.cols - it.c >= 4 && ((d.cols | d.grad_ld | d.grad_split_stride | d.offset) & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0) && d.grad_splits <= 4 &&
@@ -273,10 +287,8 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
         sl[u][s_] = s_ < d.grad_splits ? load_slab4(d, base + (long)s_ * d.grad_split_stride)
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float tt = (float)(*step_counter);
-    const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);
-    const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));
-    const float step_size = lr / bc1;
+    float step_size, inv_bc2s;
+    adam_step_consts(step_counter, lr, &step_size, &inv_bc2s);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it[u].t)];
@@ -297,7 +309,7 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         gv[j] *= grad_scale;
-        adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
+        adam_update(mv[j], vv[j], wv[j], gv[j], step_size, inv_bc2s);
       }
       *reinterpret_cast<float4*>(m_arena + it[u].o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4*>(v_arena + it[u].o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -366,6 +378,7 @@ inline int adam_build_table(const rv_param_desc* descs, int n, DescTable* tab) {
     tab->d[i] = descs[i];
     RV_REQUIRE(descs[i].rows > 0 && descs[i].cols > 0 && descs[i].grad_slabs && descs[i].grad_splits >= 1,
                RV_ERR_SHAPE, "param desc %d invalid", i);
+    RV_REQUIRE(descs[i].rows * ((descs[i].cols + 3) / 4) < 0x7fffffffL, RV_ERR_SHAPE, "param desc %d: tensor too large", i);
     tab->blk_start[i] = blk;
     {
       const long groups = descs[i].rows * ((descs[i].cols + 3) / 4);

@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
   const long total = rows_p * cpr;
   const bool vec_ok = (ld_src % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / cpr, c = (i % cpr) * 8;
+    const unsigned r32 = (unsigned)i / (unsigned)cpr;   // total < 2^31 (checked by the launchers)
+    const long r = r32, c = (long)((unsigned)i - r32 * (unsigned)cpr) * 8;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -192,7 +193,8 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
   __shared__ float red[4];
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long lq = Lp / 4;
-  const long b = i / lq, l = (i % lq) * 4;
+  const unsigned b32 = (unsigned)i / (unsigned)lq;      // Bp * Lp / 4 < 2^31 (checked by the launcher)
+  const long b = b32, l = (long)((unsigned)i - b32 * (unsigned)lq) * 4;
   const long L2p = 2 * Lp;
   float kl = 0.f;
   if (b < Bp) {
@@ -541,10 +543,8 @@ __global__ void __launch_bounds__(256)
 k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __restrict__ v_arena,
             const float* __restrict__ grad_shard, const long lo, const long n, const float lr, const float grad_scale,
             const long long* __restrict__ step_counter) {
-  const float tt = (float)(*step_counter);
-  const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);
-  const float bc2s = sqrtf(1.0f - exp2f(tt * -0.0014434168696687f));
-  const float step_size = lr / bc1;
+  float step_size, bc2s;   // bc2s: 1 / sqrt(1 - beta2^t)
+  adam_step_consts(step_counter, lr, &step_size, &bc2s);
   const bool vec = (lo & 3) == 0 && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m_arena) |
                                       reinterpret_cast<uintptr_t>(v_arena) | reinterpret_cast<uintptr_t>(grad_shard)) & 15) == 0;
   const long n4 = vec ? n >> 2 : 0;
@@ -610,6 +610,7 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
                  ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst & 15) == 0,
              RV_ERR_SHAPE, "rv_cast_pad_bf16: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
   const long total = rows_p * (cols_p / 8);
+  RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
@@ -628,6 +629,7 @@ int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, voi
   RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_cast_pad_bf16_q8: the fp8 output needs the state block and 8-byte aligned rows");
   const long total = rows_p * (cols_p / 8);
+  RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state /* [0] = scale of x */,
@@ -646,6 +648,7 @@ int rv_gather_cast_frames(const float* audio, long n_samples, const long long* f
   RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_gather_cast_frames: the fp8 output needs the state block and 8-byte aligned rows");
   const long total = rows_p * (cols_p / 8);
+  RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      audio, n_frames, S, 0L, (bf16_t*)dst_bf16, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state, amax_part,
@@ -661,6 +664,7 @@ int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* d
                  ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0,
              RV_ERR_SHAPE, "rv_cast_pad_fp8: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
   const long total = rows_p * (cols_p / 8);
+  RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)nullptr, rows_p, cols_p, ld_dst, (long long*)nullptr,
                      (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0,
@@ -684,7 +688,7 @@ int rv_reparam_fwd(const float* slabs, int splits, long Bp, long Lp, long B, lon
                    void* stream) {
   RV_REQUIRE(slabs && mulv && z && kl_partial, RV_ERR_NULL, "rv_reparam_fwd: null pointer");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_reparam_fwd: need eps_in or eps_out");
-  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && (Bp * Lp) % 1024 == 0, RV_ERR_SHAPE, "rv_reparam_fwd: bad extents");
+  RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && (Bp * Lp) % 1024 == 0 && Bp * Lp < 0x7fffffffL, RV_ERR_SHAPE, "rv_reparam_fwd: bad extents");
   hipLaunchKernelGGL(k_reparam_fwd, dim3((unsigned)(Bp * Lp / 1024)), dim3(256), 0, (hipStream_t)stream,
                      slabs, splits, Bp, Lp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv,
                      (bf16_t*)z, kl_partial);

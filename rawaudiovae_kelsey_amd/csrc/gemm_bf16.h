@@ -761,8 +761,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           float tt = v[it][e] + bias[it % NP][e];
           if (p.relu) tt = fmaxf(tt, 0.f);
           o[e] = (bf16_t)tt;
-          q8[e] = tt * qs;
-          amax = fmaxf(amax, fabsf(tt));
+          q8[e] = tt;
+        }
+        if (p.out_fp8 || p.amax_part) {   // fp8 forward only
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            amax = fmaxf(amax, fabsf(q8[e]));
+            q8[e] *= qs;
+          }
         }
         if (p.out_maskbits) {   // from the ROUNDED output: exactly what a consumer of the bf16 activation would test
           unsigned mb = 0;
@@ -836,6 +842,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           }
         }
       }
+      // a tile that lies wholly inside the valid extent (every tile at C2) skips the per-element validity selects
+      const bool interior = m0 + BM <= p.M_valid && n0 + BN <= p.N_valid;
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         const long r = rowi[it], col = coli[it];
@@ -843,17 +851,29 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         bf16x8 o;
         float rec[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          rec[e] = fast_tanh(v[it][e] + bias[it % NP][e]);
-          const bool valid = rv_ && col + e < p.N_valid;
-          float g = 0.f;
-          if (p.x) {
-            const float d = valid ? rec[e] - xin[it][e] : 0.f;
+        for (int e = 0; e < 8; ++e) rec[e] = fast_tanh(v[it][e] + bias[it % NP][e]);
+        if (p.x && interior) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = rec[e] - xin[it][e];
             sq += d * d;
-            g = p.scale * d * (1.f - rec[e] * rec[e]);
+            const float g = p.scale * d * (1.f - rec[e] * rec[e]);
             cs[it % NP][e] += g;
+            o[e] = (bf16_t)g;
           }
-          o[e] = (bf16_t)g;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool valid = rv_ && col + e < p.N_valid;
+            float g = 0.f;
+            if (p.x) {
+              const float d = valid ? rec[e] - xin[it][e] : 0.f;
+              sq += d * d;
+              g = p.scale * d * (1.f - rec[e] * rec[e]);
+              cs[it % NP][e] += g;
+            }
+            o[e] = (bf16_t)g;
+          }
         }
         if (p.x && mem) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
         else asm volatile("" ::"v"(o));
