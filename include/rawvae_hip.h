@@ -10,10 +10,12 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures
  *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
- *   - every pointer is a DEVICE pointer owned by the caller; the library allocates
- *     nothing except the opaque rv_plan / rv_graph host objects, a plan's internal
- *     streams and events, and -- only when the bf16 data-parallel payload is selected
- *     (rv_plan_set_ddp_payload) -- that plan's flat bf16 gradient arena.
+ *   - every pointer is a DEVICE pointer owned by the caller; the library allocates no
+ *     device memory at all -- only the opaque rv_plan / rv_graph host objects and a
+ *     plan's internal streams and events.
+ *   - one process per GPU, one host thread calling in at a time: the per-kernel
+ *     "dynamic LDS attribute set" latches and the rv_gemm_force_tile test hook are
+ *     plain process-wide statics (not per device, not thread-safe).
  *   - every function returns 0 on success or a negative RV_ERR_* code;
  *     rv_last_error() gives the message.  Nothing throws, aborts or synchronises
  *     unless its name ends in _sync; all launches are safe under stream capture.
@@ -458,9 +460,10 @@ typedef int (*rv_all_gather_fn)(const void* sendbuf, void* recvbuf, size_t sendc
 long rv_plan_shard_count(const rv_plan*, int bucket, int world);
 int rv_plan_attach_comm_sharded(rv_plan*, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
                                 int world, int rank, float* rs_buf, float* ag_buf);
-/* Payload of the gradient all-reduces: 0 = fp32 (default, exact mean of the ranks' fp32 gradients),
- * 1 = bf16 (each rank's summed gradient rounded to bf16, summed by the collective in bf16). */
-int rv_plan_set_ddp_payload(rv_plan*, int bf16);
+/* Payload of the gradient all-reduces: bf16_arena == NULL = fp32 (default, exact mean of the ranks' fp32
+ * gradients); otherwise bf16 (each rank's summed gradient rounded to bf16 into the caller's `bf16_arena`, which holds
+ * at least as many 2-byte elements as the fp32 arenas hold floats, and summed by the collective in bf16). */
+int rv_plan_set_ddp_payload(rv_plan*, void* bf16_arena);
 int rv_plan_step_ddp(rv_plan*, const float* x, const float* eps, float* recon_out, float kl_beta,
                      float lr, unsigned long long seed, void* stream);
 /* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */

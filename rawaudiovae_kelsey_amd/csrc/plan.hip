@@ -71,7 +71,7 @@ struct rv_plan {
   const long long* fr_idx = nullptr;
   long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
   int payload_bf16 = 0;
-  void* grad_bf16 = nullptr;   // flat bf16 payload arena (allocated when the bf16 payload is first selected)
+  void* grad_bf16 = nullptr;   // caller's flat bf16 payload arena (rv_plan_set_ddp_payload)
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -184,7 +184,6 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
-  if (p->grad_bf16) (void)hipFree(p->grad_bf16);
   delete p;
 }
 
@@ -643,10 +642,10 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   return RV_OK;
 }
 
-int rv_plan_set_ddp_payload(rv_plan* p, int bf16) {
+int rv_plan_set_ddp_payload(rv_plan* p, void* bf16_arena) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_ddp_payload: null plan");
-  if (bf16 && !p->grad_bf16) RV_HIP(hipMalloc(&p->grad_bf16, (size_t)p->n_params * 2));
-  p->payload_bf16 = bf16 ? 1 : 0;
+  p->grad_bf16 = bf16_arena;
+  p->payload_bf16 = bf16_arena ? 1 : 0;
   return RV_OK;
 }
 

@@ -251,7 +251,12 @@ class TrainEngine:
         exchange, which then sums in bf16)."""
         if payload not in ("fp32", "bf16"):
             raise _lib.RvError("set_ddp_payload: %r (expected 'fp32' or 'bf16')" % (payload,))
-        lib().rv_plan_set_ddp_payload(self._plan, int(payload == "bf16"))
+        if payload == "bf16":
+            if getattr(self, "_grad_bf16", None) is None:
+                self._grad_bf16 = torch.empty(self.param.numel(), dtype=torch.bfloat16, device=self.param.device)
+            lib().rv_plan_set_ddp_payload(self._plan, self._grad_bf16.data_ptr())
+        else:
+            lib().rv_plan_set_ddp_payload(self._plan, None)
 
     def step_ddp(self, x, eps=None, recon_out=None, stream=None):
         """One whole data-parallel training step in one host call (`rv_plan_step_ddp`): every rank
