@@ -46,6 +46,8 @@ def parse():
                          "launches of the same 14 kernels, so eager is the default")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
+    ap.add_argument("--adam-split", type=int, default=None,
+                    help="permille of fc4.weight rows whose Adam update rides in the fc1 wgrad launch (default: library's)")
     ap.add_argument("--sched", type=int, default=0,
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
     ap.add_argument("--fp8", action="store_true",
@@ -138,6 +140,8 @@ def main():
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **ekw)
     eng.load_params(make_params(S, H, L, 0))
     eng.set_concurrency(0 if args.serial else args.sched)
+    if args.adam_split is not None:
+        eng.set_adam_split(args.adam_split)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
     comp = torch.cuda.Stream(device=dev)
     use_graph = world == 1 and args.graph and not args.no_graph and os.environ.get("RV_FORCE_DDP") != "1"

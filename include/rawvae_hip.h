@@ -169,6 +169,19 @@ int rv_reparam_fwd(const float* mulv_slabs, int splits, long Bp, long Lp, long B
                    const long long* step_counter, float* mulv, void* z_bf16, float* kl_partial,
                    void* stream);
 
+/* encode's heads + reparameterize in one call, model.py:21-26 (fc21 | fc22 as ONE [2Lp, Kp] weight, then
+ * z = mu + eps * exp(logvar / 2)) with the KL partials of model.py:45: rv_linear_fwd_f32 into `mulv_slabs`
+ * (workspace, [splits][Bp][2Lp] fp32) followed by rv_reparam_fwd -- two launches back to back on `stream`.
+ * A one-launch form was priced and not built: at 2L = 128 outputs the GEMM only fills the chip as 512 split-K
+ * blocks, and combining split-K partials inside a launch (release fence + arrival ticket + acquire, 5-13 us per seam
+ * on this chip: MI355X_MICROARCH.md, price list row "splitk-seam") costs more than the ~1.5 us kernel boundary it
+ * removes; without split-K every block re-streams the whole head weight through its CU's ~60 GB/s L2->LDS port
+ * (12-14 us for any row tile from 16 to 64 against 12.9 us for the two launches).  See DESIGN.md section 3. */
+int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldw, const float* bias_heads,
+                         long Bp, long Lp, long Kp, long B, long L, int splits, float* mulv_slabs,
+                         const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                         float* mulv, void* z_bf16, float* kl_partial, void* stream);
+
 /* Backward of reparameterize + KL:
  *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
  * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums
@@ -388,6 +401,10 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *    join sits on the critical path and it measures slower than 0 at C2).
  * rv_plan_step_ddp refuses to run while a non-zero schedule is set (see there). */
 int rv_plan_set_concurrency(rv_plan*, int enable);
+/* Schedule 0 only: the first `permille`/1000 of fc4.weight's rows are updated by the optimizer blocks that ride in
+ * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch.  Same arithmetic
+ * either way; the value only balances the two launches. */
+int rv_plan_set_adam_split(rv_plan*, int permille);
 /* fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay bf16).
  * The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
  *   [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)

@@ -104,6 +104,9 @@ _SIGS = {
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
                                      c_int, c_float, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_int, c_void_p]),
+    "rv_heads_reparam_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_long,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
@@ -125,6 +128,7 @@ _SIGS = {
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
+    "rv_plan_set_adam_split": (c_int, [c_void_p, c_int]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,

@@ -233,7 +233,7 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
   }
 }
 
-// Two virtual blocks per thread with all loads of both issued before the first dependent instruction (twice
+// U virtual blocks per thread with all loads of all of them issued before the first dependent instruction (twice
 // the bytes in flight per lane): for callers that walk the table with few resident threads (the optimizer blocks
 // of rv_linear_wgrad_adam get one 512-thread block per CU).  Same arithmetic as adam_block; anything off the
 // aligned 4-wide path (ragged row ends, bias rows summed by a wave) falls back to it.
@@ -268,15 +268,23 @@ __device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long
   return it;
 }
 
-__device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, const long vb1, const int tid,
-                                          float* __restrict__ param, float* __restrict__ m_arena,
-                                          float* __restrict__ v_arena, const float lr, const float grad_scale,
-                                          const long long* __restrict__ step_counter) {
-  const AdamItem it[2] = {adam_locate(tab, vb0, tid), adam_locate(tab, vb1, tid)};
-  if (it[0].state == 1 && it[1].state == 1) {
-    float4 m4[2], v4[2], w4[2], sl[2][4];
+template <int U>
+__device__ __forceinline__ void adam_group(const DescTable& tab, const long vb0, const long vb_stride, const int tid,
+                                           float* __restrict__ param, float* __restrict__ m_arena,
+                                           float* __restrict__ v_arena, const float lr, const float grad_scale,
+                                           const long long* __restrict__ step_counter) {
+  AdamItem it[U];
+  bool all_vec = true;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < U; ++u) {
+    it[u] = adam_locate(tab, vb0 + u * vb_stride, tid);
+    all_vec = all_vec && it[u].state != 2;   // state 0 (past the end of the table) is skipped item by item
+  }
+  if (all_vec) {
+    float4 m4[U], v4[U], w4[U], sl[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (it[u].state != 1) continue;
       const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it[u].t)];
       m4[u] = *reinterpret_cast<const float4*>(m_arena + it[u].o);
       v4[u] = *reinterpret_cast<const float4*>(v_arena + it[u].o);
@@ -290,7 +298,8 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
     float step_size, inv_bc2s;
     adam_step_consts(step_counter, lr, &step_size, &inv_bc2s);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
+      if (it[u].state != 1) continue;
       const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it[u].t)];
       float gv[4];
       if (d.grad_splits == 4) {  // the summation order of slab_sum4
@@ -322,10 +331,11 @@ __device__ __forceinline__ void adam_pair(const DescTable& tab, const long vb0, 
     }
     return;
   }
-  if (it[0].state)
-    adam_block<true>(tab, vb0, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
-  if (it[1].state)
-    adam_block<true>(tab, vb1, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter, nullptr, nullptr);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (it[u].state)
+      adam_block<true>(tab, vb0 + u * vb_stride, tid, param, m_arena, v_arena, nullptr, lr, grad_scale, step_counter,
+                       nullptr, nullptr);
 }
 
 // Parameters and every operand shadow of the table's tensors from a flat fp32 source (the all-gather's output):

@@ -118,8 +118,9 @@ gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable t
     const long total = tab.blk_start[tab.n];
     const long stride = 2L * ((long)gridDim.x - n_gemm);   // virtual blocks taken per sweep of the optimizer blocks
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // wave-uniform
-    for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += 2 * stride)
-      adam_pair(tab, vb, vb + stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter);
+    constexpr int U = 2;   // virtual blocks in flight per thread (4 measured 0.6 us slower: more registers, same bytes/s)
+    for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += U * stride)
+      adam_group<U>(tab, vb, stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter);
   }
 }
 

@@ -49,6 +49,7 @@ struct rv_plan {
   // side stream, ordered against the caller's stream with events (graph-capture safe)
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int adam_split = 1000;  // permille of fc4.weight's rows updated by the optimizer blocks of the dW1 launch
   int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
   // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
@@ -191,6 +192,37 @@ int rv_plan_set_concurrency(rv_plan* p, int enable) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
   p->concurrent = enable;
   return RV_OK;
+}
+
+int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldw, const float* bias_heads,
+                         long Bp, long Lp, long Kp, long B, long L, int splits, float* mulv_slabs,
+                         const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                         float* mulv, void* z_bf16, float* kl_partial, void* stream) {
+  RV_REQUIRE(mulv_slabs, RV_ERR_NULL, "rv_heads_reparam_fwd: null slab workspace");
+  const int rc = rv_linear_fwd_f32(h_bf16, ldh, wh_bf16, ldw, bias_heads, Bp, 2 * Lp, Kp, splits, mulv_slabs, 2 * Lp, stream);
+  if (rc) return rc;
+  return rv_reparam_fwd(mulv_slabs, splits, Bp, Lp, B, L, eps_in, eps_out, seed, step_counter, mulv, z_bf16, kl_partial,
+                        stream);
+}
+
+int rv_plan_set_adam_split(rv_plan* p, int permille) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_adam_split: null plan");
+  RV_REQUIRE(permille >= 0 && permille <= 1000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 1000]", permille);
+  p->adam_split = permille;
+  return RV_OK;
+}
+
+// Rows [0, r0) and [r0, rows) of one tensor as two descriptors (r0 * cols a multiple of 4 keeps both 16-byte aligned).
+static void split_rows(const rv_param_desc& d, long r0, rv_param_desc* top, rv_param_desc* bottom) {
+  *top = d;
+  top->rows = r0;
+  *bottom = d;
+  bottom->rows = d.rows - r0;
+  bottom->offset = d.offset + r0 * d.cols;
+  bottom->grad_slabs = (const float*)((const char*)d.grad_slabs + r0 * d.grad_ld * (d.grad_half ? 2 : 4));
+  if (d.shadow_bf16) bottom->shadow_bf16 = (char*)d.shadow_bf16 + r0 * d.shadow_ld * 2;
+  if (d.shadow_f32) bottom->shadow_f32 = d.shadow_f32 + r0 * d.shadow_ld;
+  if (d.shadow_fp8) bottom->shadow_fp8 = (char*)d.shadow_fp8 + r0 * d.shadow_ld;
 }
 
 int rv_plan_set_fp8(rv_plan* p, int enable) {
@@ -347,10 +379,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, nullptr, 0, stream));
     }
-    RV_TRY(rv_linear_fwd_f32(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, L2p, Hp, p->s_heads,
-                             mulv_slabs, L2p, stream));
-    RV_TRY(rv_reparam_fwd(mulv_slabs, p->s_heads, Bp, Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z,
-                          kl_part, stream));
+    RV_TRY(rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
+                                eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
     if (p->fr_hop) {
       if (p->fp8)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
@@ -405,10 +435,25 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // fc3 + fc4 ride along (92 MB at C2): an optimizer block streams ~25 GB/s from its CU, so half the chip
     // moves ~3 TB/s -- about what the GEMM blocks take to finish; the heads' update on top made the launch wait
     // for the optimizer (43 us against 36)
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, p->d_slab + 6, 4,
-                                p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter,
-                                256 - n_gemm, stream));
-    RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+    // How much rides along is a balance: the optimizer blocks get half the chip's CUs at ~20 GB/s each while the
+    // GEMM blocks need ~30 us, and the last launch updates at the whole chip's rate -- so only the first
+    // `adam_split` permille of fc4.weight's rows are updated here and the rest by the last launch.
+    rv_param_desc ride[4] = {p->d_slab[6], p->d_slab[7], p->d_slab[8], p->d_slab[9]}, last[7];
+    int n_last = 6;
+    for (int i = 0; i < 6; ++i) last[i] = p->d_slab[i];
+    const long r0 = (p->d_slab[8].rows * p->adam_split / 1000) & ~3L;
+    if (r0 < p->d_slab[8].rows) {
+      if (r0 > 0) {
+        split_rows(p->d_slab[8], r0, &ride[2], &last[n_last++]);
+      } else {
+        last[n_last++] = p->d_slab[8];
+        ride[2] = ride[3];   // fc3.weight, fc3.bias, fc4.bias
+      }
+    }
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, ride,
+                                r0 > 0 ? 4 : 3, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+                                p->b.step_counter, 256 - n_gemm, stream));
+    RV_TRY(rv_adam_multi(last, n_last, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     return RV_OK;
   }

@@ -136,6 +136,11 @@ class TrainEngine:
         onto a side stream beside the fc1 weight-gradient GEMM (measured slower at C2: 224 vs 217 us)."""
         lib().rv_plan_set_concurrency(self._plan, int(enable))
 
+    def set_adam_split(self, permille):
+        """Share (in 1/1000) of fc4.weight's rows whose Adam update rides in the fc1 weight-gradient launch; the rest
+        is updated by the step's last launch (`rv_plan_set_adam_split`; arithmetic unchanged, only the balance)."""
+        lib().rv_plan_set_adam_split(self._plan, int(permille))
+
     def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
         """Write entries of the fp8 state block (include/rawvae_hip.h, rv_plan_set_fp8).  Weight scales are
         normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""

@@ -273,6 +273,50 @@ def test_reparameterize(L):
     assert abs(e.mean()) < 0.15 and abs(e.std() - 1) < 0.15
 
 
+@pytest.mark.parametrize("B,Lt,K,splits", [(100, 3, 256, 2), (4096, 64, 2048, 4), (256, 256, 128, 1)])
+def test_heads_reparam_fwd(L, B, Lt, K, splits):
+    """rv_heads_reparam_fwd (model.py:21-26 + the KL term of :45): fc21 | fc22 as one GEMM, z = mu + eps * std and the
+    KL partials, against numpy on the same bf16-rounded operands; explicit eps and generated eps."""
+    rng = np.random.default_rng(8)
+    Bp, Lp = -(-B // 128) * 128, -(-Lt // 64) * 64
+    h = np.zeros((Bp, K), np.float32); h[:B] = rand_bf16(rng, (B, K), 0.5)
+    w = np.zeros((2 * Lp, K), np.float32)
+    w[:Lt] = rand_bf16(rng, (Lt, K), 0.05); w[Lp:Lp + Lt] = rand_bf16(rng, (Lt, K), 0.05)
+    bias = np.zeros(2 * Lp, np.float32)
+    bias[:Lt] = rng.standard_normal(Lt) * 0.1; bias[Lp:Lp + Lt] = rng.standard_normal(Lt) * 0.1
+    eps = rng.standard_normal((B, Lt)).astype(np.float32)
+    hd, wd, bd, ed = dev(h, torch.bfloat16), dev(w, torch.bfloat16), dev(bias), dev(eps)
+    slabs = torch.empty(splits, Bp, 2 * Lp, device="cuda")
+    mulv = torch.empty(Bp, 2 * Lp, device="cuda")
+    z = torch.empty(Bp, Lp, device="cuda", dtype=torch.bfloat16)
+    klp = torch.zeros(Bp * Lp // 1024, device="cuda")
+    ctr = torch.ones(1, dtype=torch.int64, device="cuda")
+    L.rv_heads_reparam_fwd(hd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), Bp, Lp, K, B, Lt, splits, slabs.data_ptr(),
+                           ed.data_ptr(), None, 0, ctr.data_ptr(), mulv.data_ptr(), z.data_ptr(), klp.data_ptr(), sp())
+    ref = h[:B].astype(np.float64) @ w.astype(np.float64).T + bias
+    mu, lv = ref[:, :Lt], ref[:, Lp:Lp + Lt]
+    got = mulv.cpu().numpy()
+    np.testing.assert_allclose(got[:B, :Lt], mu, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got[:B, Lp:Lp + Lt], lv, rtol=1e-5, atol=2e-5)
+    assert not got[B:].any() and not got[:, Lt:Lp].any() and not got[:, Lp + Lt:].any()
+    zr = O.bf16_round((mu + eps * np.exp(0.5 * lv)).astype(np.float32))
+    zg = z.float().cpu().numpy()
+    assert np.mean(zg[:B, :Lt] != zr) < 2e-3            # a last-bit fp32 difference may cross a bf16 rounding boundary
+    np.testing.assert_allclose(zg[:B, :Lt], zr, rtol=1e-2, atol=1e-6)
+    kl = float(klp.double().sum())
+    kl_ref = float(np.sum(1 + lv - mu ** 2 - np.exp(lv)))
+    assert abs(kl - kl_ref) <= 1e-5 * abs(kl_ref) + 1e-4
+    # generated eps (Philox, written to eps_out) reproduces z through the same formula
+    eo = torch.empty(B, Lt, device="cuda")
+    L.rv_heads_reparam_fwd(hd.data_ptr(), K, wd.data_ptr(), K, bd.data_ptr(), Bp, Lp, K, B, Lt, splits, slabs.data_ptr(),
+                           None, eo.data_ptr(), 77, ctr.data_ptr(), mulv.data_ptr(), z.data_ptr(), klp.data_ptr(), sp())
+    e2 = eo.cpu().numpy()
+    assert abs(e2.mean()) < 0.05 + 2.0 / np.sqrt(e2.size) and abs(e2.std() - 1) < 0.1
+    mv = mulv.cpu().numpy().astype(np.float64)
+    z2 = O.bf16_round((mv[:B, :Lt] + e2 * np.exp(0.5 * mv[:B, Lp:Lp + Lt])).astype(np.float32))
+    np.testing.assert_allclose(z.float().cpu().numpy()[:B, :Lt], z2, rtol=1e-2, atol=1e-6)
+
+
 def test_adam_multi_and_finalize(L):
     from rawaudiovae_kelsey_amd._lib import ParamDesc
     rng = np.random.default_rng(8)
