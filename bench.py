@@ -11,9 +11,11 @@ Workload (BASELINE.json configs[1] / configs[2]): S=1024, H=2048, L=64, per-GPU 
 A step is one pass of the hot path over one resident batch (a pool of 8 distinct
 device-resident batches is cycled); eps is drawn on-device: one host call per step
 (`rv_plan_step`) enqueues its 12 kernels back to back on one stream (`--graph` replays them from a
-hipGraph instead; measured ~6 us/step slower).  One process per GPU; with N > 1 each step is one
-`rv_plan_step_ddp` call that also issues the two RCCL all-reduces of the fp32 gradients (fc4 | rest)
-as backward produces them (weak scaling: per-GPU batch fixed).
+hipGraph instead: the kernels run as fast, but consecutive replays are ~8 us apart where eager launches
+are back to back -- profiles/r02_graph_vs_eager_timeline.txt).  One process per GPU; with N > 1 each
+step is one `rv_plan_step_ddp` call that also issues the RCCL collectives as backward produces the
+gradients (default: sharded optimizer = reduce-scatter, Adam on the local shard, all-gather; the
+all-reduce schedule is timed beside it as `alt_allreduce`).  Weak scaling: per-GPU batch fixed.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the paired fc4
 backward GEMM launch, the longest kernel of the step), timed live with HIP events; `cpu_baseline`
@@ -42,8 +44,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", action="store_true",
-                    help="replay each step from a hipGraph (N=1); measured 217 us vs 211 us for back-to-back eager "
-                         "launches of the same 14 kernels, so eager is the default")
+                    help="replay each step from a hipGraph (N=1); ~8 us/step slower than back-to-back eager launches "
+                         "of the same 12 kernels (gap between replays), so eager is the default")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
     ap.add_argument("--adam-split", type=int, default=None,
