@@ -52,9 +52,11 @@ def parse():
                     help="permille of fc4.weight rows whose Adam update rides in the fc1 wgrad launch (default: library's)")
     ap.add_argument("--sched", type=int, default=0,
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
-    ap.add_argument("--fp8", action="store_true",
-                    help="also time the step with fc1 / fc4 forward on fp8 (e4m3) operands and report it as the side "
-                         "line `alt_fp8` (BASELINE configs[4]); the headline stays bf16")
+    ap.add_argument("--fp8", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--no-alts", action="store_true",
+                    help="skip the side lines `alt_fp8` (fc1 / fc4 forward on e4m3 operands, BASELINE configs[4]), "
+                         "`alt_fp16_slabs` and `alt_fp8_fp16_slabs`; they are timed after the headline at N=1 and never "
+                         "replace it")
     ap.add_argument("--slab-dtype", default=None, choices=["fp32", "fp16"],
                     help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
     ap.add_argument("--n128-loop", type=int, default=0,
@@ -329,26 +331,36 @@ def main():
             finally:
                 runner.set_payload("fp32")
         kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
-        alt_fp8 = None
-        if args.fp8 and world == 1:
-            eng8 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, fp8=True)
-            eng8.load_params(make_params(S, H, L, 0))
-            for i in range(args.warmup + 5):
-                eng8.step(pool[i % POOL], stream=comp)
-            torch.cuda.synchronize()
-            reps8 = []
-            for r in range(max(5, min(len(passes), 50))):
-                t0 = time.perf_counter()
-                for i in range(args.steps):
-                    eng8.step(pool[(r * args.steps + i) % POOL], stream=comp)
-                torch.cuda.synchronize()
-                reps8.append(time.perf_counter() - t0)
-            reps8.sort()
-            m8 = reps8[len(reps8) // 2]
-            alt_fp8 = {"what": "fc1 and fc4 forward on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor "
-                               "scales, delayed activation scaling); backward and everything else bf16",
-                       "ms_per_step": m8 / args.steps * 1e3, "value": float(B) * args.steps / m8,
-                       "final_loss": eng8.losses(1)[-1], "repeats": len(reps8)}
+        # Side lines, never the headline: the same K steps on engines with opt-in reduced-precision storage
+        alts = {}
+        if world == 1 and not args.no_alts:
+            def time_alt(what, **kw):
+                try:
+                    e2 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **kw)
+                    e2.load_params(make_params(S, H, L, 0))
+                    for i in range(args.warmup + 5):
+                        e2.step(pool[i % POOL], stream=comp)
+                    torch.cuda.synchronize()
+                    reps = []
+                    for r in range(max(5, min(len(passes), 50))):
+                        t0 = time.perf_counter()
+                        for i in range(args.steps):
+                            e2.step(pool[(r * args.steps + i) % POOL], stream=comp)
+                        torch.cuda.synchronize()
+                        reps.append(time.perf_counter() - t0)
+                    reps.sort()
+                    med = reps[len(reps) // 2]
+                    return {"what": what, "ms_per_step": med / args.steps * 1e3, "value": float(B) * args.steps / med,
+                            "final_loss": e2.losses(1)[-1], "repeats": len(reps)}
+                except Exception as exc:   # the headline is already measured: report, do not lose it
+                    return {"what": what, "error": str(exc)[:200]}
+            alts["alt_fp8"] = time_alt(
+                "fc1 and fc4 forward on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor scales, delayed "
+                "activation scaling); backward and everything else bf16", fp8=True)
+            alts["alt_fp16_slabs"] = time_alt(
+                "split-K partial sums of dW1 / dW4 stored as fp16(partial * 4096) instead of fp32 (summed in fp32 by "
+                "Adam); everything else as the headline", slab_dtype="fp16")
+            alts["alt_fp8_fp16_slabs"] = time_alt("both of the above", fp8=True, slab_dtype="fp16")
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
         print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)
@@ -364,7 +376,9 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_traffic.json")))
+            cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]*_traffic.json")),
+                          key=lambda f: os.path.basename(f).replace("_traffic", "_v0_traffic")
+                          if "_v" not in os.path.basename(f) else os.path.basename(f))
             with open(cand[-1]) as f:
                 traffic = json.load(f)["traffic_bytes"]
             traffic_src = "profiles/%s (PMC passes of an earlier builder run, not this run)" % os.path.basename(cand[-1])
@@ -388,7 +402,7 @@ def main():
                        "timed_seconds_total": sum(passes)},
             "host_us_per_step": host_dt / args.steps * 1e6,
             **({("alt_allreduce" if getattr(runner, "sharded", False) else "alt_bf16_payload"): alt} if alt else {}),
-            **({"alt_fp8": alt_fp8} if alt_fp8 else {}),
+            **alts,
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None)}
                if world > 1 or force_ddp else {}),

@@ -195,6 +195,15 @@ int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, 
                    float* dbh_partial, const float* mse_partial, int n_mse,
                    const float* kl_partial, int n_kl, float* loss_out,
                    const long long* step_counter, int ring, void* stream);
+/* The same with gradients that arrive from outside added in (exact [B, L] fp32, either may be NULL):
+ * dmu += dmu_ext, dlv += dlv_ext -- what autograd hands the backward of reparameterize when mu / logvar also feed
+ * a loss term directly (the KL half of loss_function, model.py:45).  Pass kl_beta = 0 when the KL gradient is
+ * already inside dmu_ext / dlv_ext. */
+int rv_reparam_bwd_ext(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
+                       const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
+                       const float* dlv_ext, void* dmulv_bf16, float* dbh_partial, const float* mse_partial,
+                       int n_mse, const float* kl_partial, int n_kl, float* loss_out,
+                       const long long* step_counter, int ring, void* stream);
 
 /* loss_function(recon_x, x, mu, logvar, kl_beta, segment_length), model.py:38-47, as ONE
  * wave-reduced kernel over exact-shape fp32 tensors; also emits the gradients autograd
@@ -291,7 +300,9 @@ int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, lon
 /* Sharded data-parallel optimizer (rv_plan_step_ddp in sharded mode; also callable on their own):
  * rv_adam_flat: the Adam update of elements [lo, lo + n) of the flat arenas, gradient element i of the shard at
  *   grad_shard[i] (a reduce-scatter's output), multiplied by grad_scale first.
- * rv_params_from_flat: parameters AND every operand shadow of the `descs` tensors from a flat fp32 source (an
+ * rv_params_from_flat: parameters (unless `param` is NULL: shadows only; `flat` may then be the parameter arena
+ *   itself, which is how rv_plan_refresh_shadows rebuilds all shadows in one launch) AND every operand shadow of the
+ *   `descs` tensors from a flat fp32 source (an
  *   all-gather's output): arena element o is flat[o - flat_base]. */
 int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
                  float grad_scale, const long long* step_counter, void* stream);
@@ -405,6 +416,14 @@ int rv_plan_set_concurrency(rv_plan*, int enable);
  * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch.  Same arithmetic
  * either way; the value only balances the two launches. */
 int rv_plan_set_adam_split(rv_plan*, int permille);
+/* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
+ * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and
+ * dlogvar [B,L], all exact-shape fp32, each NULL = zero; the reparameterisation backward then takes kl_beta from
+ * the rv_plan_step call (pass 0 when dmu / dlogvar already hold the KL gradient).  grad_out (or NULL = the bound
+ * grad arena) receives the FINALIZE phases' flat fp32 gradients.  All NULL restores the fused loss of the forward
+ * phase.  Not honoured by the full-step schedules (phases == RV_PHASE_ALL_LOCAL). */
+int rv_plan_set_external_grads(rv_plan*, const float* d_recon, const float* recon, const float* dmu,
+                               const float* dlogvar, float* grad_out);
 /* fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay bf16).
  * The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
  *   [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)

@@ -129,6 +129,10 @@ _SIGS = {
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_set_adam_split": (c_int, [c_void_p, c_int]),
+    "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
+    "rv_reparam_bwd_ext": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
+                                   c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                   c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,

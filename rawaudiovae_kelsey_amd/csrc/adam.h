@@ -338,11 +338,11 @@ __device__ __forceinline__ void adam_group(const DescTable& tab, const long vb0,
                        nullptr, nullptr);
 }
 
-// Parameters and every operand shadow of the table's tensors from a flat fp32 source (the all-gather's output):
-// element at flat arena offset o is flat[o - flat_base].  One virtual block = 256 threads, 4 elements each.
+// Parameters (unless `param` is null) and every operand shadow of the table's tensors from a flat fp32 source (the
+// all-gather's output, or the parameter arena itself): element at flat arena offset o is flat[o - flat_base].
+// One virtual block = 256 threads, 4 elements each.  No __restrict__: `flat` may be the parameter arena.
 __device__ __forceinline__ void refresh_block(const DescTable& tab, const long vblock, const int tid,
-                                              const float* __restrict__ flat, const long flat_base,
-                                              float* __restrict__ param) {
+                                              const float* flat, const long flat_base, float* param) {
   int t = 0;
   while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
   t = __builtin_amdgcn_readfirstlane(t);
@@ -352,17 +352,30 @@ __device__ __forceinline__ void refresh_block(const DescTable& tab, const long v
   const long blk = vblock - tab.blk_start[t];
   const long grp = coop ? blk * 4 + (tid >> 6) : blk * 256 + tid;
   if (grp >= gpr * d.rows || (coop && (tid & 63) != 0)) return;
-  const long r = grp / gpr, c = (grp % gpr) * 4;
+  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
+  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
   const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
   const long o = d.offset + r * d.cols + c;
   float wv[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < nvalid; ++j) {
-    wv[j] = flat[o - flat_base + j];
-    param[o + j] = wv[j];
+  const bool vec = nvalid == 4 && (((o - flat_base) | o) & 3) == 0 && ((reinterpret_cast<uintptr_t>(flat) & 15) == 0);
+  if (vec) {
+    const float4 w4 = *reinterpret_cast<const float4*>(flat + (o - flat_base));
+    wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+    if (param) *reinterpret_cast<float4*>(param + o) = w4;
+  } else {
+    for (int j = 0; j < nvalid; ++j) {
+      wv[j] = flat[o - flat_base + j];
+      if (param) param[o + j] = wv[j];
+    }
   }
   if (d.shadow_bf16) {
     bf16_t* sp = reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c;
-    for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
+    if (nvalid == 4 && (d.shadow_ld & 3) == 0) {
+      const bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+      *reinterpret_cast<bf16x4*>(sp) = b4;
+    } else {
+      for (int j = 0; j < nvalid; ++j) sp[j] = (bf16_t)wv[j];
+    }
   }
   if (d.shadow_f32)
     for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];

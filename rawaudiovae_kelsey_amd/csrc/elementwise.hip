@@ -269,7 +269,8 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
               bf16_t* __restrict__ dmulv, float* __restrict__ dbh_partial,
               const float* __restrict__ mse_partial, int n_mse,
               const float* __restrict__ kl_partial, int n_kl, float* __restrict__ loss_out,
-              const long long* __restrict__ step_counter, int ring) {
+              const long long* __restrict__ step_counter, int ring,
+              const float* __restrict__ dmu_ext, const float* __restrict__ dlv_ext) {
   __shared__ float sh[2 * 256 * 4];
   const int tid = threadIdx.x;
   const long L2p = 2 * Lp;
@@ -300,6 +301,8 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
           const float sd = __expf(0.5f * lva[j]);
           dmu[j] = dza[j] + kl_beta * mua[j] * inv_nk;
           dlv[j] = dza[j] * e * 0.5f * sd + kl_beta * 0.5f * (sd * sd - 1.f) * inv_nk;
+          if (dmu_ext) dmu[j] += dmu_ext[b * L + l + j];   // gradients arriving from outside (autograd)
+          if (dlv_ext) dlv[j] += dlv_ext[b * L + l + j];
         }
       }
     }
@@ -571,7 +574,7 @@ k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __res
 }
 
 __global__ void __launch_bounds__(256)
-k_params_from_flat(const DescTable tab, const float* __restrict__ flat, const long flat_base, float* __restrict__ param) {
+k_params_from_flat(const DescTable tab, const float* flat, const long flat_base, float* param) {
   refresh_block(tab, (long)blockIdx.x, (int)threadIdx.x, flat, flat_base, param);
 }
 
@@ -701,13 +704,22 @@ int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, 
                    float* dbh_partial, const float* mse_partial, int n_mse,
                    const float* kl_partial, int n_kl, float* loss_out,
                    const long long* step_counter, int ring, void* stream) {
+  return rv_reparam_bwd_ext(dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta, nullptr, nullptr, dmulv, dbh_partial,
+                            mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring, stream);
+}
+
+int rv_reparam_bwd_ext(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
+                       const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
+                       const float* dlv_ext, void* dmulv, float* dbh_partial, const float* mse_partial, int n_mse,
+                       const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,
+                       void* stream) {
   RV_REQUIRE(dz_slabs && mulv && eps && dmulv, RV_ERR_NULL, "rv_reparam_bwd: null pointer");
   RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && Bp % RB_ROWS == 0 && 256 % Lp == 0, RV_ERR_SHAPE,
              "rv_reparam_bwd: bad extents (Lp must divide 256)");
   hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / RB_ROWS)), dim3(256), 0,
                      (hipStream_t)stream, dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta,
                      (bf16_t*)dmulv, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
-                     step_counter, ring);
+                     step_counter, ring, dmu_ext, dlv_ext);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -843,7 +855,7 @@ int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* g
 
 int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
                         void* stream) {
-  RV_REQUIRE(flat && param, RV_ERR_NULL, "rv_params_from_flat: null pointer");
+  RV_REQUIRE(flat, RV_ERR_NULL, "rv_params_from_flat: null pointer");
   DescTable tab;
   int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;

@@ -49,6 +49,12 @@ struct rv_plan {
   // side stream, ordered against the caller's stream with events (graph-capture safe)
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // gradients supplied by the caller for the next backward phases (rv_plan_set_external_grads); all null = the
+  // fused loss of the forward phase
+  const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
+  const float* ext_dmu = nullptr; const float* ext_dlv = nullptr;
+  float* ext_grad_out = nullptr;
+  bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   int adam_split = 1000;  // permille of fc4.weight's rows updated by the optimizer blocks of the dW1 launch
   int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
@@ -205,6 +211,14 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
                         stream);
 }
 
+int rv_plan_set_external_grads(rv_plan* p, const float* d_recon, const float* recon, const float* dmu,
+                               const float* dlogvar, float* grad_out) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_external_grads: null plan");
+  RV_REQUIRE(!d_recon || recon, RV_ERR_NULL, "rv_plan_set_external_grads: d_recon needs recon (tanh')");
+  p->ext_d_recon = d_recon; p->ext_recon = recon; p->ext_dmu = dmu; p->ext_dlv = dlogvar; p->ext_grad_out = grad_out;
+  return RV_OK;
+}
+
 int rv_plan_set_adam_split(rv_plan* p, int permille) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_adam_split: null plan");
   RV_REQUIRE(permille >= 0 && permille <= 1000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 1000]", permille);
@@ -311,6 +325,9 @@ int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
 int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_refresh_shadows: plan not bound");
   hipStream_t st = (hipStream_t)stream;
+  // after the first refresh the padding of every shadow is zero and stays zero (nothing writes it): one launch
+  // rewrites the valid elements of all ten shadows from the parameter arena
+  if (p->shadows_padded) return rv_params_from_flat(p->d_slab, 10, p->b.param, 0, nullptr, stream);
   for (int i = 0; i < 10; ++i) {
     const rv_param_desc& d = p->d_slab[i];
     const float* src = p->b.param + d.offset;
@@ -332,6 +349,7 @@ int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
       RV_HIP(hipMemcpyAsync(d.shadow_f32, src, d.cols * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
   }
+  p->shadows_padded = true;
   return RV_OK;
 }
 
@@ -417,9 +435,12 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  (float*)p->ws("dWh"), Hp, p->s_wh, st);
   };
+  RV_REQUIRE(!(full_local && (p->ext_d_recon || p->ext_dmu || p->ext_dlv)), RV_ERR_STATE,
+             "rv_plan_step: external gradients are set (rv_plan_set_external_grads); run the backward phases without ADAM");
   auto reparam_bwd = [&](void* st) {
-    return rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
-                          mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, st);
+    return rv_reparam_bwd_ext(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, dmulv,
+                              (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
+                              p->b.step_counter, p->b.ring, st);
   };
   if (full_local && p->concurrent == 0 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) &&
       (Hp / 256) * (Sp / 256) * p->s_w1 <= 192) {
@@ -509,6 +530,13 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const bool do_chain_a = old_a || (phases & RV_PHASE_BWD_CHAIN);   // dz, reparam_bwd
   const bool do_chain_b = old_b || (phases & RV_PHASE_BWD_CHAIN);   // heads dgrad + wgrad (one launch), fc1 wgrad
   const bool do_w3 = old_a || (phases & RV_PHASE_BWD_REST);         // fc3 wgrad
+  if (do_pair && p->ext_d_recon) {
+    // dP4 = d_recon * (1 - recon^2) and its column sums (fc4.bias) from the caller's gradient instead of the
+    // forward's fused MSE gradient; the partial-sum rows this does not write are zero
+    RV_HIP(hipMemsetAsync(p->ws("db4p"), 0, (size_t)p->n_mt4 * Sp * sizeof(float), (hipStream_t)stream));
+    RV_TRY(rv_tanh_bwd_pack(p->ext_d_recon, p->ext_recon, B, S, dP4, Bp, Sp, stream));
+    RV_TRY(rv_colsum_partial(dP4, 1, Bp, Sp, Sp, (float*)p->ws("db4p"), Sp, stream));
+  }
   if (do_pair)
     RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
@@ -538,14 +566,15 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (phases & RV_PHASE_ADAM_FC4) adam |= 0x300;
   if (phases & RV_PHASE_ADAM_FC1) adam |= 0x003;
   if (phases & RV_PHASE_ADAM_MID) adam |= 0x0FC;
-  if (fin) RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
+  float* fin_out = p->ext_grad_out ? p->ext_grad_out : p->b.grad;
+  if (fin) RV_REQUIRE(fin_out, RV_ERR_STATE, "rv_plan_step: FINALIZE needs a grad arena");
   if (adam) RV_REQUIRE(!adam_from_flat || p->b.grad, RV_ERR_STATE, "rv_plan_step: adam_from_flat needs a grad arena");
   const rv_param_desc* ad = adam_from_flat ? p->d_flat : p->d_slab;
   for (int i = 0; i < 10;) {   // contiguous runs of selected tensors -> one launch each
     if (!((fin >> i) & 1)) { ++i; continue; }
     int j = i;
     while (j < 10 && ((fin >> j) & 1)) ++j;
-    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, p->b.grad, stream));
+    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, fin_out, stream));
     i = j;
   }
   for (int i = 0; i < 10;) {

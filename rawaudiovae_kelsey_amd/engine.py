@@ -301,8 +301,12 @@ class TrainEngine:
 
     def outputs(self):
         """mu, logvar of the last forward as exact-shape fp32 copies."""
-        Bp, Sp, Hp, Lp = self.padded()
-        mulv = self.buffer("mulv", torch.float32, (Bp, 2 * Lp))
+        mulv = getattr(self, "_mulv_view", None)
+        if mulv is None:
+            Bp, Sp, Hp, Lp = self.padded()
+            mulv = self._mulv_view = self.buffer("mulv", torch.float32, (Bp, 2 * Lp))
+            self._lp = Lp
+        Lp = self._lp
         return mulv[:self.B, :self.L].contiguous(), mulv[:self.B, Lp:Lp + self.L].contiguous()
 
     def steps_done(self):

@@ -1,0 +1,144 @@
+"""`VAE.forward` under autograd as ONE graph node backed by a step plan.
+
+The reference's training loop (train.py:184-193) is
+
+    optimizer.zero_grad(); recon, mu, logvar = model(x)
+    loss = loss_function(recon, x, mu, logvar, kl_beta, S); loss.backward(); optimizer.step()
+
+Run through one autograd Function per layer group (ops.EncodeFn / ReparamFn / DecodeFn) that loop costs ~60
+kernel launches and ~1 ms of host time per step at C2.  Here the forward is one host call -- the FWD phase of
+`rv_plan_step` (cast, fc1, heads, reparam, fc3, fc4: the six kernels the fused engine runs) -- and the backward is
+one more: `rv_plan_set_external_grads` hands the plan whatever gradients autograd delivers for (recon, mu, logvar)
+-- any loss, not only `loss_function` -- and the BWD + FINALIZE phases produce all ten parameter gradients
+(paired fc4 backward, latent pair, reparam backward, heads pair, fc1 weight gradient, one finalize launch).
+The optimizer stays the caller's (`torch.optim.Adam` in the reference): the module's Parameters are re-pointed
+at the plan's fp32 arena (`TrainEngine.adopt`, state_dict keys / layouts unchanged) and the bf16 operand shadows
+are rebuilt when a Parameter's version counter has moved.
+
+Limits (the per-layer Functions remain the general path and are used automatically otherwise): the input must
+not require grad, every parameter must, and `backward` must run before the next fused `forward` of the same
+batch size on the same module (activations live in the plan's workspace; a second forward overwrites them --
+the error says so; set `model.fused_training = False` for such loops).
+"""
+import collections
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import (PHASE_BWD_A, PHASE_BWD_B, PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, lib, ptr, stream_ptr)
+from .engine import PARAM_NAMES, TrainEngine
+
+MAX_ENGINES = 4          # distinct batch sizes kept per module (each owns a workspace)
+_HOLDERS = weakref.WeakKeyDictionary()   # module -> _Holder; off the module so that it pickles as before
+
+
+def _params(module):
+    return (module.fc1.weight, module.fc1.bias, module.fc21.weight, module.fc21.bias, module.fc22.weight,
+            module.fc22.bias, module.fc3.weight, module.fc3.bias, module.fc4.weight, module.fc4.bias)
+
+
+class _Holder:
+    def __init__(self):
+        self.engines = collections.OrderedDict()   # batch size -> TrainEngine (all share the first one's arenas)
+        self.ptrs = None
+        self.versions = None
+
+    def engine(self, module, B, params):
+        eng = self.engines.get(B)
+        dev = params[0].device
+        if eng is not None and eng.device != dev:
+            self.engines.clear()
+            eng = None
+        if eng is None:
+            base = next(iter(self.engines.values()), None)
+            eng = TrainEngine(module.segment_length, module.n_units, module.latent_dim, B, device=dev, kl_beta=0.0,
+                              lr=0.0, seed=module._rng_seed, grad_arena=False, share=base)
+            self.engines[B] = eng
+            while len(self.engines) > MAX_ENGINES:
+                self.engines.popitem(last=False)
+        else:
+            self.engines.move_to_end(B)
+        ptrs = tuple(p.data_ptr() for p in params)
+        if ptrs != self.ptrs:           # first use, or .to() / .cpu().cuda() / a swapped .data since
+            eng.adopt(module)
+            self.ptrs = tuple(p.data_ptr() for p in params)
+            self.versions = None
+        vers = tuple(p._version for p in params)
+        if vers != self.versions:       # optimizer.step / load_state_dict / any in-place write
+            eng.params_changed()
+            self.versions = vers
+        return eng
+
+
+def fusable(module, x2):
+    if not getattr(module, "fused_training", True) or not torch.is_grad_enabled():
+        return False
+    if not x2.is_cuda or x2.requires_grad or x2.dtype != torch.float32 or x2.shape[0] == 0:
+        return False
+    if module.latent_dim > 256:
+        return False
+    for p in _params(module):
+        if not p.requires_grad or p.dtype != torch.float32 or p.device != x2.device:
+            return False
+    return True
+
+
+class VaeFn(torch.autograd.Function):
+    """(recon, mu, logvar) = VAE.forward(x) -- rawvae/model.py:19-35 -- on a step plan."""
+
+    @staticmethod
+    def forward(ctx, x, eps, eng, *params):
+        B = x.shape[0]
+        recon = torch.empty((B, eng.S), dtype=torch.float32, device=x.device)
+        eng.step(x, eps=eps, recon_out=recon, phases=PHASE_FWD)
+        mu, logvar = eng.outputs()
+        ctx.eng, ctx.tick, ctx.eps = eng, eng.host_steps, eps
+        ctx.save_for_backward(recon)
+        return recon, mu, logvar
+
+    @staticmethod
+    def backward(ctx, d_recon, d_mu, d_lv):
+        eng = ctx.eng
+        if eng.host_steps != ctx.tick:
+            raise _lib.RvError(
+                "rawvae fused forward: backward() reached a forward pass whose activations a later forward of the "
+                "same batch size has overwritten. Call backward() before the next model(x), or set "
+                "`model.fused_training = False` to use the per-layer autograd path.")
+        (recon,) = ctx.saved_tensors
+        dev = recon.device
+
+        def f32c(t, shape):
+            if t is None:
+                return torch.zeros(shape, dtype=torch.float32, device=dev)
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+        d_recon = f32c(d_recon, recon.shape)
+        d_mu = None if d_mu is None else f32c(d_mu, None)
+        d_lv = None if d_lv is None else f32c(d_lv, None)
+        grad = torch.empty(eng.n_params, dtype=torch.float32, device=dev)
+        L_ = lib()
+        L_.rv_plan_set_external_grads(eng._plan, ptr(d_recon), ptr(recon), ptr(d_mu), ptr(d_lv), ptr(grad))
+        try:
+            L_.rv_plan_step(eng._plan, PHASE_BWD_A | PHASE_BWD_B | PHASE_FINALIZE_A | PHASE_FINALIZE_B, None,
+                            ptr(ctx.eps), None, 0.0, 0.0, 1.0, 0, eng.seed, stream_ptr())
+        finally:
+            L_.rv_plan_set_external_grads(eng._plan, None, None, None, None, None)
+        out = [None, None, None]
+        for i, k in enumerate(PARAM_NAMES):
+            out.append(eng.view(grad, k) if ctx.needs_input_grad[3 + i] else None)
+        return tuple(out)
+
+
+def forward(module, x2, eps=None):
+    """`VAE.forward` body for a fusable call: x2 is [B, S] fp32 on the module's device."""
+    holder = _HOLDERS.get(module)
+    if holder is None:
+        holder = _HOLDERS[module] = _Holder()
+    params = _params(module)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    if eps is not None:
+        eps = eps.reshape(x2.shape[0], module.latent_dim)
+        eps = eps if (eps.dtype == torch.float32 and eps.is_contiguous()) else eps.contiguous().float()
+    eng = holder.engine(module, x2.shape[0], params)
+    eng.seed = module._rng_seed
+    return VaeFn.apply(x2, eps, eng, *params)

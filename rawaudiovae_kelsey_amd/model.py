@@ -15,6 +15,10 @@ accumulation; calls under `torch.no_grad()` -- the reference's eval reconstructi
 exact-fp32 kernels (`rv_linear_fp32`), so inference outputs match the reference to fp32 summation
 order.  Set `model.inference_precision = "bf16"` to use the bf16 kernels there too.
 
+`forward` under autograd (the training loop, train.py:184-193) runs as ONE autograd node on a step plan
+(fused.py: the fused engine's forward kernels, and its backward kernels fed with whatever gradients autograd
+delivers); `model.fused_training = False` selects the per-layer Functions instead.
+
 Added (optional, keyword-only): an explicit `eps` for `reparameterize`/`forward`
 (parity runs: the reference draws it from torch's global generator, model.py:25),
 and `VAE.engine(batch_size, ...)`, which returns the fused whole-step
@@ -25,7 +29,7 @@ The module computes on the GPU only; CPU tensors raise (there is no fallback).
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fused, ops
 
 
 class VAE(nn.Module):
@@ -69,7 +73,13 @@ class VAE(nn.Module):
         return ops.DecodeFn.apply(z2, self.fc3.weight, self.fc3.bias, self.fc4.weight, self.fc4.bias)
 
     def forward(self, x, eps=None):
-        mu, logvar = self.encode(x.view(-1, self.segment_length))
+        x2 = x.view(-1, self.segment_length)
+        if fused.fusable(self, x2):
+            # training: the whole forward is one autograd node on a step plan (fused.py); same arithmetic as the
+            # three per-layer Functions below, ~6 launches instead of ~25 and one host call
+            self._rng_calls += 1
+            return fused.forward(self, x2, eps)
+        mu, logvar = self.encode(x2)
         z = self.reparameterize(mu, logvar, eps)
         return self.decode(z), mu, logvar
 

@@ -15,6 +15,7 @@ S, H, L, B = 1024, 2048, 64, 4096
 m = VAE(S, H, L)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(S, H, L, 0).items()})
 m = m.cuda()
+m.fused_training = os.environ.get("RV_API_FUSED", "1") != "0"
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 xs = [torch.from_numpy(make_frames(B, S, i)).cuda() for i in range(4)]
 
@@ -37,5 +38,6 @@ for i in range(n):
     loss = step(xs[i % 4])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("API path (autograd Functions + torch.optim.Adam): %.1f us/step, %.2f M frames/s, loss %.5f"
-      % (dt * 1e6, B / dt / 1e6, loss.item()))
+print("API path, reference loop unchanged (%s + torch.optim.Adam): %.1f us/step, %.2f M frames/s, loss %.5f"
+      % ("one autograd node on a step plan" if getattr(m, "fused_training", True) else "per-layer autograd Functions",
+         dt * 1e6, B / dt / 1e6, loss.item()))

@@ -11,11 +11,11 @@ PY
 }
 {
 echo "== schedules (bench.py --sched: 0 default = fc1 wgrad launch carries Adam(fc3,fc4); 3 = round-1 single stream; 2 = two streams), interleaved twice"
-for i in 1 2; do for s in 3 0 2; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --sched $s > $O/tmp_b.json 2>/dev/null; line "sched $s" $O/tmp_b.json; done; done
+for i in 1 2; do for s in 3 0 2; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-alts --sched $s > $O/tmp_b.json 2>/dev/null; line "sched $s" $O/tmp_b.json; done; done
 echo "== split-K slab dtype of dW1/dW4"
-for i in 1 2; do for d in fp32 fp16; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --slab-dtype $d > $O/tmp_b.json 2>/dev/null; line "slabs $d" $O/tmp_b.json; done; done
+for i in 1 2; do for d in fp32 fp16; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-alts --slab-dtype $d > $O/tmp_b.json 2>/dev/null; line "slabs $d" $O/tmp_b.json; done; done
 echo "== 256x128 main loop (3 ring = default, 9 ping-pong)"
-for i in 1 2; do for l in 3 9; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --n128-loop $l > $O/tmp_b.json 2>/dev/null; line "n128 loop $l" $O/tmp_b.json; done; done
+for i in 1 2; do for l in 3 9; do python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-alts --n128-loop $l > $O/tmp_b.json 2>/dev/null; line "n128 loop $l" $O/tmp_b.json; done; done
 } > $O/r02_ab_step.txt 2>&1
 {
 for l in 3 9 3 9; do echo "== 256x128 main loop $l (tools/gemm_bench.py, stand-alone GEMMs, split-K 4 weight gradients)"; RV_N128=$l SPL_w1=4 SPL_w4=4 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; done
