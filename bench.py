@@ -181,10 +181,57 @@ def main():
                 reasons = [None] * world
                 dist.all_gather_object(reasons, my_reason)
                 native_fallback_reason = "; ".join(r for r in reasons if r) or "another rank failed"
+        sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
+        if ok and os.environ.get("RV_DDP_CHECK", "1") == "1":
+            # The library-driven step has only ever run on ONE rank before this job (one-GPU development boxes), so
+            # before it is timed it is checked here, on scratch engines: three steps of it against three steps of the
+            # torch.distributed path from the same weights on the same batches.  Replicas must end bit-identical and
+            # the two paths' parameters must agree (Adam moves every element by ~lr per step, so agreement is a
+            # mean |difference| far below lr; elements whose tiny gradient changes sign between two summation
+            # orders differ by 2 lr each).  A failing mode is dropped for the next one and the JSON says why.
+            def checked(mode_sharded):
+                ea = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=7, ring=16)
+                eb = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=7, ring=16)
+                for e in (ea, eb):
+                    e.load_params(make_params(S, H, L, 0))
+                ra = ddp.NativeDdpRunner(ea, comm, comp, sharded=mode_sharded)
+                rb = ddp.DdpRunner(eb, ddp.GradSync(eb.grad, ddp.engine_buckets(eb)), comp, use_graphs=False)
+                with torch.cuda.stream(comp):   # same seed and step counters: both engines draw the same eps
+                    for i in range(3):
+                        ra.step(pool[i % POOL])
+                        rb.step(pool[i % POOL])
+                torch.cuda.synchronize()
+                chk = torch.stack([ea.param.double().sum(), ea.param.double().abs().sum()])
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                same = bool(torch.equal(lo, hi))
+                diff = float((ea.param - eb.param).abs().mean())
+                worst = torch.tensor([diff], dtype=torch.float64, device=dev)
+                dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+                diff = float(worst.item())
+                good = same and diff < 0.05 * LR
+                return good, "replicas %s, mean |param - torch.distributed path| = %.3g (lr %.1g)" % (
+                    "identical" if same else "DIVERGED", diff, LR)
+            try:
+                good, note = checked(sharded)
+                if not good and sharded:
+                    native_fallback_reason = "sharded step failed the startup check (%s); all-reduce schedule used" % note
+                    sharded = False
+                    good, note = checked(False)
+                if not good:
+                    native_fallback_reason = ((native_fallback_reason or "") +
+                                              " native all-reduce step failed the startup check (%s)" % note).strip()
+                    ok = 0
+            except Exception as exc:
+                native_fallback_reason = "startup check raised %s: %s" % (type(exc).__name__, str(exc)[:300])
+                ok = 0
+            flag = torch.tensor([ok, int(sharded)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok, sharded = int(flag[0].item()), bool(int(flag[1].item()))
         if ok:
             # RV_DDP_MODE=sharded (default): sharded optimizer -- reduce-scatter gradients, Adam on 1/world of the
             # arena per rank, all-gather parameters; =allreduce: all-reduce + the full update on every rank
-            sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
             runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1", sharded=sharded)
             ddp_mode = ("sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the arena -> "
                         "fp32 all-gather of the parameters, all issued by rv_plan_step_ddp on its own stream" % world) \
@@ -404,7 +451,8 @@ def main():
             **({("alt_allreduce" if getattr(runner, "sharded", False) else "alt_bf16_payload"): alt} if alt else {}),
             **alts,
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
-            **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None)}
+            **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None),
+                "comm_stream_pick": [{"us_per_round_trip": u, "candidates_tried": n} for u, n in ddp.comm_stream_report()]}
                if world > 1 or force_ddp else {}),
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,
             "step_mfma_frac": value * flops_per_frame(S, H, L) / 1e12 / (PEAK_BF16_TFLOPS * world),

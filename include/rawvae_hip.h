@@ -500,6 +500,14 @@ int rv_plan_attach_comm_sharded(rv_plan*, rv_reduce_scatter_fn reduce_scatter, r
  * gradients); otherwise bf16 (each rank's summed gradient rounded to bf16 into the caller's `bf16_arena`, which holds
  * at least as many 2-byte elements as the fp32 arenas hold floats, and summed by the collective in bf16). */
 int rv_plan_set_ddp_payload(rv_plan*, void* bf16_arena);
+/* The stream rv_plan_step_ddp issues its collectives on.  Default: one high-priority stream per process, created by
+ * the first attach.  Why a caller may want to choose: the HIP runtime multiplexes streams onto a few hardware queues
+ * (GPU_MAX_HW_QUEUES, default 4), and when the collective stream shares a queue with the caller's compute stream the
+ * runtime resolves their cross-stream waits on the host -- every kernel of the step then starts ~50 us late (880 us
+ * instead of 255 us per step measured at one rank).  ddp.NativeDdpRunner times a short ping-pong against the compute
+ * stream and hands over the first of several candidate streams that is not affected.  Call before or after attach;
+ * the stream stays the caller's. */
+int rv_plan_set_comm_stream(rv_plan*, void* stream);
 int rv_plan_step_ddp(rv_plan*, const float* x, const float* eps, float* recon_out, float kl_beta,
                      float lr, unsigned long long seed, void* stream);
 /* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */

@@ -189,13 +189,37 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_gath)
     if (e) (void)hipEventDestroy(e);
-  if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->comm_stream) (void)hipStreamDestroy(p->comm_stream);
+  // p->side / p->comm_stream are the process-wide helper streams (helper_stream below): not destroyed here
   delete p;
+}
+
+// The two helper streams (side: the two-stream experiments; comm: collectives, highest priority) exist ONCE per process
+// and are created on first need.  One per plan was measured harmful: every extra HIP stream may land on another of
+// the runtime's few hardware queues (GPU_MAX_HW_QUEUES, default 4), and with an unlucky mapping -- it depended on how
+// many plans had been created before -- every kernel of a data-parallel step started ~50 us late (880 instead of
+// 255 us per step at one rank).  One process drives one GPU (header, Conventions), so the streams are not per device.
+static hipStream_t g_side_stream = nullptr, g_comm_stream = nullptr;
+static int helper_stream(bool comm, hipStream_t* out) {
+  hipStream_t& s = comm ? g_comm_stream : g_side_stream;
+  if (!s) {
+    if (comm) {
+      int lo = 0, hi = 0;  // collectives ahead of compute when both are runnable
+      RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      RV_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    } else {
+      RV_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+  }
+  *out = s;
+  return RV_OK;
 }
 
 int rv_plan_set_concurrency(rv_plan* p, int enable) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
+  if (enable && !p->side) {
+    const int rc = helper_stream(false, &p->side);
+    if (rc) return rc;
+  }
   p->concurrent = enable;
   return RV_OK;
 }
@@ -277,10 +301,8 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   RV_REQUIRE(((uintptr_t)b->workspace & 255) == 0, RV_ERR_SHAPE, "rv_plan_bind: workspace must be 256-byte aligned");
   p->b = *b;
   p->bound = true;
-  if (!p->side) {
-    RV_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  if (!p->ev[0])
     for (hipEvent_t& e : p->ev) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
   const long H = p->H, S = p->S, L = p->L, Hp = p->Hp, Sp = p->Sp, Lp = p->Lp, L2p = p->L2p, Bp = p->Bp;
   float* dW1 = (float*)p->ws("dW1"); float* dWh = (float*)p->ws("dWh");
   float* dW3 = (float*)p->ws("dW3"); float* dW4 = (float*)p->ws("dW4");
@@ -601,13 +623,20 @@ int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, long n_sampl
 }
 
 // ------------------------------------------------------------ data-parallel step
+int rv_plan_set_comm_stream(rv_plan* p, void* stream) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_comm_stream: null plan");
+  p->comm_stream = (hipStream_t)stream;   // NULL: back to the library's own (created on the next attach)
+  return RV_OK;
+}
+
 int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int world) {
   RV_REQUIRE(p && allreduce && comm, RV_ERR_NULL, "rv_plan_attach_comm: null argument");
   RV_REQUIRE(world >= 1, RV_ERR_SHAPE, "rv_plan_attach_comm: world %d", world);
   if (!p->comm_stream) {
-    int lo = 0, hi = 0;  // collectives ahead of compute when both are runnable
-    RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    RV_HIP(hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, hi));
+    const int src = helper_stream(true, &p->comm_stream);
+    if (src) return src;
+  }
+  if (!p->ev_ready[0]) {
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -630,9 +659,10 @@ int rv_plan_attach_comm_sharded(rv_plan* p, rv_reduce_scatter_fn reduce_scatter,
   RV_REQUIRE(world >= 1 && rank >= 0 && rank < world, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: rank %d of %d", rank, world);
   RV_REQUIRE((((uintptr_t)rs_buf | (uintptr_t)ag_buf) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: buffers must be 16-byte aligned");
   if (!p->comm_stream) {
-    int lo = 0, hi = 0;
-    RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    RV_HIP(hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, hi));
+    const int src = helper_stream(true, &p->comm_stream);
+    if (src) return src;
+  }
+  if (!p->ev_ready[0]) {
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }

@@ -10,6 +10,7 @@ rawvae/model.py:39,45); Adam then applies `grad_scale = 1/world`.
 """
 import ctypes as C
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -305,6 +306,57 @@ class RcclComm:
             self.handle = None
 
 
+_COMM_STREAMS = {}   # (device index, compute stream handle) -> (collective stream, us per ping-pong, candidates tried)
+
+
+def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0):
+    """A high-priority stream for the collectives whose cross-stream waits against `compute_stream` stay on the
+    device.  The HIP runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); when two
+    streams that wait on each other share one, the runtime resolves the waits on the host and every kernel behind
+    them starts ~50 us late (measured: 880 instead of 255 us per data-parallel step at one rank, depending only on how
+    many streams the process had created before).  So: time a short ping-pong (kernel, event, wait, kernel, event,
+    wait) between the compute stream and a candidate; a healthy pair takes ~15 us per round trip, an affected one
+    >100.  Candidates are created one after the other (each lands on the next hardware queue) until one is healthy;
+    the rejected ones are kept alive so that the mapping of the chosen one does not move.  Cached per compute stream."""
+    key = (device.index, compute_stream.cuda_stream)
+    if key in _COMM_STREAMS:
+        return _COMM_STREAMS[key][0]
+    a = torch.zeros(4096, device=device)
+    ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
+
+    def round_trip_us(cand, n):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            with torch.cuda.stream(compute_stream):
+                a.add_(1.0)
+                ev1.record(compute_stream)
+            cand.wait_event(ev1)
+            with torch.cuda.stream(cand):
+                a.add_(1.0)
+                ev2.record(cand)
+            compute_stream.wait_event(ev2)
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / n * 1e6
+    tried, best = [], None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device, priority=-1)
+        round_trip_us(cand, 5)
+        us = round_trip_us(cand, 40)
+        tried.append((cand, us))
+        if best is None or us < best[1]:
+            best = (cand, us)
+        if us < good_us:
+            break
+    _COMM_STREAMS[key] = (best[0], best[1], tried)
+    return best[0]
+
+
+def comm_stream_report():
+    """[(us per ping-pong of the chosen stream, candidates tried)] for bench / train logs."""
+    return [(round(v[1], 1), len(v[2])) for v in _COMM_STREAMS.values()]
+
+
 class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
@@ -312,6 +364,8 @@ class NativeDdpRunner:
     def __init__(self, engine, comm, stream, use_graph=False, payload="fp32", sharded=False):
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
         self.sharded = bool(sharded)
+        if stream is not None:
+            engine._pick_comm_stream(stream)    # before any capture: the choice times a few launches
         engine.attach_comm(comm, sharded=self.sharded)
         self._graphs = {}
         if not self.sharded:

@@ -9,6 +9,7 @@ PyTorch is used for device memory and streams only.  Parameters, Adam moments an
 `state_dict()` / checkpoints keep the reference's keys and layouts.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -273,12 +274,27 @@ class TrainEngine:
             raise _lib.RvError("step_ddp: eps must be contiguous fp32 [B, L]")
         if self._shadow_version != self._shared["version"]:
             self.refresh_shadows(stream)
+        self._pick_comm_stream(stream)
         lib().rv_plan_step_ddp(self._plan, ptr(x), ptr(eps), ptr(recon_out), self.kl_beta, self.lr, self.seed,
                                stream_ptr(stream))
         self.host_steps += 1
         self._shared["version"] += 1
         self._shadow_version = self._shared["version"]
         _ops_invalidate()
+
+    def _pick_comm_stream(self, stream):
+        """The collectives' stream is chosen per compute stream by measurement (ddp.pick_comm_stream: two streams
+        that wait on each other must not share one of the runtime's hardware queues); once per compute stream,
+        never during a capture.  RV_COMM_STREAM=library keeps the library's own stream."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if st.cuda_stream == getattr(self, "_comm_pick_for", None) or os.environ.get("RV_COMM_STREAM", "pick") != "pick":
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        from . import ddp
+        self._comm_stream = ddp.pick_comm_stream(st, self.device)
+        lib().rv_plan_set_comm_stream(self._plan, self._comm_stream.cuda_stream)
+        self._comm_pick_for = st.cuda_stream
 
     def plan_descs(self, from_flat=False):
         """The plan's ten `ParamDesc`s (gradient slabs or the flat arena, shadows to refresh)."""
