@@ -144,6 +144,27 @@ def test_train_iterable_end_to_end(tmp_path, capsys):
 
 
 @pytest.mark.gpu
+def test_train_iterable_fp8_weight_path_and_fp16_slabs(tmp_path, capsys):
+    """BASELINE configs[4]: the streaming entry point with the fp8 forward weight path ([mi355x] fp8 = True), here
+    together with fp16 split-K slabs: the run completes with the same artefacts and a loss that descends like the
+    bf16 run's (same data order, same seeds)."""
+    sys.path.insert(0, REPO)
+    import train_iterable as TI
+    ds = _dataset(tmp_path)
+
+    def run(**kw):
+        TI.main(["--config", str(_ini(ds, iterable=True, **kw))])
+        out = capsys.readouterr().out
+        return [float(l.split("Loss: ")[1].split()[0]) for l in out.splitlines() if l.startswith("====> Batch:")]
+    ref = run()
+    got = run(mi355x__fp8="True", mi355x__wgrad_slabs="fp16")
+    assert len(got) == len(ref) == 7 and all(np.isfinite(got))
+    np.testing.assert_allclose(got, ref, rtol=2e-2)
+    with pytest.raises(ValueError, match="wgrad_slabs"):
+        TI.main(["--config", str(_ini(ds, iterable=True, mi355x__wgrad_slabs="int8"))])
+
+
+@pytest.mark.gpu
 def test_streaming_frames_order_and_file_boundaries(tmp_path):
     """Unshuffled stream == hop frames of file a (ch0), then file b, cycled (dataset.py:53-84)."""
     from oracle import vae_oracle as O

@@ -18,7 +18,8 @@ test_original.wav, test_reconst_%05d.wav}}`), same checkpoint dict keys
     a list, and "best model" means the lowest epoch loss seen so far;
   * librosa / soundfile are replaced by scipy wav I/O; TensorBoard is used when importable.
 
-An optional `[mi355x]` section adds `seed`, `loss_ring` and `tensorboard` keys.
+An optional `[mi355x]` section adds `seed`, `loss_ring`, `tensorboard`, `fp8` (fc1 / fc4 forward on e4m3 operands,
+BASELINE configs[4]) and `wgrad_slabs` (`fp32` | `fp16` split-K partial sums) keys.
 
 Data-parallel training (no counterpart in the reference, which is single-process): launch with
 `python -m torch.distributed.run --nproc-per-node N train.py --config default.ini`, one process per
@@ -53,6 +54,21 @@ def read_config(path):
         print('Config File Not Found at {}'.format(path))
         sys.exit(1)
     return config
+
+
+def engine_options(hw):
+    """TrainEngine keyword arguments from the optional [mi355x] section: `fp8 = True` runs the fc1 / fc4 forward
+    GEMMs on fp8 (e4m3) operands (BASELINE configs[4]); `wgrad_slabs = fp16` stores the split-K partial sums of the
+    two large weight gradients as scaled fp16.  Both default to the bf16 / fp32 path the parity gates are stated on."""
+    kw = {}
+    if str(hw.get('fp8', 'False')).lower() in ('1', 'true', 'yes'):
+        kw['fp8'] = True
+    slabs = str(hw.get('wgrad_slabs', 'fp32')).lower()
+    if slabs not in ('fp32', 'fp16'):
+        raise ValueError("[mi355x] wgrad_slabs = {} (expected fp32 or fp16)".format(slabs))
+    if slabs == 'fp16':
+        kw['slab_dtype'] = 'fp16'
+    return kw
 
 
 def require_gpu(local_rank=0):
@@ -267,6 +283,7 @@ def main(argv=None):
     seed = int(hw.get('seed', 0))
     ring = int(hw.get('loss_ring', 256))
     use_tb = str(hw.get('tensorboard', 'True')).lower() in ('1', 'true', 'yes')
+    engine_kw = engine_options(hw)
 
     device = require_gpu(int(os.environ.get("LOCAL_RANK", "0")))
     dp = DataParallel(device)
@@ -310,10 +327,10 @@ def main(argv=None):
     full = min(batch_size, n_frames // dp.world)                 # per-rank batch
     ragged = (n_frames % (full * dp.world)) // dp.world          # per-rank size of the epoch's last step
     engine = TrainEngine(segment_length, n_units, latent_dim, full, device=device, kl_beta=kl_beta,
-                         lr=learning_rate, seed=seed + dp.rank, ring=ring)   # per-rank eps stream
+                         lr=learning_rate, seed=seed + dp.rank, ring=ring, **engine_kw)   # per-rank eps stream
     engine.adopt(model)
     tail_engine = TrainEngine(segment_length, n_units, latent_dim, ragged, device=device, kl_beta=kl_beta,
-                              lr=learning_rate, seed=seed + dp.rank, share=engine) if ragged else None
+                              lr=learning_rate, seed=seed + dp.rank, share=engine, **engine_kw) if ragged else None
     step_full = dp.prepare(engine)
     step_tail = dp.prepare(tail_engine) if tail_engine is not None else None
     # the data-parallel step forks its collectives from the caller's stream: it needs a non-default one

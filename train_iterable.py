@@ -119,7 +119,7 @@ def main(argv=None):
         torch.manual_seed(seed)
         model = VAE(segment_length, n_units, latent_dim).to(device)
         engine = TrainEngine(segment_length, n_units, latent_dim, batch_size, device=device, kl_beta=kl_beta,
-                             lr=learning_rate, seed=seed, ring=ring)
+                             lr=learning_rate, seed=seed, ring=ring, **T.engine_options(hw))
         engine.adopt(model)
         model.train()
 
