@@ -48,6 +48,8 @@ def parse():
                          "of the same 12 kernels (gap between replays), so eager is the default")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
+    ap.add_argument("--latent-fused", type=int, default=None, choices=[0, 1],
+                    help="heads + reparam + fc3 of the forward as one launch (1: experiment, measured slower) or three (0, default)")
     ap.add_argument("--adam-split", type=int, default=None,
                     help="permille of fc4.weight rows whose Adam update rides in the fc1 wgrad launch (default: library's)")
     ap.add_argument("--sched", type=int, default=0,
@@ -146,6 +148,8 @@ def main():
     eng.set_concurrency(0 if args.serial else args.sched)
     if args.adam_split is not None:
         eng.set_adam_split(args.adam_split)
+    if args.latent_fused is not None:
+        eng.set_latent_fused(args.latent_fused)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
     comp = torch.cuda.Stream(device=dev)
     use_graph = world == 1 and args.graph and not args.no_graph and os.environ.get("RV_FORCE_DDP") != "1"

@@ -182,6 +182,20 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
                          const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                          float* mulv, void* z_bf16, float* kl_partial, void* stream);
 
+/* The latent-sized forward in ONE launch for a padded latent width of 64 (L <= 64; BASELINE's C2): heads GEMM
+ * (model.py:21) + reparameterisation and KL partials (model.py:23-26,45) + fc3 with bias and ReLU (model.py:29),
+ * 16 batch rows per workgroup, all three steps row-local, MFMA operands loaded straight from global memory.
+ * Replaces rv_heads_reparam_fwd followed by rv_linear_fwd(fc3): same outputs (mulv [Bp][128], z bf16 [Bp][64],
+ * kl_partial[Bp / 16], eps_out, h3 bf16 [Bp][Hp]); mu / logvar differ from the split-K route by fp32 summation
+ * order only; eps draws and the KL partial layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a
+ * padded hidden width that is not a multiple of 512.  Correct and tested, but SLOWER than the three launches it
+ * replaces (45 vs 21 us at C2: loads scheduled by the compiler stream 21-30 GB/s per CU where the GEMM kernels'
+ * LDS-DMA ring streams 60), so nothing in the library calls it unless rv_plan_set_latent_fused(plan, 1). */
+int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
+                  const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
+                  const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                  float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream);
+
 /* Backward of reparameterize + KL:
  *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
  * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums
@@ -416,6 +430,10 @@ int rv_plan_set_concurrency(rv_plan*, int enable);
  * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch.  Same arithmetic
  * either way; the value only balances the two launches. */
 int rv_plan_set_adam_split(rv_plan*, int permille);
+/* 0 (default): heads GEMM, reparameterisation and fc3 of the forward are three launches (rv_heads_reparam_fwd + fc3);
+ * 1: one launch (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 and the
+ * fp8 path off -- an experiment kept for the record: 45 us against 21 us at C2 (see rv_latent_fwd). */
+int rv_plan_set_latent_fused(rv_plan*, int enable);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and
  * dlogvar [B,L], all exact-shape fp32, each NULL = zero; the reparameterisation backward then takes kl_beta from

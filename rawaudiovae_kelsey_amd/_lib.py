@@ -107,6 +107,9 @@ _SIGS = {
     "rv_heads_reparam_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_long,
                                      c_int, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    "rv_latent_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long,
+                              c_long, c_long, c_long, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_long, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
@@ -129,6 +132,7 @@ _SIGS = {
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
     "rv_plan_set_adam_split": (c_int, [c_void_p, c_int]),
+    "rv_plan_set_latent_fused": (c_int, [c_void_p, c_int]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
     "rv_reparam_bwd_ext": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

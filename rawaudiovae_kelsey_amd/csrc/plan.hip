@@ -54,6 +54,7 @@ struct rv_plan {
   const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
   const float* ext_dmu = nullptr; const float* ext_dlv = nullptr;
   float* ext_grad_out = nullptr;
+  int latent_fused = 0;          // rv_plan_set_latent_fused: heads + reparam + fc3 as one launch (measured slower)
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   int adam_split = 1000;  // permille of fc4.weight's rows updated by the optimizer blocks of the dW1 launch
   int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
@@ -243,6 +244,12 @@ int rv_plan_set_external_grads(rv_plan* p, const float* d_recon, const float* re
   return RV_OK;
 }
 
+int rv_plan_set_latent_fused(rv_plan* p, int enable) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_latent_fused: null plan");
+  p->latent_fused = enable ? 1 : 0;
+  return RV_OK;
+}
+
 int rv_plan_set_adam_split(rv_plan* p, int permille) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_adam_split: null plan");
   RV_REQUIRE(permille >= 0 && permille <= 1000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 1000]", permille);
@@ -419,13 +426,19 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, nullptr, 0, stream));
     }
-    RV_TRY(rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
-                                eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
+    // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64, bf16), else three
+    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && !p->fp8;
+    if (latent_fused)
+      RV_TRY(rv_latent_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
+                           B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp, stream));
+    else
+      RV_TRY(rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
+                                  eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
     if (p->fr_hop) {
       if (p->fp8)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), nullptr, 0, stream));
-      else
+      else if (!latent_fused)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
                                 nullptr, nullptr, nullptr, 0, stream));
       RV_TRY(rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
@@ -438,7 +451,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
                                         x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     } else {
-      RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+      if (!latent_fused)
+        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
                                 nullptr, nullptr, nullptr, 0, stream));
       RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));

@@ -322,6 +322,27 @@ def test_schedules_agree(shape):
     assert float((out[2][0] - out[0][0]).abs().mean()) <= 1e-3 * LR
 
 
+def test_latent_forward_one_launch_vs_three_in_the_step():
+    """The step with heads + reparam + fc3 as one launch (`set_latent_fused(True)`, an opt-in experiment) against
+    the default step with the three launches: same eps, losses equal to fp32 summation order, parameters after 5 steps
+    agree like two summation orders do."""
+    from oracle.inputs import make_frames, make_params
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    S, H, L, B = 1024, 2048, 64, 4096
+    engs = []
+    for fused in (True, False):
+        e = TrainEngine(S, H, L, B, kl_beta=1e-2, lr=1e-3, seed=5)
+        e.load_params(make_params(S, H, L, 0))
+        e.set_latent_fused(fused)
+        for i in range(5):
+            e.step(torch.from_numpy(make_frames(B, S, 10 + i)).cuda())
+        engs.append(e)
+    la, lb = engs[0].losses(5), engs[1].losses(5)
+    np.testing.assert_allclose(la, lb, rtol=2e-5)
+    d = (engs[0].param - engs[1].param).abs()
+    assert float(d.mean()) < 2e-5 and float(d.max()) <= 5 * 2 * 1e-3 + 1e-6
+
+
 @pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 384, 100, 130)])
 def test_fp16_split_k_slabs_vs_fp32_slabs(shape):
     """slab_dtype="fp16": the split-K partials of dW1 / dW4 are stored as fp16(partial * 2^12) and summed in fp32.

@@ -317,6 +317,74 @@ def test_heads_reparam_fwd(L, B, Lt, K, splits):
     np.testing.assert_allclose(z.float().cpu().numpy()[:B, :Lt], z2, rtol=1e-2, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,Lt,H", [(100, 3, 512), (4096, 64, 2048), (300, 40, 900)])
+def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
+    """rv_latent_fwd (heads GEMM + reparam + KL partials + fc3 in one launch, model.py:21-29) against the route it
+    replaces (rv_heads_reparam_fwd + rv_linear_fwd) and against numpy, on the same bf16 operands and eps."""
+    rng = np.random.default_rng(9)
+    Bp, Lp, Hp = -(-B // 128) * 128, 64, -(-H // 512) * 512
+    h = np.zeros((Bp, Hp), np.float32); h[:B, :H] = np.maximum(rand_bf16(rng, (B, H), 0.5), 0)
+    wh = np.zeros((2 * Lp, Hp), np.float32)
+    wh[:Lt, :H] = rand_bf16(rng, (Lt, H), 0.05); wh[Lp:Lp + Lt, :H] = rand_bf16(rng, (Lt, H), 0.05)
+    bh = np.zeros(2 * Lp, np.float32)
+    bh[:Lt] = rng.standard_normal(Lt) * 0.1; bh[Lp:Lp + Lt] = rng.standard_normal(Lt) * 0.1
+    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.2)
+    b3 = np.zeros(Hp, np.float32); b3[:H] = rng.standard_normal(H) * 0.1
+    eps = rng.standard_normal((B, Lt)).astype(np.float32)
+    hd, whd, w3d = dev(h, torch.bfloat16), dev(wh, torch.bfloat16), dev(w3, torch.bfloat16)
+    bhd, b3d, ed = dev(bh), dev(b3), dev(eps)
+    ctr = torch.ones(1, dtype=torch.int64, device="cuda")
+
+    def outs():
+        return (torch.empty(Bp, 2 * Lp, device="cuda"), torch.empty(Bp, Lp, device="cuda", dtype=torch.bfloat16),
+                torch.zeros(Bp * Lp // 1024, device="cuda"), torch.empty(Bp, Hp, device="cuda", dtype=torch.bfloat16))
+    mulv1, z1, kl1, h31 = outs()
+    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
+                    B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), mulv1.data_ptr(), z1.data_ptr(), kl1.data_ptr(),
+                    h31.data_ptr(), Hp, sp())
+    mulv3, z3, kl3, h33 = outs()
+    splits = 2
+    slabs = torch.empty(splits, Bp, 2 * Lp, device="cuda")
+    L.rv_heads_reparam_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), Bp, Lp, Hp, B, Lt, splits, slabs.data_ptr(),
+                           ed.data_ptr(), None, 0, ctr.data_ptr(), mulv3.data_ptr(), z3.data_ptr(), kl3.data_ptr(), sp())
+    L.rv_linear_fwd(z3.data_ptr(), Lp, w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp, 1, h33.data_ptr(), Hp, sp())
+    ref = h[:B].astype(np.float64) @ wh.astype(np.float64).T + bh
+    mu, lv = ref[:, :Lt], ref[:, Lp:Lp + Lt]
+    got = mulv1.cpu().numpy()
+    np.testing.assert_allclose(got[:B, :Lt], mu, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got[:B, Lp:Lp + Lt], lv, rtol=1e-5, atol=2e-5)
+    assert not got[B:].any() and not got[:, Lt:Lp].any() and not got[:, Lp + Lt:].any()
+    np.testing.assert_allclose(got, mulv3.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    za, zb = z1.float().cpu().numpy(), z3.float().cpu().numpy()
+    assert np.mean(za != zb) < 2e-3 and not za[B:].any() and not za[:, Lt:].any()
+    np.testing.assert_allclose(za, zb, rtol=1e-2, atol=1e-6)
+    kl_ref = float(np.sum(1 + lv - mu ** 2 - np.exp(lv)))
+    assert abs(float(kl1.double().sum()) - kl_ref) <= 1e-5 * abs(kl_ref) + 1e-4
+    np.testing.assert_allclose(kl1.cpu().numpy(), kl3.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # fc3 on the kernel's own z (bf16) against float64: only the fp32 accumulation and the output rounding differ
+    h3ref = np.maximum(za[:B].astype(np.float64) @ w3.astype(np.float64).T + b3, 0)
+    np.testing.assert_allclose(h31.float().cpu().numpy()[:B], h3ref, rtol=1e-2, atol=1e-3)
+    # where both routes rounded z alike, h3 differs only where another k order of the 64-term sum crosses a bf16
+    # rounding boundary of the output (a few elements per million, one ulp)
+    rows_same = (za == zb).all(axis=1)
+    ha, hb = h31.float().cpu().numpy()[rows_same], h33.float().cpu().numpy()[rows_same]
+    assert np.mean(ha != hb) < 1e-4
+    np.testing.assert_allclose(ha, hb, rtol=1e-2, atol=1e-3)
+    # generated eps: the same Philox draws as the three-launch route
+    e1, e3 = torch.empty(B, Lt, device="cuda"), torch.empty(B, Lt, device="cuda")
+    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
+                    B, Lt, None, e1.data_ptr(), 77, ctr.data_ptr(), mulv1.data_ptr(), z1.data_ptr(), kl1.data_ptr(),
+                    h31.data_ptr(), Hp, sp())
+    L.rv_heads_reparam_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), Bp, Lp, Hp, B, Lt, splits, slabs.data_ptr(),
+                           None, e3.data_ptr(), 77, ctr.data_ptr(), mulv3.data_ptr(), z3.data_ptr(), kl3.data_ptr(), sp())
+    assert torch.equal(e1, e3)
+    from rawaudiovae_kelsey_amd import _lib
+    with pytest.raises(_lib.RvError):
+        L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, 128,
+                        B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), mulv1.data_ptr(), z1.data_ptr(), kl1.data_ptr(),
+                        h31.data_ptr(), Hp, sp())
+
+
 def test_adam_multi_and_finalize(L):
     from rawaudiovae_kelsey_amd._lib import ParamDesc
     rng = np.random.default_rng(8)
