@@ -427,8 +427,9 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  * rv_plan_step_ddp refuses to run while a non-zero schedule is set (see there). */
 int rv_plan_set_concurrency(rv_plan*, int enable);
 /* Schedule 0 only: the first `permille`/1000 of fc4.weight's rows are updated by the optimizer blocks that ride in
- * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch.  Same arithmetic
- * either way; the value only balances the two launches. */
+ * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch; above 1000 (up to
+ * 2000) all of fc4 and the heads' tensors (fc21, fc22) ride as well.  Same arithmetic either way; the value only
+ * balances the two launches (default 1000 measured best: profiles/r02_adam_split_sweep.txt). */
 int rv_plan_set_adam_split(rv_plan*, int permille);
 /* 0 (default): heads GEMM, reparameterisation and fc3 of the forward are three launches (rv_heads_reparam_fwd + fc3);
  * 1: one launch (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 and the

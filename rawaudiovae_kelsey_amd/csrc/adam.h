@@ -338,6 +338,103 @@ __device__ __forceinline__ void adam_group(const DescTable& tab, const long vb0,
                        nullptr, nullptr);
 }
 
+// ------------------------------------------------------------------ streamed update (LDS-DMA ring per wave)
+// The same update for callers that own a whole CU with few waves (the optimizer blocks of rv_linear_wgrad_adam).
+// A loop of plain loads and stores streams ~20-25 GB/s per CU: loads and stores share vmcnt and complete out of
+// order with respect to each other, so the compiler drains the queue before every trip.  Here each wave moves its
+// operands with global_load_lds (no VGPR destination, so nothing for the compiler to wait on) into a private
+// two-slot LDS ring, one slot = 64 four-element groups x 7 streams (4 gradient slabs, exp_avg, exp_avg_sq, param)
+// x 16 B = 7 KB, and retires a slot with a COUNTED wait: memory reads return in order among themselves, so once at
+// most 7 vector-memory operations are outstanding none of them can be a load older than the 7 loads of the next
+// slot -- whatever the stores in between are doing.  One "wave chunk" = a quarter of a 256-thread virtual block;
+// every chunk issues exactly 7 loads (lanes or chunks that do not take the aligned path read a valid dummy
+// address and go through adam_block), which keeps the count static.  Arithmetic: adam_update, slab order of slab_sum4.
+constexpr int AS_SLOT = 7 * 1024;
+
+__device__ __forceinline__ void adam_stream_issue(const DescTable& tab, const AdamItem& it, lds_char* slot,
+                                                  const float* param, const float* m_arena, const float* v_arena) {
+  const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(it.t)];
+  const bool on = it.state == 1 && !d.grad_half;
+  const long o = on ? it.o : d.offset;
+  const long base = on ? it.r * d.grad_ld + it.c : 0;
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const float* g = d.grad_slabs + base + (long)(s_ < d.grad_splits ? s_ : 0) * d.grad_split_stride;
+    __builtin_amdgcn_global_load_lds((glb_cptr)g, (__attribute__((address_space(3))) void*)(slot + s_ * 1024), 16, 0, 0);
+  }
+  __builtin_amdgcn_global_load_lds((glb_cptr)(m_arena + o), (__attribute__((address_space(3))) void*)(slot + 4096), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_cptr)(v_arena + o), (__attribute__((address_space(3))) void*)(slot + 5120), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_cptr)(param + o), (__attribute__((address_space(3))) void*)(slot + 6144), 16, 0, 0);
+}
+
+// `lds`: 2 * AS_SLOT bytes private to the calling wave.  Chunks wc_first, wc_first + wc_stride, ... (wave-uniform).
+__device__ __forceinline__ void adam_stream(const DescTable& tab, const long wc_first, const long wc_stride, lds_char* lds,
+                                            const int lane, float* param, float* m_arena, float* v_arena, const float lr,
+                                            const float grad_scale, const long long* __restrict__ step_counter) {
+  const long total = tab.blk_start[tab.n] * 4;
+  if (wc_first >= total) return;
+  auto locate = [&](const long wc) {
+    return wc < total ? adam_locate(tab, wc >> 2, (int)(wc & 3) * 64 + lane) : AdamItem{0, 0, 0, 0, 0};
+  };
+  AdamItem a = locate(wc_first), b = locate(wc_first + wc_stride);
+  adam_stream_issue(tab, a, lds, param, m_arena, v_arena);
+  adam_stream_issue(tab, b, lds + AS_SLOT, param, m_arena, v_arena);
+  float step_size, inv_bc2s;
+  adam_step_consts(step_counter, lr, &step_size, &inv_bc2s);
+  int slot = 0;
+  for (long wc = wc_first; wc < total; wc += wc_stride) {
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // slot `slot` has landed; the next slot's 7 loads may fly
+    const lds_char* sl = lds + slot * AS_SLOT + lane * 16;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    f32x4 sv[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) sv[s_] = *reinterpret_cast<lds_f4>(sl + s_ * 1024);
+    const f32x4 m4 = *reinterpret_cast<lds_f4>(sl + 4096);
+    const f32x4 v4 = *reinterpret_cast<lds_f4>(sl + 5120);
+    const f32x4 w4 = *reinterpret_cast<lds_f4>(sl + 6144);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the DMA below refills the slot
+    const AdamItem c = locate(wc + 2 * wc_stride);
+    adam_stream_issue(tab, c, lds + slot * AS_SLOT, param, m_arena, v_arena);
+    const rv_param_desc d = tab.d[__builtin_amdgcn_readfirstlane(a.t)];
+    if (a.state == 1 && !d.grad_half) {
+      float gv[4];
+      if (d.grad_splits == 4) {  // the summation order of slab_sum4
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[j] = (sv[0][j] + sv[1][j]) + (sv[2][j] + sv[3][j]);
+      } else {
+        gv[0] = gv[1] = gv[2] = gv[3] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+          if (s_ < d.grad_splits) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] += sv[s_][j];
+          }
+      }
+      float mv[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]}, wv[4] = {w4[0], w4[1], w4[2], w4[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gv[j] *= grad_scale;
+        adam_update(mv[j], vv[j], wv[j], gv[j], step_size, inv_bc2s);
+      }
+      *reinterpret_cast<float4*>(m_arena + a.o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v_arena + a.o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      *reinterpret_cast<float4*>(param + a.o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      if (d.shadow_bf16) {
+        const bf16x4 b4 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(d.shadow_bf16) + a.r * d.shadow_ld + a.c) = b4;
+      }
+      if (d.shadow_fp8) store_fp8x4(d, a.r, a.c, wv, 4);
+    } else if (a.state != 0) {
+      adam_block<true>(tab, wc >> 2, (int)(wc & 3) * 64 + lane, param, m_arena, v_arena, nullptr, lr, grad_scale,
+                       step_counter, nullptr, nullptr);
+    }
+    a = b;
+    b = c;
+    slot ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last two (dummy) refills land before the LDS is given back
+}
+
 // Parameters (unless `param` is null) and every operand shadow of the table's tensors from a flat fp32 source (the
 // all-gather's output, or the parameter arena itself): element at flat arena offset o is flat[o - flat_base].
 // One virtual block = 256 threads, 4 elements each.  No __restrict__: `flat` may be the parameter arena.

@@ -21,6 +21,7 @@ int g_force_tile = -1;
 // at C2 (tools/gemm_bench.py, same box, interleaved): NT 19.7 vs 21.5 us, TN 28.7 vs 29.5, NN 27.3 vs 25.4 -- at this
 // tile the loop is bound by how fast one CU fills its LDS (~60 GB/s), which the phase structure does not change.
 int g_n128_loop = 3;
+int g_adam_stream = 1;   // optimizer blocks of rv_linear_wgrad_adam: 1 = LDS-DMA ring per wave (adam_stream), 0 = plain loads
 int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
 int g_pair_only = 0;  // paired launch: 1 = dgrad blocks only, 2 = wgrad blocks only (diagnostics: 300 + v)
 
@@ -110,11 +111,19 @@ template <int NSTAGE>
 __global__ void __launch_bounds__(512)
 gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable tab, float* __restrict__ param,
                        float* __restrict__ m_arena, float* __restrict__ v_arena, const float lr,
-                       const float grad_scale, const long long* __restrict__ step_counter) {
+                       const float grad_scale, const long long* __restrict__ step_counter, const int stream_mode) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   if ((int)blockIdx.x < n_gemm) {
     gemm_body<256, 256, 2, 4, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x, smem_dyn);
   } else {
+    if (stream_mode) {
+      // each wave streams its own chunks through a private two-slot LDS ring (adam_stream)
+      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      const long n_waves = 8L * ((long)gridDim.x - n_gemm);
+      adam_stream(tab, 8L * ((long)blockIdx.x - n_gemm) + wave, n_waves, (lds_char*)smem_dyn + wave * 2 * AS_SLOT,
+                  (int)(threadIdx.x & 63), param, m_arena, v_arena, lr, grad_scale, step_counter);
+      return;
+    }
     const long total = tab.blk_start[tab.n];
     const long stride = 2L * ((long)gridDim.x - n_gemm);   // virtual blocks taken per sweep of the optimizer blocks
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // wave-uniform
@@ -262,7 +271,8 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 
 extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
-  if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }  // experiment hook: 256x128 main loop
+  if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }
+  if (tile == 400 || tile == 401) { g_adam_stream = tile - 400; return RV_OK; }  // experiment hook: optimizer blocks' loader  // experiment hook: 256x128 main loop
   if (tile >= 200 && tile < 216) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
   if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
   g_force_tile = tile;
@@ -483,7 +493,7 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
     attr_done[pp] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_adam_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
-                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter);
+                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, g_adam_stream);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -252,7 +252,7 @@ int rv_plan_set_latent_fused(rv_plan* p, int enable) {
 
 int rv_plan_set_adam_split(rv_plan* p, int permille) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_adam_split: null plan");
-  RV_REQUIRE(permille >= 0 && permille <= 1000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 1000]", permille);
+  RV_REQUIRE(permille >= 0 && permille <= 2000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 2000]", permille);
   p->adam_split = permille;
   return RV_OK;
 }
@@ -495,20 +495,29 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // How much rides along is a balance: the optimizer blocks get half the chip's CUs at ~20 GB/s each while the
     // GEMM blocks need ~30 us, and the last launch updates at the whole chip's rate -- so only the first
     // `adam_split` permille of fc4.weight's rows are updated here and the rest by the last launch.
-    rv_param_desc ride[4] = {p->d_slab[6], p->d_slab[7], p->d_slab[8], p->d_slab[9]}, last[7];
-    int n_last = 6;
-    for (int i = 0; i < 6; ++i) last[i] = p->d_slab[i];
-    const long r0 = (p->d_slab[8].rows * p->adam_split / 1000) & ~3L;
-    if (r0 < p->d_slab[8].rows) {
-      if (r0 > 0) {
-        split_rows(p->d_slab[8], r0, &ride[2], &last[n_last++]);
-      } else {
-        last[n_last++] = p->d_slab[8];
-        ride[2] = ride[3];   // fc3.weight, fc3.bias, fc4.bias
-      }
+    // Above 1000 the heads' tensors (fc21, fc22: gradients complete since heads_bwd) ride as well.
+    rv_param_desc ride[8], last[7];
+    int n_ride = 0, n_last = 0;
+    const bool heads_ride = p->adam_split > 1000;
+    for (int i = 0; i < 6; ++i) {
+      if (heads_ride && i >= 2) ride[n_ride++] = p->d_slab[i];
+      else last[n_last++] = p->d_slab[i];
     }
+    ride[n_ride++] = p->d_slab[6];
+    ride[n_ride++] = p->d_slab[7];
+    const long r0 = heads_ride ? p->d_slab[8].rows : (p->d_slab[8].rows * p->adam_split / 1000) & ~3L;
+    if (r0 >= p->d_slab[8].rows) {
+      ride[n_ride++] = p->d_slab[8];
+    } else if (r0 > 0) {
+      split_rows(p->d_slab[8], r0, &ride[n_ride], &last[n_last]);
+      ++n_ride;
+      ++n_last;
+    } else {
+      last[n_last++] = p->d_slab[8];
+    }
+    ride[n_ride++] = p->d_slab[9];
     RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, ride,
-                                r0 > 0 ? 4 : 3, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+                                n_ride, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                 p->b.step_counter, 256 - n_gemm, stream));
     RV_TRY(rv_adam_multi(last, n_last, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
