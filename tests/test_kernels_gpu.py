@@ -430,6 +430,71 @@ def test_adam_multi_and_finalize(L):
         o += r * c
 
 
+@pytest.mark.parametrize("loader", [401, 400], ids=["lds_dma_ring", "plain_loads"])
+def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
+    """rv_linear_wgrad_adam: the weight-gradient GEMM must equal rv_linear_wgrad_ex bit for bit, and the optimizer
+    blocks riding in its launch must equal rv_adam_multi bit for bit on a mixed bag of tensors -- aligned matrices
+    with 4, 2 and 1 split-K slabs (the streamed path), a ragged matrix, short rows, a bias row summed by a wave
+    (>= 16 partials), a bias row with few partials, fp16 slabs -- for both loaders of the optimizer blocks."""
+    from rawaudiovae_kelsey_amd._lib import ParamDesc
+    rng = np.random.default_rng(12)
+    M, N, K, splits = 512, 256, 512, 2
+    dy = dev(rand_bf16(rng, (K, M), 0.1), torch.bfloat16)
+    x = dev(rand_bf16(rng, (K, N), 0.5), torch.bfloat16)
+    # (rows, cols, splits, ld, fp16)
+    spec = [(300, 256, 4, 256, False), (64, 128, 2, 136, False), (40, 64, 1, 64, False), (50, 37, 3, 44, False),
+            (7, 3, 2, 4, False), (1, 200, 32, 208, False), (1, 77, 3, 80, False), (96, 64, 4, 64, True)]
+    n = sum(r * c for r, c, *_ in spec)
+    n_pad = n + 16
+    param = rng.standard_normal(n_pad).astype(np.float32)
+    m0 = (0.01 * rng.standard_normal(n_pad)).astype(np.float32)
+    v0 = (1e-4 * rng.random(n_pad)).astype(np.float32)
+    descs = (ParamDesc * len(spec))()
+    keep, off = [], 0
+    shadows = []
+    for i, (r, c, s, ld, half) in enumerate(spec):
+        slab = (rng.standard_normal((s, r + 1, ld)) * 1e-2).astype(np.float32)
+        sd = dev((slab * 4096).astype(np.float16)) if half else dev(slab)
+        keep.append(sd)
+        cp = -(-c // 8) * 8
+        sh = torch.zeros((r, cp), dtype=torch.bfloat16, device="cuda") if r > 1 else None
+        shf = torch.zeros((1, cp), dtype=torch.float32, device="cuda") if r == 1 else None
+        shadows.append((sh, shf))
+        # offsets: multiples of 4 for the aligned tensors, odd ones in between stay valid for the scalar path
+        descs[i] = ParamDesc(off, r, c, sd.data_ptr(), ld, (r + 1) * ld, s, sh.data_ptr() if sh is not None else None,
+                             shf.data_ptr() if shf is not None else None, cp, None, None, int(half), 1.0 / 4096 if half else 0.0)
+        off += r * c
+    ctr = torch.full((1,), 4, dtype=torch.int64, device="cuda")
+
+    def state():
+        return dev(param.copy()), dev(m0.copy()), dev(v0.copy())
+    L.rv_gemm_force_tile(loader)
+    try:
+        pa, ma, va = state()
+        dwa = torch.zeros(splits, M, N, device="cuda")
+        L.rv_linear_wgrad_adam(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, dwa.data_ptr(), N, 0, 1.0, descs, len(spec),
+                               pa.data_ptr(), ma.data_ptr(), va.data_ptr(), 1e-3, 0.25, ctr.data_ptr(), 24, sp())
+        sha = [(a.clone() if a is not None else None, b.clone() if b is not None else None) for a, b in shadows]
+        for a, b in shadows:
+            for t in (a, b):
+                if t is not None:
+                    t.zero_()
+        pb, mb, vb = state()
+        dwb = torch.zeros(splits, M, N, device="cuda")
+        L.rv_linear_wgrad_tile(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, 7, dwb.data_ptr(), N, 0, 1.0, sp())
+        L.rv_adam_multi(descs, len(spec), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, 1e-3, 0.25, ctr.data_ptr(), sp())
+        torch.cuda.synchronize()
+    finally:
+        L.rv_gemm_force_tile(401)
+    assert torch.equal(dwa, dwb)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(pa, dev(param))
+    for (a1, b1), (a2, b2) in zip(sha, shadows):
+        for t1, t2 in ((a1, a2), (b1, b2)):
+            if t1 is not None:
+                assert torch.equal(t1, t2)
+
+
 def test_gather_frames_matches_audio_dataset_semantics(L):
     """rv_gather_frames == AudioDataset.__getitem__ (rawvae/dataset.py:108-118) for a shuffled index,
     and == TestDataset for hop == S."""
