@@ -485,6 +485,11 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
   g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.dbg = g_dbg;
   const int n_gemm = g.tiles_m * g.tiles_n * splits;
   constexpr int smem = 2 * (256 + 256) * 128;
+  static_assert(8 * 2 * AS_SLOT <= smem, "the optimizer waves' LDS rings live in the launch's dynamic LDS");
+  // fp16 slabs are 8 B per group, below the 16-byte LDS-DMA piece: such tables take the plain-load walk (adam_group)
+  int stream_mode = g_adam_stream;
+  for (int i = 0; i < n_desc; ++i)
+    if (descs[i].grad_half) stream_mode = 0;
   const bool pp = g.k_tiles % 2 == 0;
   auto kern = pp ? gemm_wgrad_adam_kernel<8> : gemm_wgrad_adam_kernel<2>;
   static bool attr_done[2] = {false, false};
@@ -493,7 +498,7 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
     attr_done[pp] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_adam_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
-                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, g_adam_stream);
+                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
