@@ -135,9 +135,10 @@ class DataParallel:
         if not self.active:
             return engine.step
         if self.comm is not None:
-            # RV_DDP_MODE=sharded (default): reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
+            # RV_DDP_MODE=allreduce (default): all-reduce and the full update on every rank;
+            # RV_DDP_MODE=sharded: reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
             # all-gather the parameters; =allreduce: all-reduce and the full update on every rank
-            self.sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
+            self.sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
             engine.attach_comm(self.comm, sharded=self.sharded)
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
