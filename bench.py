@@ -329,7 +329,7 @@ def main():
                 print("bench.py: replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
         # Not the headline: the same K steps again with the bf16 gradient payload (half the all-reduce
         # bytes), so that one run shows what the exchange costs at this GPU count.
-        alt, alt_key, ddp_pick = None, None, None
+        alt, alt_key, ddp_pick, alt_bf16 = None, None, None, None
         if isinstance(runner, ddp.NativeDdpRunner) and runner.sharded and os.environ.get("RV_DDP_ALT", "1") == "1":
             alt_key = "alt_allreduce"
             # Not the headline: the same K steps with the all-reduce + full-update schedule on a second engine
@@ -372,6 +372,40 @@ def main():
                 alt = {"grad_allreduce": ar_what, "ms_per_step": adt / args.steps * 1e3,
                        "value": float(B) * world * args.steps / adt, "repeats": len(apasses),
                        **({"replicas_consistent": a_consistent} if a_consistent is not None else {})}
+                # side line only (it rounds each rank's summed gradient to bf16 before the exchange): the same
+                # all-reduce schedule with half the bytes on the links
+                try:
+                    run2.set_payload("bf16")
+                    for i in range(3):
+                        run2.step(pool[i % POOL])
+                    torch.cuda.synchronize()
+                    bp = []
+                    for r in range(min(5, len(passes))):
+                        if world > 1:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for i in range(args.steps):
+                            run2.step(pool[(r * args.steps + i) % POOL])
+                        torch.cuda.synchronize()
+                        if world > 1:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        el = time.perf_counter() - t1
+                        if world > 1:
+                            t = torch.tensor([el], dtype=torch.float64, device=dev)
+                            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                            el = float(t.item())
+                        bp.append(el)
+                    bp.sort()
+                    alt_bf16 = {"grad_allreduce": "all-reduce schedule with the bf16 gradient payload (half the bytes; "
+                                                  "gradients rounded to bf16 before the exchange)",
+                                "ms_per_step": bp[len(bp) // 2] / args.steps * 1e3,
+                                "value": float(B) * world * args.steps / bp[len(bp) // 2], "repeats": len(bp)}
+                except Exception as exc:
+                    alt_bf16 = {"grad_allreduce": "bf16 payload", "error": str(exc)[:200]}
+                finally:
+                    run2.set_payload("fp32")
                 # Both schedules are the product's (same step, same arithmetic up to the order of the reduction);
                 # which one is faster depends on the GPU count and the links, and this is the first hardware either
                 # has run on at N > 1: the headline is the faster of the two, the other stays beside it.
@@ -487,6 +521,7 @@ def main():
             "host_us_per_step": host_dt / args.steps * 1e6,
             **({(alt_key or "alt_bf16_payload"): alt} if alt else {}),
             **({"ddp_schedule_pick": ddp_pick} if ddp_pick else {}),
+            **({"alt_allreduce_bf16_payload": alt_bf16} if alt_bf16 else {}),
             **alts,
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "rccl_version": getattr(comm, "version", None),
