@@ -206,7 +206,9 @@ def main():
                         ra.step(pool[i % POOL])
                         rb.step(pool[i % POOL])
                 torch.cuda.synchronize()
-                chk = torch.stack([ea.param.double().sum(), ea.param.double().abs().sum()])
+                ddp.gather_sharded_params(ea)
+                chk = torch.stack([ea.param.double().sum(), ea.param.double().abs().sum(),
+                                   ea.buffer("W4b", torch.bfloat16, (-1,)).double().abs().sum()])
                 lo, hi = chk.clone(), chk.clone()
                 dist.all_reduce(lo, op=dist.ReduceOp.MIN)
                 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -239,7 +241,9 @@ def main():
             # arena per rank, all-gather parameters; =allreduce: all-reduce + the full update on every rank
             runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1", sharded=sharded)
             ddp_mode = ("sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the arena -> "
-                        "fp32 all-gather of the parameters, all issued by rv_plan_step_ddp on its own stream" % world) \
+                        "all-gather of %s, all issued by rv_plan_step_ddp on its own stream"
+                        % (world, "the 16-bit parameter message (bf16 weights + fp32 biases)"
+                           if getattr(eng, "shard_gather", "fp32") == "bf16" else "the fp32 parameters")) \
                 if sharded else ("fp32, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its own "
                                  "stream, overlapped with backward")
             ddp_mode += ", hipGraph" if runner.use_graph else ""
@@ -320,7 +324,10 @@ def main():
         last = eng.losses(min(8, args.steps))
         replicas_consistent = None
         if world > 1:  # replicas must hold identical weights after identical averaged updates
-            chk = torch.stack([eng.param.double().sum(), eng.param.double().abs().sum()])
+            ddp.gather_sharded_params(eng)   # 16-bit parameter message: fp32 weight masters live on their owners
+            chk = torch.stack([eng.param.double().sum(), eng.param.double().abs().sum(),
+                               eng.buffer("W1b", torch.bfloat16, (-1,)).double().sum(),
+                               eng.buffer("W4b", torch.bfloat16, (-1,)).double().abs().sum()])
             lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)

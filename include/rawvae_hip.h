@@ -318,6 +318,19 @@ int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, lon
  *   itself, which is how rv_plan_refresh_shadows rebuilds all shadows in one launch) AND every operand shadow of the
  *   `descs` tensors from a flat fp32 source (an
  *   all-gather's output): arena element o is flat[o - flat_base]. */
+/* The same exchange with a 16-bit parameter message (half the all-gather bytes).  After updating its shard a rank
+ * encodes it: bf16 (round to nearest even, the rounding of the operand shadows) of the shard's `cnt` elements,
+ * followed by the bucket's bias elements as fp32 (a rank fills those it owns, zeroes the rest);
+ * rv_shard_msg_slots gives the message length in 16-bit slots (a multiple of 8).  An all-gather of that many slots
+ * per rank lets rv_shadows_from_msg rebuild every bf16 weight shadow and, exactly, every bias (fp32 shadow and the
+ * parameter arena) of the `descs` tensors from the rank-major gathered buffer.  fp32 weight masters then stay current
+ * on their owner rank only (gather them before a checkpoint, like the moments).  Tensors with an fp8 shadow are
+ * refused: their shadow is derived from the fp32 value. */
+long rv_shard_msg_slots(const rv_param_desc* descs, int n_desc, long cnt);
+int rv_shard_encode(const rv_param_desc* descs, int n_desc, const float* param, long own, long n, long cnt, void* msg,
+                    void* stream);
+int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg, long lo, long cnt, long slots,
+                        float* param, void* stream);
 int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
                  float grad_scale, const long long* step_counter, void* stream);
 int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
@@ -513,6 +526,13 @@ typedef int (*rv_reduce_scatter_fn)(const void* sendbuf, void* recvbuf, size_t r
                                     void* stream);
 typedef int (*rv_all_gather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, void* stream);
 long rv_plan_shard_count(const rv_plan*, int bucket, int world);
+/* Sharded mode with the 16-bit parameter message (rv_shard_encode / rv_shadows_from_msg below) instead of the fp32
+ * all-gather: half the bytes of the exchange nothing hides.  msg_send holds the sum over the two buckets of
+ * rv_plan_shard_msg_slots 16-bit slots, msg_recv `world` times that (caller-owned, 16-byte aligned); NULL, NULL
+ * returns to the fp32 all-gather.  Weight shadows and biases are bit-identical to the fp32 route on every rank;
+ * fp32 weight masters are current on their owner rank only.  Not available with the fp8 forward. */
+long rv_plan_shard_msg_slots(const rv_plan*, int bucket, int world);
+int rv_plan_set_shard_message(rv_plan*, void* msg_send, void* msg_recv);
 int rv_plan_attach_comm_sharded(rv_plan*, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
                                 int world, int rank, float* rs_buf, float* ag_buf);
 /* Payload of the gradient all-reduces: bf16_arena == NULL = fp32 (default, exact mean of the ranks' fp32

@@ -153,6 +153,11 @@ _SIGS = {
     "rv_params_from_flat": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_plan_set_ddp_payload": (c_int, [c_void_p, c_void_p]),
     "rv_plan_set_comm_stream": (c_int, [c_void_p, c_void_p]),
+    "rv_plan_shard_msg_slots": (c_long, [c_void_p, c_int, c_int]),
+    "rv_plan_set_shard_message": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rv_shard_msg_slots": (c_long, [C.POINTER(ParamDesc), c_int, c_long]),
+    "rv_shard_encode": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
+    "rv_shadows_from_msg": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_grad_finalize_bf16": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
     "rv_adam_multi_bf16grad": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_float, c_float, c_void_p, c_void_p]),

@@ -747,6 +747,79 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
   }
 }
 
+
+// ------------------------------------------------------------------ sharded optimizer: 16-bit parameter message
+// What a rank sends after updating its shard [own, own + n) of a bucket [lo, hi) cut into shards of `cnt` elements:
+//   slots [0, cnt)              bf16 (round to nearest even, the rounding of every operand shadow) of param[own + i]
+//   slots [cnt, cnt + 2 nbias)  the bucket's bias elements as fp32 (two slots each, in arena order over the bucket's
+//                               bias tensors); a rank fills the ones it owns and zeroes the others
+// so that an all-gather of cnt + 2 nbias 16-bit slots per rank (half the bytes of the fp32 parameters) lets every rank
+// rebuild every bf16 weight shadow and -- exactly -- every bias.  fp32 weight masters stay current on their owner.
+struct MsgBias { long offset, n, side; };            // arena offset, elements, first index in the side region
+struct MsgBiasTable { MsgBias b[4]; int n; };
+
+__global__ void __launch_bounds__(256)
+k_shard_encode(const float* __restrict__ param, const long own, const long n, const long cnt, const MsgBiasTable bt,
+               const long nbias, unsigned short* __restrict__ msg) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt) {
+    bf16_t v = (bf16_t)(i < n ? param[own + i] : 0.f);
+    msg[i] = *reinterpret_cast<unsigned short*>(&v);
+  }
+  if (i < nbias) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < bt.n && i >= bt.b[t].side && i < bt.b[t].side + bt.b[t].n) {
+        const long o = bt.b[t].offset + (i - bt.b[t].side);
+        if (o >= own && o < own + n) v = param[o];
+      }
+    }
+    reinterpret_cast<float*>(msg + cnt)[i] = v;
+  }
+}
+
+struct MsgTensor { long offset, rows, cols; bf16_t* shadow_bf16; float* shadow_f32; long shadow_ld; long side; };
+struct MsgTable { MsgTensor t[8]; long blk_start[9]; int n; };
+
+// Every operand shadow of the table's tensors from the gathered messages (rank-major, `slots` 16-bit slots per
+// rank); bias tensors (shadow_f32 != null) also refresh the fp32 parameter arena.  256 threads x 4 elements.
+__global__ void __launch_bounds__(256)
+k_shadows_from_msg(const MsgTable tab, const unsigned short* __restrict__ msg, const long lo, const long cnt,
+                   const long slots, float* __restrict__ param) {
+  const long vblock = blockIdx.x;
+  int t = 0;
+  while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
+  t = __builtin_amdgcn_readfirstlane(t);
+  const MsgTensor d = tab.t[t];
+  const long gpr = (d.cols + 3) / 4;
+  const long grp = (vblock - tab.blk_start[t]) * 256 + threadIdx.x;
+  if (grp >= gpr * d.rows) return;
+  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
+  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
+  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
+  const long o = d.offset + r * d.cols + c;
+  if (d.shadow_f32) {   // a bias row: exact fp32 from its owner's side region
+    for (int j = 0; j < nvalid; ++j) {
+      const long rk = (o + j - lo) / cnt;
+      const float v = reinterpret_cast<const float*>(msg + rk * slots + cnt)[d.side + c + j];
+      d.shadow_f32[c + j] = v;
+      param[o + j] = v;
+    }
+    return;
+  }
+  bf16_t* sp = d.shadow_bf16 + r * d.shadow_ld + c;
+  const long rk = (o - lo) / cnt, idx = (o - lo) - rk * cnt;
+  if (nvalid == 4 && idx + 4 <= cnt && (idx & 3) == 0 && (d.shadow_ld & 3) == 0) {
+    *reinterpret_cast<uint2*>(sp) = *reinterpret_cast<const uint2*>(msg + rk * slots + idx);
+  } else {
+    for (int j = 0; j < nvalid; ++j) {
+      const long rj = (o + j - lo) / cnt, ij = (o + j - lo) - rj * cnt;
+      reinterpret_cast<unsigned short*>(sp)[j] = msg[rj * slots + ij];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1049,6 +1122,67 @@ int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* fla
     RV_REQUIRE(descs[i].offset >= flat_base, RV_ERR_SHAPE, "rv_params_from_flat: tensor %d starts before the flat source", i);
   hipLaunchKernelGGL(k_params_from_flat, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0, (hipStream_t)stream, tab,
                      flat, flat_base, param);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+// ---- sharded optimizer, 16-bit parameter message (see k_shard_encode)
+static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* bt, long* nbias) {
+  bt->n = 0;
+  *nbias = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    if (!descs[i].shadow_f32) continue;   // bias tensors carry a padded fp32 shadow, weights a bf16 one
+    RV_REQUIRE(descs[i].rows == 1 && bt->n < 4, RV_ERR_SHAPE, "shard message: at most four bias rows per bucket");
+    bt->b[bt->n++] = MsgBias{descs[i].offset, descs[i].cols, *nbias};
+    *nbias += descs[i].cols;
+  }
+  return RV_OK;
+}
+
+long rv_shard_msg_slots(const rv_param_desc* descs, int n_desc, long cnt) {
+  MsgBiasTable bt;
+  long nbias = 0;
+  if (!descs || msg_bias_table(descs, n_desc, &bt, &nbias)) return -1;
+  return (cnt + 2 * nbias + 7) / 8 * 8;
+}
+
+int rv_shard_encode(const rv_param_desc* descs, int n_desc, const float* param, long own, long n, long cnt, void* msg,
+                    void* stream) {
+  RV_REQUIRE(descs && param && msg, RV_ERR_NULL, "rv_shard_encode: null pointer");
+  RV_REQUIRE(cnt > 0 && cnt % 4 == 0 && n >= 0 && n <= cnt && ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE,
+             "rv_shard_encode: shard of %ld in slots of %ld", n, cnt);
+  MsgBiasTable bt;
+  long nbias = 0;
+  int rc = msg_bias_table(descs, n_desc, &bt, &nbias);
+  if (rc) return rc;
+  const long total = cnt > nbias ? cnt : nbias;
+  hipLaunchKernelGGL(k_shard_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, own, n, cnt,
+                     bt, nbias, (unsigned short*)msg);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg, long lo, long cnt, long slots, float* param,
+                        void* stream) {
+  RV_REQUIRE(descs && msg && param, RV_ERR_NULL, "rv_shadows_from_msg: null pointer");
+  RV_REQUIRE(n_desc >= 1 && n_desc <= 8 && cnt > 0 && cnt % 4 == 0 && slots >= cnt && slots % 8 == 0 &&
+                 ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE, "rv_shadows_from_msg: bad extents");
+  MsgTable tab;
+  tab.n = n_desc;
+  long blk = 0, side = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    const rv_param_desc& d = descs[i];
+    RV_REQUIRE(d.rows > 0 && d.cols > 0 && d.offset >= lo && (d.shadow_bf16 || d.shadow_f32) && !d.shadow_fp8, RV_ERR_SHAPE,
+               "rv_shadows_from_msg: tensor %d has no shadow to write (or an fp8 one: gather fp32 parameters instead)", i);
+    RV_REQUIRE(d.rows * ((d.cols + 3) / 4) < 0x7fffffffL, RV_ERR_SHAPE, "rv_shadows_from_msg: tensor %d too large", i);
+    tab.t[i] = MsgTensor{d.offset, d.rows, d.cols, (bf16_t*)d.shadow_bf16, d.shadow_f32, d.shadow_ld, side};
+    if (d.shadow_f32) side += d.cols;
+    tab.blk_start[i] = blk;
+    blk += (d.rows * ((d.cols + 3) / 4) + 255) / 256;
+  }
+  tab.blk_start[n_desc] = blk;
+  hipLaunchKernelGGL(k_shadows_from_msg, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, tab, (const unsigned short*)msg, lo,
+                     cnt, slots, param);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

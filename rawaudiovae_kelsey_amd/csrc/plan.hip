@@ -71,6 +71,9 @@ struct rv_plan {
   int rank = 0;
   float* rs_buf = nullptr;
   float* ag_buf = nullptr;
+  // 16-bit parameter message instead of the fp32 all-gather (rv_plan_set_shard_message): send / receive buffers
+  unsigned short* msg_send = nullptr;
+  unsigned short* msg_recv = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
   int slab_dtype = RV_SLAB_F32;   // element type of the dW1 / dW4 split-K slabs (rv_plan_set_slab_dtype)
@@ -698,6 +701,23 @@ int rv_plan_attach_comm_sharded(rv_plan* p, rv_reduce_scatter_fn reduce_scatter,
   return RV_OK;
 }
 
+long rv_plan_shard_msg_slots(const rv_plan* p, int bucket, int world) {
+  if (!p || !p->bound || world < 1 || bucket < 0 || bucket > 1) return -1;
+  return bucket == 0 ? rv_shard_msg_slots(p->d_slab + 8, 2, shard_count(p->off[8], p->n_params, world))
+                     : rv_shard_msg_slots(p->d_slab, 8, shard_count(0, p->off[8], world));
+}
+
+int rv_plan_set_shard_message(rv_plan* p, void* msg_send, void* msg_recv) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_shard_message: null plan");
+  RV_REQUIRE((msg_send == nullptr) == (msg_recv == nullptr), RV_ERR_NULL, "rv_plan_set_shard_message: both buffers or neither");
+  RV_REQUIRE((((uintptr_t)msg_send | (uintptr_t)msg_recv) & 15) == 0, RV_ERR_SHAPE, "rv_plan_set_shard_message: buffers must be 16-byte aligned");
+  RV_REQUIRE(!(msg_send && p->fp8), RV_ERR_UNSUPPORTED, "rv_plan_set_shard_message: the fp8 shadows are derived from fp32 parameters; "
+             "use the fp32 all-gather with the fp8 forward");
+  p->msg_send = (unsigned short*)msg_send;
+  p->msg_recv = (unsigned short*)msg_recv;
+  return RV_OK;
+}
+
 // One sharded data-parallel step (see rv_plan_attach_comm_sharded in the header).  Collectives run on the internal
 // stream in the order RS(fc4) RS(rest) AG(fc4) AG(rest); it forks from and joins into the caller's stream only.
 static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
@@ -753,18 +773,39 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     own_of(b, &own, &n);
     RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, stream));
   }
-  RV_HIP(hipEventRecord(p->ev_upd[0], s0));
-  RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
-  for (int b = 0; b < 2; ++b) {
-    long own, n;
-    own_of(b, &own, &n);
-    const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)sc);
-    if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
+  if (p->msg_send && !p->fp8) {
+    // 16-bit parameter message: bf16 of the shard + the bucket's biases in fp32 (half the all-gather bytes)
+    const long slots[2] = {rv_shard_msg_slots(p->d_slab + t0_b[0], nt_b[0], cnt[0]),
+                           rv_shard_msg_slots(p->d_slab + t0_b[1], nt_b[1], cnt[1])};
+    unsigned short* snd[2] = {p->msg_send, p->msg_send + slots[0]};
+    unsigned short* rcv[2] = {p->msg_recv, p->msg_recv + (long)p->world * slots[0]};
+    for (int b = 0; b < 2; ++b) {
+      long own, n;
+      own_of(b, &own, &n);
+      RV_TRY(rv_shard_encode(p->d_slab + t0_b[b], nt_b[b], p->b.param, lo_b[b] + (long)p->rank * cnt[b], n, cnt[b], snd[b], stream));
+    }
+    RV_HIP(hipEventRecord(p->ev_upd[0], s0));
+    RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
+    for (int b = 0; b < 2; ++b) {
+      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, (void*)sc);
+      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter message %d failed (collective library code %d)", b, nrc);
+    }
+    RV_HIP(hipEventRecord(p->ev_gath[0], sc));
+    RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
+    for (int b = 0; b < 2; ++b)
+      RV_TRY(rv_shadows_from_msg(p->d_slab + t0_b[b], nt_b[b], rcv[b], lo_b[b], cnt[b], slots[b], p->b.param, stream));
+  } else {
+    RV_HIP(hipEventRecord(p->ev_upd[0], s0));
+    RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
+    for (int b = 0; b < 2; ++b) {
+      const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)sc);
+      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
+    }
+    RV_HIP(hipEventRecord(p->ev_gath[0], sc));
+    RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
+    for (int b = 0; b < 2; ++b)
+      RV_TRY(rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, stream));
   }
-  RV_HIP(hipEventRecord(p->ev_gath[0], sc));
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
-  for (int b = 0; b < 2; ++b)
-    RV_TRY(rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, stream));
 #undef RV_TRY
   return RV_OK;
 }

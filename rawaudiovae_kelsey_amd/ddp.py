@@ -119,6 +119,25 @@ def gather_sharded_moments(engine, group=None):
             arena[lo:hi].copy_(torch.cat(parts)[:hi - lo])
 
 
+def gather_sharded_params(engine, group=None):
+    """Sharded optimizer with the 16-bit parameter message: fp32 WEIGHT masters are current on their owner rank only
+    (operand shadows and biases are current everywhere).  Before a checkpoint, an exact-fp32 evaluation or a
+    comparison of replicas every rank calls this; afterwards each rank's parameter arena is complete and current
+    (an all-gather of the shards over torch.distributed -- any backend; checkpoint time only)."""
+    sp = getattr(engine, "shard_plan", None)
+    if sp is None or sp.world == 1 or not dist.is_initialized() or getattr(engine, "shard_gather", "fp32") != "bf16":
+        return
+    rank = dist.get_rank(group)
+    arena = engine._arena_full[0]
+    for b in (0, 1):
+        lo, hi = sp.buckets[b]
+        cnt = sp.counts[b]
+        mine = arena[lo + rank * cnt: lo + (rank + 1) * cnt].clone()
+        parts = [torch.empty_like(mine) for _ in range(sp.world)]
+        dist.all_gather(parts, mine, group=group)
+        arena[lo:hi].copy_(torch.cat(parts)[:hi - lo])
+
+
 def engine_buckets(engine):
     """Buckets in the order their gradients become available in backward:
     fc4 (after the paired fc4 backward), fc1 (end of the dependent chain), then fc21/fc22/fc3."""
@@ -361,12 +380,12 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32", sharded=False):
+    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32", sharded=False, gather=None):
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
         self.sharded = bool(sharded)
         if stream is not None:
             engine._pick_comm_stream(stream)    # before any capture: the choice times a few launches
-        engine.attach_comm(comm, sharded=self.sharded)
+        engine.attach_comm(comm, sharded=self.sharded, gather=gather)
         self._graphs = {}
         if not self.sharded:
             self.set_payload(payload)

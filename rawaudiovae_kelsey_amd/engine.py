@@ -237,11 +237,15 @@ class TrainEngine:
             self._shadow_version = self._shared["version"]
             _ops_invalidate()
 
-    def attach_comm(self, comm, sharded=False):
+    def attach_comm(self, comm, sharded=False, gather=None):
         """Data-parallel mode with the collectives issued by the library itself: `comm` is a `ddp.RcclComm`
         (RCCL communicator + the addresses of its collectives).  sharded: optimizer state and update sharded
         over the ranks (reduce-scatter gradients, Adam on the own shard, all-gather parameters) instead of an
-        all-reduce followed by the full update on every rank."""
+        all-reduce followed by the full update on every rank.  gather (sharded only): "bf16" (default without
+        the fp8 forward) all-gathers a 16-bit message -- bf16 of the updated weights plus the biases in fp32,
+        half the bytes; every rank's operand shadows and biases are bit-identical to the "fp32" route, but fp32
+        weight masters are then current on their owner rank only (`ddp.gather_sharded_params` before a
+        checkpoint); "fp32" all-gathers the fp32 parameters."""
         if sharded:
             from .ddp import ShardPlan
             self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
@@ -253,6 +257,21 @@ class TrainEngine:
             self._ag_buf = torch.zeros(self.shard_plan.ag_elems, **f32)
             lib().rv_plan_attach_comm_sharded(self._plan, comm.reduce_scatter_addr, comm.all_gather_addr, comm.handle,
                                               comm.world, comm.rank, ptr(self._rs_buf), ptr(self._ag_buf))
+            gather = gather or ("fp32" if self.fp8 else "bf16")
+            if gather not in ("bf16", "fp32") or (gather == "bf16" and self.fp8):
+                raise _lib.RvError("attach_comm: gather=%r (expected 'bf16' or 'fp32'; 'bf16' not with the fp8 forward)" % (gather,))
+            self.shard_gather = gather
+            if gather == "bf16":
+                slots = [lib().rv_plan_shard_msg_slots(self._plan, b, comm.world) for b in (0, 1)]
+                if min(slots) <= 0:
+                    raise _lib.RvError("rv_plan_shard_msg_slots failed")
+                i16 = dict(dtype=torch.int16, device=self.device)
+                self._msg_send = torch.zeros(sum(slots), **i16)
+                self._msg_recv = torch.zeros(comm.world * sum(slots), **i16)
+                self.msg_slots = slots
+                lib().rv_plan_set_shard_message(self._plan, ptr(self._msg_send), ptr(self._msg_recv))
+            else:
+                lib().rv_plan_set_shard_message(self._plan, None, None)
         else:
             lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
         self._comm = comm   # keep the communicator alive as long as the plan can use it

@@ -106,17 +106,19 @@ with torch.cuda.stream(st):
     for _ in range(5):
         ref.step(x, stream=st)
 st.synchronize()
-sh = fresh(); sh.attach_comm(comm, sharded=True)
-with torch.cuda.stream(st):
-    for _ in range(5):
-        sh.step_ddp(x, stream=st)
-st.synchronize()
-assert torch.equal(sh.param, ref.param) and torch.equal(sh.exp_avg, ref.exp_avg) and torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
-assert sh.losses(5) == ref.losses(5)
-for name in ("W1b", "Whb", "W3b", "W4b", "b1p", "b4p"):
-    dt = torch.bfloat16 if name.startswith("W") else torch.float32
-    a, b = sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))
-    assert torch.equal(a, b), name
+for gather in ("bf16", "fp32"):      # the 16-bit parameter message (default) and the fp32 all-gather
+    sh = fresh(); sh.attach_comm(comm, sharded=True, gather=None if gather == "bf16" else gather)
+    assert sh.shard_gather == gather
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            sh.step_ddp(x, stream=st)
+    st.synchronize()
+    assert torch.equal(sh.param, ref.param) and torch.equal(sh.exp_avg, ref.exp_avg) and torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
+    assert sh.losses(5) == ref.losses(5)
+    for name in ("W1b", "Whb", "W3b", "W4b", "b1p", "bhp", "b3p", "b4p"):
+        dt = torch.bfloat16 if name.startswith("W") else torch.float32
+        a, b = sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))
+        assert torch.equal(a, b), (gather, name)
 shg = fresh()
 run = ddp.NativeDdpRunner(shg, comm, st, use_graph=True, sharded=True)
 with torch.cuda.stream(st):
@@ -130,6 +132,55 @@ print("NATIVE_OK")
 ''' % REPO
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0 and "NATIVE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_16bit_message_rebuilds_shadows_and_biases(world):
+    """The sharded optimizer's 16-bit parameter message (rv_shard_encode -> all-gather -> rv_shadows_from_msg), all
+    ranks emulated one after the other on this GPU: every bf16 weight shadow and every fp32 bias shadow / bias
+    parameter rebuilt from the gathered messages alone must equal the fp32 route's, bit for bit (C2-shaped and an
+    odd-sized model whose shards cut through tensors and 4-element groups)."""
+    from oracle.inputs import make_params
+    from rawaudiovae_kelsey_amd import _lib as P
+    from rawaudiovae_kelsey_amd import engine as E
+    from rawaudiovae_kelsey_amd._lib import lib, ptr, stream_ptr
+    from rawaudiovae_kelsey_amd.ddp import ShardPlan
+    L_ = lib()
+    names = (("W1b", torch.bfloat16), ("Whb", torch.bfloat16), ("W3b", torch.bfloat16), ("W4b", torch.bfloat16),
+             ("b1p", torch.float32), ("bhp", torch.float32), ("b3p", torch.float32), ("b4p", torch.float32))
+    for (S, H, Ld, B) in ((256, 512, 16, 128), (100, 200, 5, 37)):
+        ref = E.TrainEngine(S, H, Ld, B, seed=3); ref.load_params(make_params(S, H, Ld, 1))   # its shadows = truth
+        sh = E.TrainEngine(S, H, Ld, B, seed=3); sh.load_params(make_params(S, H, Ld, 1))
+        sp = ShardPlan(sh.offsets["fc4.weight"], sh.n_params, world)
+        descs = sh.plan_descs()
+        truth = sh.param.clone()
+        for name, dt in names:
+            sh.buffer(name, dt, (-1,)).zero_()           # everything must come back from the messages
+        sh.param.zero_()
+        for b, (t0, nt) in ((0, (8, 2)), (1, (0, 8))):
+            arr = (P.ParamDesc * nt)(*descs[t0:t0 + nt])
+            lo, hi = sp.buckets[b]
+            cnt = sp.counts[b]
+            slots = L_.rv_shard_msg_slots(arr, nt, cnt)
+            assert slots == L_.rv_plan_shard_msg_slots(sh._plan, b, world) and slots % 8 == 0 and slots >= cnt
+            gathered = torch.zeros(world * slots, dtype=torch.int16, device="cuda")
+            for r in range(world):
+                a, e = sp.own(b, r)
+                # a rank only knows its own shard's fp32 values: poison the rest while it encodes
+                local = torch.full((sh._arena_full[0].numel(),), float("nan"), device="cuda")
+                local[a:e] = truth[a:e]
+                L_.rv_shard_encode(arr, nt, ptr(local), lo + r * cnt, e - a, cnt, gathered[r * slots:].data_ptr(), stream_ptr())
+                torch.cuda.synchronize()
+            L_.rv_shadows_from_msg(arr, nt, ptr(gathered), lo, cnt, slots, ptr(sh.param), stream_ptr())
+        torch.cuda.synchronize()
+        for name, dt in names:
+            assert torch.equal(sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))), (name, world, (S, H, Ld, B))
+        for k in E.PARAM_NAMES:        # biases come back exactly; weight masters are not part of the message
+            got, want = sh.view(sh.param, k), ref.view(ref.param, k)
+            if k.endswith("bias"):
+                assert torch.equal(got, want), k
+            else:
+                assert float(got.abs().max()) == 0.0, k
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

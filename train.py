@@ -139,19 +139,25 @@ class DataParallel:
             # RV_DDP_MODE=sharded: reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
             # all-gather the parameters; =allreduce: all-reduce and the full update on every rank
             self.sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
-            engine.attach_comm(self.comm, sharded=self.sharded)
+            # sharded: fp32 parameters are all-gathered by default here (every rank's masters stay current for the
+            # per-epoch histograms and evaluation); RV_SHARD_GATHER=bf16 selects the 16-bit message (half the bytes,
+            # masters gathered at checkpoints by sync_optimizer_state)
+            engine.attach_comm(self.comm, sharded=self.sharded,
+                               gather=os.environ.get("RV_SHARD_GATHER", "fp32") if self.sharded else None)
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
         sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
         return lambda x: ddp.ddp_step(engine, sync, x)
 
     def sync_optimizer_state(self, engine):
-        """Before a checkpoint (every rank calls it): with the sharded optimizer the Adam moments live on their
-        owner ranks; gather them so that rank 0's optimizer_state_dict() is complete."""
+        """Before a checkpoint or an evaluation (every rank calls it): with the sharded optimizer the Adam moments
+        -- and, with the 16-bit parameter message, the fp32 weight masters -- live on their owner ranks; gather
+        them so that rank 0's state_dict() / optimizer_state_dict() are complete."""
         if self.active and self.sharded:
             from rawaudiovae_kelsey_amd import ddp
             torch.cuda.synchronize(self.device)
             ddp.gather_sharded_moments(engine)
+            ddp.gather_sharded_params(engine)
 
     def mean(self, value):
         """Mean over ranks of a host scalar."""
@@ -417,8 +423,8 @@ def main(argv=None):
                 print("Loss did not improve.")
         final_loss = train_loss
 
-    dp.check_replicas(engine)
     dp.sync_optimizer_state(engine)
+    dp.check_replicas(engine)
     if dp.main:
         print('Last Checkpoint - Epoch {}'.format(epoch))
         if generate_test:
