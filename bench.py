@@ -57,9 +57,8 @@ def parse():
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
     ap.add_argument("--fp8", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--no-alts", action="store_true",
-                    help="skip the side lines `alt_fp8` (fc1 / fc4 forward on e4m3 operands, BASELINE configs[4]), "
-                         "`alt_fp16_slabs` and `alt_fp8_fp16_slabs`; they are timed after the headline at N=1 and never "
-                         "replace it")
+                    help="skip the side lines `alt_fp8` (fc1 / fc4 forward on e4m3 operands, BASELINE configs[4]) and "
+                         "`alt_fp32_slabs`; they are timed after the headline at N=1 and never replace it")
     ap.add_argument("--slab-dtype", default=None, choices=["fp32", "fp16"],
                     help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
     ap.add_argument("--n128-loop", type=int, default=0,
@@ -88,14 +87,17 @@ def time_dominant_kernel(eng, reps=50):
     dP3 = torch.empty((Bp, Hp), dtype=torch.bfloat16, device="cuda")
     cs = torch.empty((Bp // bm) * Hp, dtype=torch.float32, device="cuda")
     dW4 = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
+    half = eng.slab_dtype == "fp16"      # the slab element type the step itself uses
+    us = torch.empty(splits * (Sp // 32) * (Hp // 32), dtype=torch.float32, device="cuda")
     st = stream_ptr()
     e0, e1 = C.c_void_p(), C.c_void_p()
     Lb.rv_event_create(C.byref(e0))
     Lb.rv_event_create(C.byref(e1))
 
     def launch():
-        Lb.rv_linear_dgrad_wgrad(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, Bp, Hp, Sp,
-                                 dP3.data_ptr(), Hp, cs.data_ptr(), dW4.data_ptr(), Hp, splits, st)
+        Lb.rv_linear_dgrad_wgrad_ex(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, None, 0, Bp, Hp, Sp,
+                                    dP3.data_ptr(), Hp, cs.data_ptr(), dW4.data_ptr(), Hp, splits, int(half),
+                                    us.data_ptr() if half else None, st)
     for _ in range(5):
         launch()
     Lb.rv_event_record(e0, st)
@@ -107,7 +109,7 @@ def time_dominant_kernel(eng, reps=50):
     Lb.rv_event_destroy(e0)
     Lb.rv_event_destroy(e1)
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
-            "dW=dY^T X 1024x2048x4096 split-K %d)" % splits) if paired else \
+            "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
     return ms.value / reps, 4.0 * S * H * B, desc
 
@@ -482,10 +484,9 @@ def main():
             alts["alt_fp8"] = time_alt(
                 "fc1 and fc4 forward on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor scales, delayed "
                 "activation scaling); backward and everything else bf16", fp8=True)
-            alts["alt_fp16_slabs"] = time_alt(
-                "split-K partial sums of dW1 / dW4 stored as fp16(partial * 4096) instead of fp32 (summed in fp32 by "
-                "Adam); everything else as the headline", slab_dtype="fp16")
-            alts["alt_fp8_fp16_slabs"] = time_alt("both of the above", fp8=True, slab_dtype="fp16")
+            alts["alt_fp32_slabs"] = time_alt(
+                "split-K partial sums of dW1 / dW4 stored as fp32 instead of block-floating-point fp16 (round 2's "
+                "default); everything else as the headline", slab_dtype="fp32")
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
         print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)

@@ -146,15 +146,19 @@ int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx
 /* The same on a named block tile instead of the picker's choice (extents must be multiples of it; `splits`
  * must divide Kp/64).  RV_TILE_256x256 runs the ping-pong main loop when Kp/64/splits is even. */
 enum { RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x256 = 7 };
-/* Split-K slab element type of a weight gradient: fp32, or fp16 holding fp16(partial * slab_scale) (slab_scale a power
- * of two; same element strides; the sum over slabs stays fp32 in rv_adam_multi / rv_grad_finalize, which are told by
- * rv_param_desc.grad_half / grad_unscale).  Halves the bytes the GEMM writes and the optimizer reads back. */
+/* Split-K slab element type of a weight gradient: fp32, or block-floating-point fp16 -- fp16(partial * 2^e) with
+ * one exponent e per wave tile of one slab, taken from that tile's own largest magnitude, so gradients of ANY
+ * magnitude keep fp16's 11 significant bits relative to their tile (same element strides as fp32 slabs).  The GEMM
+ * writes the factors that undo the scales, 2^-e, to `slab_unscale`: [splits][Mp / 32][Np / 32] fp32, one per
+ * 32 x 32 granule of each slab (required with RV_SLAB_F16, ignored with RV_SLAB_F32).  The sum over slabs stays fp32
+ * in rv_adam_multi / rv_grad_finalize, which are told by rv_param_desc.grad_half / grad_unscale.  Halves the bytes
+ * the GEMM writes and the optimizer reads back. */
 enum { RV_SLAB_F32 = 0, RV_SLAB_F16 = 1 };
 int rv_linear_wgrad_tile(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np,
-                         long Kp, int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float slab_scale,
+                         long Kp, int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
                          void* stream);
 int rv_linear_wgrad_ex(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
-                       int splits, void* dw_slabs, long lddw, int slab_dtype, float slab_scale, void* stream);
+                       int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale, void* stream);
 
 /* Reparameterisation forward, model.py:23-26, fused with the KL half of
  * loss_function (model.py:45):
@@ -283,8 +287,10 @@ typedef struct rv_param_desc {
   long shadow_ld;
   void* shadow_fp8;        /* padded fp8 (e4m3) copy fp8(w * *fp8_scale), leading dim shadow_ld, or NULL */
   const float* fp8_scale;  /* device scalar */
-  int grad_half;           /* non-zero: grad_slabs holds fp16 values fp16(partial * 2^k) (same element strides) ... */
-  float grad_unscale;      /* ... and this is 2^-k */
+  int grad_half;           /* non-zero: grad_slabs holds fp16 values fp16(partial * 2^e) (same element strides), e per */
+  const float* grad_unscale; /* 32 x 32 granule and slab: element (r,c) of slab s is scaled back by                 */
+  long us_ld;              /*   grad_unscale[s*us_split_stride + (r/32)*us_ld + c/32]                               */
+  long us_split_stride;    /* (the table a weight-gradient GEMM writes with RV_SLAB_F16)                            */
 } rv_param_desc;
 
 /* torch.optim.Adam(lr) step (train.py:163,193: betas 0.9/0.999, eps 1e-8, no weight
@@ -306,7 +312,7 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, vo
  * the CUs the GEMM's tiles * splits blocks leave idle.  rv_wgrad_adam_fits says whether the extents tile. */
 int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);
 int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
-                         int splits, void* dw_slabs, long lddw, int slab_dtype, float slab_scale,
+                         int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
                          const rv_param_desc* descs, int n_desc,
                          float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
                          const long long* step_counter, int n_adam_blocks, void* stream);
@@ -383,7 +389,7 @@ int rv_linear_dgrad_wgrad_mb(const void* dy_bf16, long lddy, const void* w_bf16,
 int rv_linear_dgrad_wgrad_ex(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
                              const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
                              float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype,
-                             float slab_scale, void* stream);
+                             float* slab_unscale, void* stream);
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
 int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
@@ -466,9 +472,10 @@ int rv_plan_set_external_grads(rv_plan*, const float* d_recon, const float* reco
  * Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them. */
 int rv_plan_set_fp8(rv_plan*, int enable);
 /* Element type of the split-K slabs of the two large weight gradients (fc1.weight, fc4.weight; 2 x 33.5 MB of fp32
- * slabs per step at C2): RV_SLAB_F32 (default) or RV_SLAB_F16 = fp16(partial * 2^12), which halves what the two
- * weight-gradient GEMMs write and Adam reads back.  Each partial is an fp32 sum over a quarter of the batch; rounding
- * it to fp16 adds ~3e-4 relative noise to those two gradients (the sum over slabs stays fp32). */
+ * slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see RV_SLAB_F16 above), which halves what
+ * the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32 sum over a
+ * quarter of the batch; rounding it to fp16 adds ~3e-4 relative noise to those two gradients whatever their
+ * magnitude (the sum over slabs stays fp32). */
 int rv_plan_set_slab_dtype(rv_plan*, int slab_dtype);
 /* The plan's ten parameter descriptors (PARAM order): gradient slabs of its own workspace (from_flat = 0) or the
  * bound flat gradient arena (1), and the operand shadows Adam must refresh.  For callers that drive

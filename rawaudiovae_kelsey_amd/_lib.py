@@ -22,7 +22,8 @@ class ParamDesc(C.Structure):
                 ("grad_slabs", c_void_p), ("grad_ld", c_long), ("grad_split_stride", c_long),
                 ("grad_splits", c_int), ("shadow_bf16", c_void_p), ("shadow_f32", c_void_p),
                 ("shadow_ld", c_long), ("shadow_fp8", c_void_p), ("fp8_scale", c_void_p),
-                ("grad_half", c_int), ("grad_unscale", c_float)]
+                ("grad_half", c_int), ("grad_unscale", c_void_p), ("us_ld", c_long),
+                ("us_split_stride", c_long)]
 
 
 class PlanBuffers(C.Structure):
@@ -93,16 +94,16 @@ _SIGS = {
     "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
                                 c_void_p, c_long, c_void_p]),
     "rv_linear_wgrad_tile": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int,
-                                     c_void_p, c_long, c_int, c_float, c_void_p]),
+                                     c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "rv_linear_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
-                                   c_int, c_float, c_void_p]),
+                                   c_int, c_void_p, c_void_p]),
     "rv_linear_dgrad_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
                                          c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int,
-                                         c_float, c_void_p]),
+                                         c_void_p, c_void_p]),
     "rv_plan_set_slab_dtype": (c_int, [c_void_p, c_int]),
     "rv_wgrad_adam_fits": (c_int, [c_long, c_long, c_long, c_int]),
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
-                                     c_int, c_float, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_int, c_void_p, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_int, c_void_p]),
     "rv_heads_reparam_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_long,
                                      c_int, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p,

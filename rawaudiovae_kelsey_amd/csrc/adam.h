@@ -16,56 +16,69 @@ struct DescTable {
 };
 
 
-// 4 consecutive elements of one slab: fp32, or fp16 slabs holding value * 2^k (grad_half; `grad_unscale` = 2^-k
-// undoes it exactly).  `off` is in elements either way.
+// 4 consecutive elements of one slab: fp32, or fp16 slabs holding value * 2^e with one exponent per 32 x 32
+// granule and slab (grad_half; the table grad_unscale[s * us_split_stride + (r / 32) * us_ld + c / 32] holds 2^-e,
+// which undoes it exactly -- written by the weight-gradient GEMM, gemm_bf16.h GemmArgs::out_f16).  `off` is in
+// elements either way; `us` is the factor of the slab the elements belong to (1 for fp32 slabs).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 load_slab4(const rv_param_desc& d, long off) {
+__device__ __forceinline__ float4 load_slab4(const rv_param_desc& d, long off, float us) {
   if (d.grad_half) {
     const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(d.grad_slabs) + off);
-    return make_float4((float)h[0] * d.grad_unscale, (float)h[1] * d.grad_unscale, (float)h[2] * d.grad_unscale,
-                       (float)h[3] * d.grad_unscale);
+    return make_float4((float)h[0] * us, (float)h[1] * us, (float)h[2] * us, (float)h[3] * us);
   }
   return *reinterpret_cast<const float4*>(d.grad_slabs + off);
 }
-__device__ __forceinline__ float load_slab1(const rv_param_desc& d, long off) {
-  if (d.grad_half) return (float)reinterpret_cast<const _Float16*>(d.grad_slabs)[off] * d.grad_unscale;
+__device__ __forceinline__ float load_slab1(const rv_param_desc& d, long off, float us) {
+  if (d.grad_half) return (float)reinterpret_cast<const _Float16*>(d.grad_slabs)[off] * us;
   return d.grad_slabs[off];
 }
+// Pointer to slab 0's factor for the granule of element (r, c); slab s is `us_split_stride` entries further.
+__device__ __forceinline__ const float* slab_unscale_ptr(const rv_param_desc& d, long r, long c) {
+  return d.grad_half ? d.grad_unscale + (r >> 5) * d.us_ld + (c >> 5) : nullptr;
+}
+__device__ __forceinline__ float slab_unscale(const rv_param_desc& d, const float* up, int s) {
+  return d.grad_half ? up[(long)s * d.us_split_stride] : 1.f;
+}
 
-// Sum of the gradient slabs for 4 consecutive elements of one row.
+// Sum of the gradient slabs for 4 consecutive elements of one row (they share a 32-column granule: c % 4 == 0).
 template <bool VEC>
 __device__ __forceinline__ float4 slab_sum4(const rv_param_desc& d, long r, long c, int nvalid) {
   const long base = r * d.grad_ld + c;
+  const float* up = slab_unscale_ptr(d, r, c);
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int s = 0;
   if constexpr (VEC) {
     for (; s + 4 <= d.grad_splits; s += 4) {  // 4 independent vector loads in flight
-      const float4 a = load_slab4(d, base + (long)(s + 0) * d.grad_split_stride);
-      const float4 b = load_slab4(d, base + (long)(s + 1) * d.grad_split_stride);
-      const float4 e = load_slab4(d, base + (long)(s + 2) * d.grad_split_stride);
-      const float4 f = load_slab4(d, base + (long)(s + 3) * d.grad_split_stride);
+      const float4 a = load_slab4(d, base + (long)(s + 0) * d.grad_split_stride, slab_unscale(d, up, s + 0));
+      const float4 b = load_slab4(d, base + (long)(s + 1) * d.grad_split_stride, slab_unscale(d, up, s + 1));
+      const float4 e = load_slab4(d, base + (long)(s + 2) * d.grad_split_stride, slab_unscale(d, up, s + 2));
+      const float4 f = load_slab4(d, base + (long)(s + 3) * d.grad_split_stride, slab_unscale(d, up, s + 3));
       g.x += (a.x + b.x) + (e.x + f.x); g.y += (a.y + b.y) + (e.y + f.y);
       g.z += (a.z + b.z) + (e.z + f.z); g.w += (a.w + b.w) + (e.w + f.w);
     }
     for (; s < d.grad_splits; ++s) {
-      const float4 a = load_slab4(d, base + (long)s * d.grad_split_stride);
+      const float4 a = load_slab4(d, base + (long)s * d.grad_split_stride, slab_unscale(d, up, s));
       g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
     }
   } else {
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (; s + 4 <= d.grad_splits; s += 4) {
+      const float u0 = slab_unscale(d, up, s), u1 = slab_unscale(d, up, s + 1), u2 = slab_unscale(d, up, s + 2),
+                  u3 = slab_unscale(d, up, s + 3);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < nvalid) {
           const long q = base + j + (long)s * d.grad_split_stride;
-          t[j] += (load_slab1(d, q) + load_slab1(d, q + d.grad_split_stride)) +
-                  (load_slab1(d, q + 2 * d.grad_split_stride) + load_slab1(d, q + 3 * d.grad_split_stride));
+          t[j] += (load_slab1(d, q, u0) + load_slab1(d, q + d.grad_split_stride, u1)) +
+                  (load_slab1(d, q + 2 * d.grad_split_stride, u2) + load_slab1(d, q + 3 * d.grad_split_stride, u3));
         }
     }
-    for (; s < d.grad_splits; ++s)
+    for (; s < d.grad_splits; ++s) {
+      const float u0 = slab_unscale(d, up, s);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nvalid) t[j] += load_slab1(d, base + j + (long)s * d.grad_split_stride);
+        if (j < nvalid) t[j] += load_slab1(d, base + j + (long)s * d.grad_split_stride, u0);
+    }
     g = make_float4(t[0], t[1], t[2], t[3]);
   }
   return g;
@@ -176,11 +189,13 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
     // lanes stride over the partial slabs, then a fixed-order butterfly: deterministic
     const int lane = tid & 63;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* up = slab_unscale_ptr(d, r, c);
     for (int s = lane; s < d.grad_splits; s += 64) {
       const long q = (long)s * d.grad_split_stride + r * d.grad_ld + c;
+      const float us = slab_unscale(d, up, s);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < nvalid) tsum[j] += load_slab1(d, q + j);
+        if (j < nvalid) tsum[j] += load_slab1(d, q + j, us);
     }
     g = make_float4(wave_sum(tsum[0]), wave_sum(tsum[1]), wave_sum(tsum[2]), wave_sum(tsum[3]));
     if (lane != 0) return;
@@ -290,9 +305,10 @@ __device__ __forceinline__ void adam_group(const DescTable& tab, const long vb0,
       v4[u] = *reinterpret_cast<const float4*>(v_arena + it[u].o);
       w4[u] = *reinterpret_cast<const float4*>(param + it[u].o);
       const long base = it[u].r * d.grad_ld + it[u].c;
+      const float* up = slab_unscale_ptr(d, it[u].r, it[u].c);
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
-        sl[u][s_] = s_ < d.grad_splits ? load_slab4(d, base + (long)s_ * d.grad_split_stride)
+        sl[u][s_] = s_ < d.grad_splits ? load_slab4(d, base + (long)s_ * d.grad_split_stride, slab_unscale(d, up, s_))
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float step_size, inv_bc2s;

@@ -47,11 +47,16 @@ struct GemmArgs {
   int relu;              // EPI_BIAS_ACT_BF16: apply ReLU
   float* out_f32;
   long ld_f32, split_stride_f32;
-  // EPI_F32 with fp16 split-K slabs: same element strides, values stored as fp16(value * f16_scale) (a power of two:
-  // weight-gradient partials are ~1e-6..1e-2 and fp16's exponent range is narrow).  Halves the slab bytes that a
-  // split-K weight gradient writes and that Adam reads back; the sum over slabs stays fp32.
+  // EPI_F32 with fp16 split-K slabs (block floating point): same element strides, values stored as
+  // fp16(value * 2^e) with ONE exponent per wave tile of one slab, chosen from that tile's own largest magnitude
+  // (so that it lands in [2^14, 2^15): any gradient magnitude keeps fp16's 11 significant bits relative to its
+  // tile).  The factor that undoes it, 2^-e, goes to f16_unscale[split * us_split_stride + (row / 32) * us_ld +
+  // col / 32] for every 32 x 32 granule the wave tile covers -- a fixed granule, so the reader (Adam) does not need
+  // to know the GEMM's tile configuration.  Halves the slab bytes that a split-K weight gradient writes and that
+  // Adam reads back; the sum over slabs stays fp32.
   void* out_f16;
-  float f16_scale;
+  float* f16_unscale;
+  long us_ld, us_split_stride;
   bf16_t* out_bf16;
   long ld_bf16;
   const float* bias;  // [N] (padded), may be null
@@ -505,6 +510,57 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   const long a_step = A_KMAJ ? 64 : 64 * p.lda;
   const long b_step = B_KMAJ ? 64 : 64 * p.ldb;
 
+  // Epilogue geometry (see the epilogue below): after the column-block pairing lane (eq = l>>4, ej = l&15) owns
+  // the (row, 8-column) items  row = roww + 16 * mi,  col = colw + 32 * t.
+  static_assert(NI % 2 == 0, "epilogue pairs column fragments");
+  constexpr int NP = NI / 2;                       // column-block pairs per wave tile
+  constexpr int CM = NP >= 2 ? 2 : (MI >= 4 ? 4 : MI);  // fragment rows per chunk (bounds live registers)
+  static_assert(MI % CM == 0, "chunking must divide the wave tile");
+  constexpr int CH = CM * NP;                      // (row, 8-column) items per chunk
+  const int eq = lane >> 4, ej = lane & 15;
+  const long colw = n0 + wn * WTN + (eq & 1) * 16 + (eq >> 1) * 8;   // + 32 * t
+  const long roww = m0 + wm * WTM + ej;                              // + 16 * mi
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+
+  // Epilogue operands that do not depend on the accumulators are fetched BEFORE the main loop, for the first
+  // chunk of the epilogue (the only one on the tiles the step uses for these GEMMs): the loss target of
+  // EPI_TANH_LOSS (fp32 frames) and the ReLU mask of EPI_MASK_BF16.  Issued ahead of every LDS-DMA of the ring
+  // they are the oldest entries of the in-order vmcnt queue, so the counted waits of the loop are unchanged, and
+  // the round trip to memory is over long before the epilogue, which used to start with it (3.7 us of the fc4
+  // forward, profiles/r02_gemm_decomp.txt).  Costs CH x 8 (target) / CH x 4 (mask) VGPRs across the loop.
+  // (The 256 x 256 ping-pong kernels have no registers to spare: their mask goes through LDS, below.)
+  constexpr bool PF_ROOM = !PINGPONG && !PINGPONG_N128 && MI * NI <= 16;   // accumulators take at most 64 VGPRs
+  constexpr bool PF_X = EPI == EPI_TANH_LOSS && PF_ROOM;
+  constexpr bool PF_MASK = EPI == EPI_MASK_BF16 && PF_ROOM;
+  float xpf[CH][8];
+  i32x4_ mpf[CH];
+  bool pf_on = false;   // wave-uniform
+  if constexpr (PF_X) {
+    const bool x_al0 = p.x && !p.x_hop && (p.ld_x & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    if (x_al0 && m0 + BM <= p.M_valid && n0 + BN <= p.N_valid) {
+      pf_on = true;
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const float* xs = p.x + (roww + 16 * (it / NP)) * p.ld_x + colw + 32 * (it % NP);
+        const f32x4 lo = *(const f32x4*)xs, hi = *(const f32x4*)(xs + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xpf[it][e] = lo[e]; xpf[it][4 + e] = hi[e]; }
+      }
+    }
+  }
+  if constexpr (PF_MASK) {
+    if (p.mask && !p.maskbits) {
+      pf_on = true;
+#pragma unroll
+      for (int it = 0; it < CH; ++it)
+        mpf[it] = *(const i32x4_*)(p.mask + (roww + 16 * (it / NP)) * p.ld_mask + colw + 32 * (it % NP));
+    }
+  }
+  if constexpr (PF_X || PF_MASK) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // keep these loads ahead of the ring's first LDS-DMA
+  }
+
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -687,14 +743,27 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // register set, last four in the second), i.e. 16-byte bf16 / 2 x 16-byte fp32 accesses, and one store
   // instruction covers 16 rows x 64 B (bf16).  Within a chunk all global LOADS are issued before the first
   // store (loads and stores share the in-order vmcnt counter).
-  static_assert(NI % 2 == 0, "epilogue pairs column fragments");
-  constexpr int NP = NI / 2;                       // column-block pairs per wave tile
-  constexpr int CM = NP >= 2 ? 2 : (MI >= 4 ? 4 : MI);  // fragment rows per chunk (bounds live registers)
-  static_assert(MI % CM == 0, "chunking must divide the wave tile");
-  constexpr int CH = CM * NP;                      // (row, 8-column) items per chunk
-  const int eq = lane >> 4, ej = lane & 15;
-  const long colw = n0 + wn * WTN + (eq & 1) * 16 + (eq >> 1) * 8;   // + 32 * t
-  const long roww = m0 + wm * WTM + ej;                              // + 16 * mi
+  // The 256 x 256 ping-pong kernels take the ReLU mask of their wave tile (128 rows x 128 B) through LDS: the ring
+  // is free now, so each wave issues ALL its mask pieces as LDS-DMA at once (16 x 1 KiB, into its own 16 KiB of the
+  // ring; 16-byte piece c of row r lands at position c ^ (r & 7), swizzled on the source address as in the main
+  // loop) and retires them chunk by chunk with a counted vmcnt -- one round trip to memory for the whole epilogue
+  // instead of one per chunk (loads into registers, stores, next chunk's loads ...: 4 dependent round trips per
+  // wave in a tail where all 256 blocks issue theirs together).
+  constexpr bool MASK_LDS = EPI == EPI_MASK_BF16 && PINGPONG;
+  static_assert(!MASK_LDS || (WTN == 64 && CH == 2 * CM), "mask through LDS: 128-byte mask rows, as many stores as DMA pieces per chunk");
+  lds_char* mk_lds = smem + wave * (WTM * 128);
+  bool mask_lds = false;
+  if constexpr (MASK_LDS) {
+    if (p.mask && !p.maskbits) {
+      mask_lds = true;
+      const int mrow = lane >> 3, mpc = (lane & 7) ^ (lane >> 3);
+      const bf16_t* mg = p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8;
+#pragma unroll
+      for (int i = 0; i < WTM / 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_cptr)(mg + (long)(8 * i) * p.ld_mask),
+                                         (__attribute__((address_space(3))) void*)(mk_lds + i * 1024), 16, 0, 0);
+    }
+  }
 
   float cs[NP][8];
 #pragma unroll
@@ -722,6 +791,34 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   const float qs = (EPI == EPI_BIAS_ACT_BF16 && p.out_fp8) ? *p.q_scale : 0.f;
   float amax = 0.f;
   const bool x_al = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+  // fp16 slabs: the wave tile's exponent (see GemmArgs::out_f16).  max|acc| over the wave (order-independent, so
+  // steps stay bit-reproducible) -> biased exponent e of the maximum -> scale 2^(14 - (e - 127)), clamped so that
+  // scale and its reciprocal are both normal floats; an infinite / NaN maximum keeps a finite scale and the
+  // non-finite values go through the fp16 conversion as they are.
+  float f16s = 1.f;
+  if constexpr (EPI == EPI_F32) {
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "fp16 slab exponents are kept per 32 x 32 granule");
+    if (p.out_f16) {
+      float mx = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(acc[mi][ni][r]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+      int sb = 268 - e;                       // biased exponent of the scale
+      sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
+      f16s = __uint_as_float((unsigned)sb << 23);
+      constexpr int GC = WTN / 32, NG = (WTM / 32) * GC;
+      if (lane < NG) {
+        const long gr = (m0 + wm * WTM) / 32 + lane / GC, gc = (n0 + wn * WTN) / 32 + lane % GC;
+        p.f16_unscale[split * p.us_split_stride + gr * p.us_ld + gc] = __uint_as_float((unsigned)(254 - sb) << 23);
+      }
+    }
+  }
 
 #pragma unroll
   for (int c0 = 0; c0 < MI; c0 += CM) {
@@ -793,7 +890,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
           f16x8 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * p.f16_scale); h[4 + e] = (_Float16)(hi[e] * p.f16_scale); }
+          for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * f16s); h[4 + e] = (_Float16)(hi[e] * f16s); }
           *(f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]) = h;
         } else if (mem) {
           *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
@@ -810,7 +907,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       for (int it = 0; it < CH; ++it)
 #pragma unroll
         for (int e = 0; e < 8; ++e) xin[it][e] = 0.f;
-      if (p.x && mem) {
+      if (PF_X && pf_on && c0 == 0) {
+#pragma unroll
+        for (int it = 0; it < CH; ++it)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xin[it][e] = xpf[it][e];
+      } else if (p.x && mem) {
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
           const long r = rowi[it], col = coli[it];
@@ -915,10 +1017,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         // as a signed integer, exceeds 0xFFFF; the low half iff it is a positive int16 (NaNs never occur in a ReLU output)
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         i32x4 mk[CH];
+        if (MASK_LDS && mask_lds) {
+          // this chunk's 2 * CM pieces have landed once at most (pieces of later chunks) + (stores of earlier
+          // chunks) = WTM / 8 - 2 * CM vector-memory operations of this wave are outstanding (in-order counter)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MASK_LDS ? WTM / 8 - 2 * CM : 0) : "memory");
 #pragma unroll
-        for (int it = 0; it < CH; ++it) {
-          mk[it] = i32x4{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
-          if (mem) mk[it] = *(const i32x4*)(p.mask + rowi[it] * p.ld_mask + coli[it]);
+          for (int it = 0; it < CH; ++it) {
+            const int rl = (c0 + it / NP) * 16 + ej, pc = (it % NP) * 4 + (eq & 1) * 2 + (eq >> 1);
+            mk[it] = *(const __attribute__((address_space(3))) i32x4*)(mk_lds + rl * 128 + ((pc ^ (rl & 7)) * 16));
+          }
+        } else if (PF_MASK && pf_on && c0 == 0) {
+#pragma unroll
+          for (int it = 0; it < CH; ++it) mk[it] = mpf[it];
+        } else {
+#pragma unroll
+          for (int it = 0; it < CH; ++it) {
+            mk[it] = i32x4{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+            if (mem) mk[it] = *(const i32x4*)(p.mask + rowi[it] * p.ld_mask + coli[it]);
+          }
         }
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
@@ -960,6 +1076,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       // lanes with equal (lane >> 4) own the same columns: butterfly over the 16 row lanes, then across
       // the block's wave rows through LDS (the ring is no longer read: barrier after the main loop)
       float* red = (float*)smem_generic;
+      if constexpr (MASK_LDS) __syncthreads();   // `red` overlays wave 0's mask rows: every wave is done reading its own
 #pragma unroll
       for (int t = 0; t < NP; ++t)
 #pragma unroll

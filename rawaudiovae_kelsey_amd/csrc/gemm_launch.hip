@@ -148,13 +148,18 @@ int launch_tile_fp8(int tile, const GemmArgs& a, long Mp, long Np, long Kp2, hip
   }
 }
 
-// Split-K slab destination of a weight-gradient GEMM: fp32 (dtype 0) or fp16(value * scale) (dtype 1), same element strides.
-int set_slabs(GemmArgs& g, void* dw, long lddw, long split_stride, int dtype, float scale) {
+// Split-K slab destination of a weight-gradient GEMM [Mp, Np]: fp32 (dtype 0), or fp16 with one power-of-two scale
+// per wave tile and slab (dtype 1, GemmArgs::out_f16): `unscale` then receives the factors that undo the scales,
+// [splits][Mp / 32][Np / 32] floats.  Same element strides either way.
+int set_slabs(GemmArgs& g, void* dw, long lddw, long split_stride, int dtype, float* unscale, long Mp, long Np) {
   RV_REQUIRE(dtype == RV_SLAB_F32 || dtype == RV_SLAB_F16, RV_ERR_UNSUPPORTED, "weight gradient: slab dtype %d", dtype);
-  RV_REQUIRE(dtype == RV_SLAB_F32 || scale > 0.f, RV_ERR_SHAPE, "weight gradient: fp16 slabs need a positive scale");
+  RV_REQUIRE(dtype == RV_SLAB_F32 || unscale, RV_ERR_NULL, "weight gradient: fp16 slabs need the table of per-tile scales");
   g.ld_f32 = lddw; g.split_stride_f32 = split_stride;
-  if (dtype == RV_SLAB_F16) { g.out_f16 = dw; g.f16_scale = scale; g.out_f32 = (float*)dw; }
-  else { g.out_f32 = (float*)dw; g.out_f16 = nullptr; }
+  g.out_f32 = (float*)dw; g.out_f16 = nullptr; g.f16_unscale = nullptr;
+  if (dtype == RV_SLAB_F16) {
+    g.out_f16 = dw; g.f16_unscale = unscale;
+    g.us_ld = Np / 32; g.us_split_stride = (Mp / 32) * (Np / 32);
+  }
   return RV_OK;
 }
 
@@ -428,23 +433,23 @@ int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp,
 
 int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp,
                     int splits, float* dw, long lddw, void* stream) {
-  return rv_linear_wgrad_ex(dy, lddy, x, ldx, Mp, Np, Kp, splits, dw, lddw, RV_SLAB_F32, 0.f, stream);
+  return rv_linear_wgrad_ex(dy, lddy, x, ldx, Mp, Np, Kp, splits, dw, lddw, RV_SLAB_F32, nullptr, stream);
 }
 
 int rv_linear_wgrad_ex(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits, void* dw,
-                       long lddw, int slab_dtype, float slab_scale, void* stream) {
+                       long lddw, int slab_dtype, float* slab_unscale, void* stream) {
   RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad: null operand");
   GemmArgs a{};
   a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
   a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
-  int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_scale);
+  int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
   return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
 }
 
 // Weight gradient on a named block tile (the training plan runs dW4 on 256x256 ping-pong tiles on its side stream).
 int rv_linear_wgrad_tile(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
-                         int tile, void* dw, long lddw, int slab_dtype, float slab_scale, void* stream) {
+                         int tile, void* dw, long lddw, int slab_dtype, float* slab_unscale, void* stream) {
   RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad_tile: null operand");
   RV_REQUIRE(tile == RV_TILE_256x256 || tile == RV_TILE_256x128 || tile == RV_TILE_128x128 || tile == RV_TILE_64x64,
              RV_ERR_UNSUPPORTED, "rv_linear_wgrad_tile: unknown tile %d", tile);
@@ -452,7 +457,7 @@ int rv_linear_wgrad_tile(const void* dy, long lddy, const void* x, long ldx, lon
   GemmArgs a{};
   a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
   a.k_tiles = (int)(Kp / 64 / splits); a.M_valid = (int)Mp; a.N_valid = (int)Np;
-  int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_scale);
+  int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
   return launch_tile<false, false, EPI_F32>(tile, a, Mp, Np, Kp, splits, (hipStream_t)stream);
 }
@@ -463,7 +468,7 @@ int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {
 }
 
 int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
-                         void* dw, long lddw, int slab_dtype, float slab_scale, const rv_param_desc* descs, int n_desc,
+                         void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
                          float* param, float* exp_avg,
                          float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
                          int n_adam_blocks, void* stream) {
@@ -480,7 +485,7 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
   GemmArgs g{};
   g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
   g.k_tiles = (int)(Kp / 64 / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np;
-  rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_scale);
+  rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
   g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.dbg = g_dbg;
   const int n_gemm = g.tiles_m * g.tiles_n * splits;
@@ -541,19 +546,19 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
                           long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
                           float* dw_slabs, long lddw, int splits, void* stream) {
   return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, nullptr, 0, Mp, Np, Kp, dx_bf16, lddx, colsum_partial, dw_slabs,
-                                  lddw, splits, RV_SLAB_F32, 0.f, stream);
+                                  lddw, splits, RV_SLAB_F32, nullptr, stream);
 }
 
 int rv_linear_dgrad_wgrad_mb(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
                              const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
                              float* colsum_partial, float* dw_slabs, long lddw, int splits, void* stream) {
   return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, maskbits, ld_maskbits, Mp, Np, Kp, dx_bf16, lddx, colsum_partial,
-                                  dw_slabs, lddw, splits, RV_SLAB_F32, 0.f, stream);
+                                  dw_slabs, lddw, splits, RV_SLAB_F32, nullptr, stream);
 }
 
 int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
                              const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
-                             float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype, float slab_scale,
+                             float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype, float* slab_unscale,
                              void* stream) {
   RV_REQUIRE(dy && w && x && dx_bf16 && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad: null operand");
   RV_REQUIRE(!maskbits || ld_maskbits >= Np / 8, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_mb: mask rows are Np/8 bytes");
@@ -571,14 +576,14 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
     d.maskbits = (const unsigned char*)maskbits; d.ld_maskbits = ld_maskbits;
     g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
     g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
-    rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_scale);
+    rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_unscale, Kp, Np);
     if (rc) return rc;
     if (td == tw && (Mp / 64) % splits == 0 &&
         try_dual<false, false, EPI_F32, true, false, EPI_MASK_BF16>(td, g, Kp, Np, splits, d, Mp, Np, 1, (hipStream_t)stream, &rc))  // long (wgrad) blocks first
       return rc;
     rc = launch_tile<true, false, EPI_MASK_BF16>(td, d, Mp, Np, Kp, 1, (hipStream_t)stream);
     if (rc) return rc;
-    return rv_linear_wgrad_ex(dy, lddy, x, ldx, Kp, Np, Mp, splits, dw_slabs, lddw, slab_dtype, slab_scale, stream);
+    return rv_linear_wgrad_ex(dy, lddy, x, ldx, Kp, Np, Mp, splits, dw_slabs, lddw, slab_dtype, slab_unscale, stream);
   }
   RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: leading dims must be multiples of 8");
   RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: operands must be 16-byte aligned");
@@ -591,7 +596,7 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
   d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1;
   g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
   g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
-  rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_scale);
+  rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_unscale, Kp, Np);
   if (rc) return rc;
   g.tiles_m = (int)(Kp / BM); g.tiles_n = (int)(Np / BN); g.splits = splits;
   if (g_pair_loop == 8 && d.k_tiles % 2 == 0 && g.k_tiles % 2 == 0) return launch_pair<8>(d, g, (hipStream_t)stream);

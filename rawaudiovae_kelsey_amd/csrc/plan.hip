@@ -76,8 +76,9 @@ struct rv_plan {
   unsigned short* msg_recv = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
-  int slab_dtype = RV_SLAB_F32;   // element type of the dW1 / dW4 split-K slabs (rv_plan_set_slab_dtype)
-  float slab_scale = 4096.f;      // fp16 slabs hold fp16(partial * 2^12)
+  int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (rv_plan_set_slab_dtype)
+  float* us_w1 = nullptr;         // per-granule scale tables of the fp16 slabs (workspace "dW1_us" / "dW4_us")
+  float* us_w4 = nullptr;
   // frame source of the step in flight (rv_plan_step_frames): `x` is then the resident waveform
   const long long* fr_idx = nullptr;
   long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
@@ -164,6 +165,8 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dWh", (long)p->s_wh * L2p * Hp * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
+  p->add("dW1_us", (long)p->s_w1 * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
+  p->add("dW4_us", (long)p->s_w4 * (Sp / 32) * (Hp / 32) * 4);
   p->add("db1p", (long)p->n_mt1 * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
@@ -268,6 +271,7 @@ static void split_rows(const rv_param_desc& d, long r0, rv_param_desc* top, rv_p
   bottom->rows = d.rows - r0;
   bottom->offset = d.offset + r0 * d.cols;
   bottom->grad_slabs = (const float*)((const char*)d.grad_slabs + r0 * d.grad_ld * (d.grad_half ? 2 : 4));
+  if (d.grad_half) bottom->grad_unscale = d.grad_unscale + (r0 / 32) * d.us_ld;   // r0 is a multiple of 32 then (caller)
   if (d.shadow_bf16) bottom->shadow_bf16 = (char*)d.shadow_bf16 + r0 * d.shadow_ld * 2;
   if (d.shadow_f32) bottom->shadow_f32 = d.shadow_f32 + r0 * d.shadow_ld;
   if (d.shadow_fp8) bottom->shadow_fp8 = (char*)d.shadow_fp8 + r0 * d.shadow_ld;
@@ -289,10 +293,12 @@ int rv_plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_slab_dtype: plan not bound");
   RV_REQUIRE(slab_dtype == RV_SLAB_F32 || slab_dtype == RV_SLAB_F16, RV_ERR_UNSUPPORTED, "rv_plan_set_slab_dtype: %d", slab_dtype);
   p->slab_dtype = slab_dtype;
-  for (rv_param_desc* d : {p->d_slab + 0, p->d_slab + 8}) {   // fc1.weight, fc4.weight: the two 8 MB gradients
-    d->grad_half = slab_dtype == RV_SLAB_F16;
-    d->grad_unscale = 1.0f / p->slab_scale;
-  }
+  const long Hp = p->Hp, Sp = p->Sp;
+  const bool half = slab_dtype == RV_SLAB_F16;
+  rv_param_desc* d1 = p->d_slab + 0;   // fc1.weight [H, S] and fc4.weight [S, H]: the two 8 MB gradients
+  d1->grad_half = half; d1->grad_unscale = half ? p->us_w1 : nullptr; d1->us_ld = Sp / 32; d1->us_split_stride = (Hp / 32) * (Sp / 32);
+  rv_param_desc* d4 = p->d_slab + 8;
+  d4->grad_half = half; d4->grad_unscale = half ? p->us_w4 : nullptr; d4->us_ld = Hp / 32; d4->us_split_stride = (Sp / 32) * (Hp / 32);
   return RV_OK;
 }
 
@@ -335,6 +341,8 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
       {p->off[8], S, H, dW4, Hp, Sp * Hp, p->s_w4, W4b, nullptr, Hp},
       {p->off[9], 1, S, db4, Sp, Sp, n_mt4, nullptr, b4p, Sp},
   };
+  p->us_w1 = (float*)p->ws("dW1_us");
+  p->us_w4 = (float*)p->ws("dW4_us");
   for (int i = 0; i < 10; ++i) {
     p->d_slab[i] = d[i];
     p->d_flat[i] = d[i];
@@ -345,7 +353,7 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
       p->d_flat[i].grad_splits = 1;
     }
   }
-  return RV_OK;
+  return rv_plan_set_slab_dtype(p, p->slab_dtype);
 }
 
 int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
@@ -488,7 +496,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc3 and fc4, below); fc1's and the heads' updates are the step's last launch.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
     RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
@@ -508,7 +516,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     }
     ride[n_ride++] = p->d_slab[6];
     ride[n_ride++] = p->d_slab[7];
-    const long r0 = heads_ride ? p->d_slab[8].rows : (p->d_slab[8].rows * p->adam_split / 1000) & ~3L;
+    const long r0 = heads_ride ? p->d_slab[8].rows : (p->d_slab[8].rows * p->adam_split / 1000) & ~31L;   // whole scale granules
     if (r0 >= p->d_slab[8].rows) {
       ride[n_ride++] = p->d_slab[8];
     } else if (r0 > 0) {
@@ -519,7 +527,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       last[n_last++] = p->d_slab[8];
     }
     ride[n_ride++] = p->d_slab[9];
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, ride,
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, ride,
                                 n_ride, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                 p->b.step_counter, 256 - n_gemm, stream));
     RV_TRY(rv_adam_multi(last, n_last, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
@@ -538,7 +546,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                            stream));
     RV_HIP(hipEventRecord(p->ev[1], s0));
     RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, p->ws("dW4"), Hp, p->slab_dtype, p->slab_scale,
+    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, p->ws("dW4"), Hp, p->slab_dtype, p->us_w4,
                                 (void*)s1));
     RV_TRY(rv_adam_multi(p->d_slab + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, (void*)s1));
@@ -546,7 +554,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
     RV_TRY(rv_adam_multi(p->d_slab, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join: the caller's stream owns the whole step again
@@ -557,7 +565,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // stream beside the fc1 weight-gradient GEMM (each cross-stream edge costs 6-10 us on this runtime).
     hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
     RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
     RV_TRY(latent_bwd(stream));
     RV_HIP(hipEventRecord(p->ev[1], s0));  // dW4, db4, dW3, db3 ready; W3b, W4b no longer read
     RV_TRY(reparam_bwd(stream));
@@ -566,7 +574,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                          p->b.step_counter, (void*)s1));
     RV_HIP(hipEventRecord(p->ev[3], s1));
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
     RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join
     RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
@@ -587,7 +595,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   }
   if (do_pair)
     RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   if (do_chain_a && do_w3) {
     RV_TRY(latent_bwd(stream));
   } else if (do_chain_a) {
@@ -597,7 +605,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   }
   if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
 
@@ -756,7 +764,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   RV_TRY(scatter_bucket(0));   // fc4's 8.4 MB travel behind the rest of backward
   RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
                                    (float*)p->ws("dW3"), Lp, p->s_w3, stream));
@@ -764,7 +772,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
+  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(scatter_bucket(1));
   RV_HIP(hipEventRecord(p->ev_done[1], sc));           // both reduce-scatters (the collective stream is in order)
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
@@ -866,7 +874,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->slab_scale, stream));
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
   // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
   // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
@@ -876,7 +884,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->slab_scale, stream));
+  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(reduce_bucket(1, 0, 8));          // fc1, fc21, fc22, fc3: contiguous in the arena
   // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));

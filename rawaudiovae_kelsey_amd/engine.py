@@ -40,7 +40,7 @@ class TrainEngine:
 
     def __init__(self, segment_length, n_units, latent_dim, batch_size, device="cuda",
                  kl_beta=1e-4, lr=1e-4, seed=0, ring=256, grad_arena=True, share=None, fp8=False,
-                 slab_dtype="fp32"):
+                 slab_dtype="fp16"):
         """share: another TrainEngine of the same (S, H, L) whose parameter / Adam / gradient
         arenas, step counter and loss ring this one uses (a second batch size, e.g. the ragged
         last batch of an epoch -- DataLoader keeps it, train.py:134)."""
@@ -93,7 +93,8 @@ class TrainEngine:
         self.fp8_h3_scale = 16.0        # first step only; afterwards 224 / max|h3| of the previous step
         if self.fp8:
             L_.rv_plan_set_fp8(self._plan, 1)
-        # element type of the fc1 / fc4 weight-gradient split-K slabs ("fp16": half the bytes written and re-read)
+        # element type of the fc1 / fc4 weight-gradient split-K slabs: "fp16" (default) = block-floating-point fp16, one
+        # power-of-two scale per wave tile and slab (half the bytes written and re-read, any gradient magnitude); "fp32"
         if slab_dtype not in ("fp32", "fp16"):
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype

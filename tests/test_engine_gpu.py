@@ -345,9 +345,10 @@ def test_latent_forward_one_launch_vs_three_in_the_step():
 
 @pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 384, 100, 130)])
 def test_fp16_split_k_slabs_vs_fp32_slabs(shape):
-    """slab_dtype="fp16": the split-K partials of dW1 / dW4 are stored as fp16(partial * 2^12) and summed in fp32.
-    Forward and every other gradient are untouched (bit-equal); the two weight gradients move by the rounding of
-    four fp16 partials (stated bound 1e-3 rel-L2, 3e-4 expected) and still meet the oracle bound of the bf16 path."""
+    """slab_dtype="fp16" (the default): the split-K partials of dW1 / dW4 are stored as block-floating-point fp16
+    (one power-of-two scale per wave tile and slab) and summed in fp32.  Forward and every other gradient are untouched
+    (bit-equal to slab_dtype="fp32"); the two weight gradients move by the rounding of four fp16 partials (stated
+    bound 1e-3 rel-L2, 3e-4 expected) and still meet the oracle bound of the bf16 path."""
     from rawaudiovae_kelsey_amd import engine as E
     S, H, L, B = shape
     x, eps = make_frames(B, S, 1234), make_eps(B, L, 4321)

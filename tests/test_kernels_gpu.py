@@ -454,15 +454,26 @@ def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
     shadows = []
     for i, (r, c, s, ld, half) in enumerate(spec):
         slab = (rng.standard_normal((s, r + 1, ld)) * 1e-2).astype(np.float32)
-        sd = dev((slab * 4096).astype(np.float16)) if half else dev(slab)
-        keep.append(sd)
+        us = None
+        if half:
+            # block-floating-point fp16 slabs: one power-of-two factor per 32 x 32 granule and slab (exponents
+            # spread over 20 binades), values stored as fp16(partial * 2^e), the table holds 2^-e
+            gr, gc = -(-(r + 1) // 32), ld // 32
+            ex = rng.integers(-12, 9, size=(s, gr, gc))
+            scale = np.repeat(np.repeat(np.exp2(ex), 32, axis=1), 32, axis=2)[:, :r + 1, :ld]
+            sd = dev((slab * 4096 * scale).astype(np.float16))
+            us = dev((np.exp2(-ex) / 4096).astype(np.float32))
+        else:
+            sd = dev(slab)
+        keep.append((sd, us))
         cp = -(-c // 8) * 8
         sh = torch.zeros((r, cp), dtype=torch.bfloat16, device="cuda") if r > 1 else None
         shf = torch.zeros((1, cp), dtype=torch.float32, device="cuda") if r == 1 else None
         shadows.append((sh, shf))
         # offsets: multiples of 4 for the aligned tensors, odd ones in between stay valid for the scalar path
         descs[i] = ParamDesc(off, r, c, sd.data_ptr(), ld, (r + 1) * ld, s, sh.data_ptr() if sh is not None else None,
-                             shf.data_ptr() if shf is not None else None, cp, None, None, int(half), 1.0 / 4096 if half else 0.0)
+                             shf.data_ptr() if shf is not None else None, cp, None, None, int(half),
+                             us.data_ptr() if half else None, ld // 32, (-(-(r + 1) // 32)) * (ld // 32))
         off += r * c
     ctr = torch.full((1,), 4, dtype=torch.int64, device="cuda")
 
@@ -472,7 +483,7 @@ def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
     try:
         pa, ma, va = state()
         dwa = torch.zeros(splits, M, N, device="cuda")
-        L.rv_linear_wgrad_adam(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, dwa.data_ptr(), N, 0, 1.0, descs, len(spec),
+        L.rv_linear_wgrad_adam(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, dwa.data_ptr(), N, 0, None, descs, len(spec),
                                pa.data_ptr(), ma.data_ptr(), va.data_ptr(), 1e-3, 0.25, ctr.data_ptr(), 24, sp())
         sha = [(a.clone() if a is not None else None, b.clone() if b is not None else None) for a, b in shadows]
         for a, b in shadows:
@@ -481,7 +492,7 @@ def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
                     t.zero_()
         pb, mb, vb = state()
         dwb = torch.zeros(splits, M, N, device="cuda")
-        L.rv_linear_wgrad_tile(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, 7, dwb.data_ptr(), N, 0, 1.0, sp())
+        L.rv_linear_wgrad_tile(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, 7, dwb.data_ptr(), N, 0, None, sp())
         L.rv_adam_multi(descs, len(spec), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, 1e-3, 0.25, ctr.data_ptr(), sp())
         torch.cuda.synchronize()
     finally:
@@ -493,6 +504,55 @@ def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
         for t1, t2 in ((a1, a2), (b1, b2)):
             if t1 is not None:
                 assert torch.equal(t1, t2)
+
+
+@pytest.mark.parametrize("tile", [7, 2, 4, 0], ids=["256x256", "256x128", "128x128", "64x64"])
+@pytest.mark.parametrize("mag", [1e-6, 1.0, 1e3, "mixed"])
+def test_fp16_slabs_keep_their_precision_at_any_gradient_magnitude(L, tile, mag):
+    """RV_SLAB_F16 is block floating point: every wave tile of every split-K slab carries its own power-of-two
+    scale, so the fp16 partials of a weight gradient of ANY magnitude -- 1e-6, 1e+3, or 128-row blocks (the
+    largest wave tile) 12 decades apart in one matrix -- sum (rv_grad_finalize) to the fp32-slab result within 1e-3 relative L2 (stated bound; 3e-4
+    expected from fp16's 11-bit significand), block by block; a static scale would flush the small ones to zero or
+    overflow the large ones.  Checked on every block tile a weight gradient can get."""
+    from rawaudiovae_kelsey_amd._lib import ParamDesc
+    rng = np.random.default_rng(77)
+    M, N, K, splits = 512, 256, 512, 2
+    dyh = rand_bf16(rng, (K, M), 0.1)
+    if mag == "mixed":
+        dyh = dyh * np.repeat(10.0 ** rng.uniform(-8, 4, M // 128), 128)[None, :]
+    else:
+        dyh = dyh * mag
+    dyh = dyh.astype(np.float32)
+    dy = dev(dyh, torch.bfloat16)
+    x = dev(rand_bf16(rng, (K, N), 0.5), torch.bfloat16)
+    w32 = torch.zeros(splits, M, N, device="cuda")
+    w16 = torch.zeros(splits, M, N, dtype=torch.float16, device="cuda")
+    us = torch.zeros(splits, M // 32, N // 32, device="cuda")
+    L.rv_linear_wgrad_tile(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w32.data_ptr(), N, 0, None, sp())
+    L.rv_linear_wgrad_tile(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w16.data_ptr(), N, 1, us.data_ptr(), sp())
+    torch.cuda.synchronize()
+    ush = us.cpu().numpy()
+    assert np.all(ush > 0) and np.all(np.log2(ush) == np.round(np.log2(ush)))   # exact powers of two
+    stored = w16.float().abs().amax().item()
+    assert 2.0 ** 13 <= stored < 2.0 ** 15     # the largest tile maximum sits in fp16's top binades, never overflows
+    deq = w16.float().cpu().numpy() * np.repeat(np.repeat(ush, 32, axis=1), 32, axis=2)
+    ref = w32.cpu().numpy()
+    for r0 in range(0, M, 128):    # every 128-row block on its own: the small blocks must be as good as the large ones
+        a, b = deq[:, r0:r0 + 128], ref[:, r0:r0 + 128]
+        assert np.linalg.norm(a - b) <= 1e-3 * np.linalg.norm(b), (r0, np.linalg.norm(a - b) / np.linalg.norm(b))
+    # the optimizer's reader: rv_grad_finalize on a descriptor of the fp16 slabs == sum of the fp32 slabs
+    out16 = torch.zeros(M * N, device="cuda")
+    out32 = torch.zeros(M * N, device="cuda")
+    d16 = (ParamDesc * 1)(ParamDesc(0, M, N, w16.data_ptr(), N, M * N, splits, None, None, 0, None, None, 1,
+                                    us.data_ptr(), N // 32, (M // 32) * (N // 32)))
+    d32 = (ParamDesc * 1)(ParamDesc(0, M, N, w32.data_ptr(), N, M * N, splits, None, None, 0))
+    L.rv_grad_finalize(d16, 1, out16.data_ptr(), sp())
+    L.rv_grad_finalize(d32, 1, out32.data_ptr(), sp())
+    torch.cuda.synchronize()
+    a, b = out16.view(M, N).cpu().numpy(), out32.view(M, N).cpu().numpy()
+    np.testing.assert_array_equal(a, deq.sum(0, dtype=np.float32))
+    for r0 in range(0, M, 128):
+        assert np.linalg.norm(a[r0:r0 + 128] - b[r0:r0 + 128]) <= 1e-3 * np.linalg.norm(b[r0:r0 + 128]), r0
 
 
 def test_gather_frames_matches_audio_dataset_semantics(L):

@@ -58,16 +58,16 @@ def read_config(path):
 
 def engine_options(hw):
     """TrainEngine keyword arguments from the optional [mi355x] section: `fp8 = True` runs the fc1 / fc4 forward
-    GEMMs on fp8 (e4m3) operands (BASELINE configs[4]); `wgrad_slabs = fp16` stores the split-K partial sums of the
-    two large weight gradients as scaled fp16.  Both default to the bf16 / fp32 path the parity gates are stated on."""
+    GEMMs on fp8 (e4m3) operands (BASELINE configs[4]); `wgrad_slabs = fp16` (default) stores the split-K partial sums
+    of the two large weight gradients as block-floating-point fp16 (one power-of-two scale per wave tile), `fp32`
+    keeps them fp32."""
     kw = {}
     if str(hw.get('fp8', 'False')).lower() in ('1', 'true', 'yes'):
         kw['fp8'] = True
-    slabs = str(hw.get('wgrad_slabs', 'fp32')).lower()
+    slabs = str(hw.get('wgrad_slabs', 'fp16')).lower()
     if slabs not in ('fp32', 'fp16'):
         raise ValueError("[mi355x] wgrad_slabs = {} (expected fp32 or fp16)".format(slabs))
-    if slabs == 'fp16':
-        kw['slab_dtype'] = 'fp16'
+    kw['slab_dtype'] = slabs
     return kw
 
 
