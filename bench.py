@@ -63,6 +63,7 @@ def parse():
                     help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
     ap.add_argument("--n128-loop", type=int, default=0,
                     help="experiment: main loop of the 256x128 GEMM tile (3 one-barrier ring = default, 9 ping-pong)")
+    ap.add_argument("--gemm-hook", type=int, default=0, help="experiment: rv_gemm_force_tile(N) before anything runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--repeats", type=int, default=0,
@@ -145,6 +146,9 @@ def main():
     if args.n128_loop:
         from rawaudiovae_kelsey_amd._lib import lib as _rvlib
         _rvlib().rv_gemm_force_tile(100 + args.n128_loop)
+    if args.gemm_hook:
+        from rawaudiovae_kelsey_amd._lib import lib as _rvlib
+        _rvlib().rv_gemm_force_tile(args.gemm_hook)
     ekw = {"slab_dtype": args.slab_dtype} if args.slab_dtype else {}
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **ekw)
     eng.load_params(make_params(S, H, L, 0))

@@ -4,6 +4,7 @@
 // multi-tensor Adam / gradient finaliser.  C ABI: include/rawvae_hip.h.
 #include "common.h"
 #include "adam.h"
+#include "philox.h"
 #include "../../include/rawvae_hip.h"
 
 #include <stdarg.h>
@@ -22,62 +23,6 @@ int rv_fail(int code, const char* fmt, ...) {
 }
 
 namespace {
-
-// ------------------------------------------------------------------ Philox4x32-10
-struct u32x4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ u32x4 philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
-  uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return {c0, c1, c2, c3};
-}
-
-// Same draw with the hardware transcendental units (v_log/v_sin/v_cos; abs error ~1e-6):
-// used where eps is consumed immediately and only its distribution matters.
-__device__ __forceinline__ void normal4_fast(uint64_t seed, uint64_t idx4, uint64_t offset, float* o) {
-  const u32x4 r = philox4x32_10(seed, idx4, offset);
-  const float inv32 = 2.3283064365386963e-10f;  // 2^-32
-  const float u0 = ((float)r.x + 0.5f) * inv32, u1 = ((float)r.y + 0.5f) * inv32;
-  const float u2 = ((float)r.z + 0.5f) * inv32, u3 = ((float)r.w + 0.5f) * inv32;
-  const float ra = sqrtf(-2.0f * __logf(fminf(u0, 0.99999994f)));
-  const float rb = sqrtf(-2.0f * __logf(fminf(u2, 0.99999994f)));
-  const float t1 = 6.283185307179586f * u1, t3 = 6.283185307179586f * u3;
-  o[0] = ra * __cosf(t1); o[1] = ra * __sinf(t1);
-  o[2] = rb * __cosf(t3); o[3] = rb * __sinf(t3);
-}
-
-// Four N(0,1) draws for counter (idx4, offset): Box-Muller on two uniform pairs.
-__device__ __forceinline__ void normal4(uint64_t seed, uint64_t idx4, uint64_t offset, float* o) {
-  const u32x4 r = philox4x32_10(seed, idx4, offset);
-  const float inv32 = 2.3283064365386963e-10f;  // 2^-32
-  const float u0 = ((float)r.x + 0.5f) * inv32, u1 = ((float)r.y + 0.5f) * inv32;
-  const float u2 = ((float)r.z + 0.5f) * inv32, u3 = ((float)r.w + 0.5f) * inv32;
-  const float ra = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f) + 1e-30f));
-  const float rb = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f) + 1e-30f));
-  float s, c;
-  sincospif(2.0f * u1, &s, &c);
-  o[0] = ra * c; o[1] = ra * s;
-  sincospif(2.0f * u3, &s, &c);
-  o[2] = rb * c; o[3] = rb * s;
-}
-
-__device__ __forceinline__ float normal1(uint64_t seed, uint64_t idx, uint64_t offset) {
-  float o[4];
-  normal4(seed, idx >> 2, offset, o);
-  return o[idx & 3];
-}
 
 __global__ void __launch_bounds__(256) k_randn(float* out, long n, uint64_t seed, uint64_t offset) {
   const long n4 = (n + 3) / 4;
@@ -260,7 +205,7 @@ k_reparam_fwd(const float* __restrict__ slabs, int splits, long Bp, long Lp, lon
 // Block = RB_ROWS batch rows x all Lp columns, one thread per 4 consecutive columns of one row
 // (float4 loads, all slabs in flight); rows of the block are covered in 256*4/Lp-row passes.
 // Column sums (bias grads of fc21|fc22) are reduced through LDS into one partial row per block.
-// The last grid block also finishes the loss scalar.
+// One extra grid block finishes the loss scalar.
 constexpr int RB_ROWS = 16;
 
 __global__ void __launch_bounds__(256)
@@ -274,6 +219,27 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
   __shared__ float sh[2 * 256 * 4];
   const int tid = threadIdx.x;
   const long L2p = 2 * Lp;
+  const float inv_nk_ = 1.0f / ((float)B * (float)L);
+  // ONE EXTRA block (the grid has Bp / RB_ROWS + 1) finishes the loss scalar and does nothing else: as an epilogue of
+  // the last row block it added a second dependent round trip to memory to the block the whole launch waits for
+  if (blockIdx.x == gridDim.x - 1) {
+    if (loss_out && mse_partial && kl_partial) {
+      float m = 0.f, k = 0.f;
+      for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+      for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+      m = block_sum_256(m, sh);
+      k = block_sum_256(k, sh);
+      if (tid == 0) {
+        const float mse = m / ((float)B * (float)S);
+        const float kld = -0.5f * k * inv_nk_;
+        if (step_counter && ring > 0) loss_out += 4 * ((*step_counter - 1) % ring);
+        loss_out[0] = mse + kl_beta * kld;
+        loss_out[1] = mse;
+        loss_out[2] = kld;
+      }
+    }
+    return;
+  }
   const int lq = (int)(Lp / 4);             // column groups per row (16, 32 or 64)
   const int rows_par = 256 / lq;            // rows covered per pass (16, 8 or 4)
   const int cg = tid % lq, r0 = tid / lq;
@@ -329,22 +295,6 @@ k_reparam_bwd(const float* __restrict__ dz_slabs, int splits, long Bp, long Lp, 
     }
     dbh_partial[(long)blockIdx.x * L2p + tid] = a;
     dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
-  }
-  if (blockIdx.x == gridDim.x - 1 && loss_out && mse_partial && kl_partial) {
-    __syncthreads();
-    float m = 0.f, k = 0.f;
-    for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
-    for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
-    m = block_sum_256(m, sh);
-    k = block_sum_256(k, sh);
-    if (tid == 0) {
-      const float mse = m / ((float)B * (float)S);
-      const float kld = -0.5f * k * inv_nk;
-      if (step_counter && ring > 0) loss_out += 4 * ((*step_counter - 1) % ring);
-      loss_out[0] = mse + kl_beta * kld;
-      loss_out[1] = mse;
-      loss_out[2] = kld;
-    }
   }
 }
 
@@ -586,168 +536,6 @@ inline unsigned grid_for(long n_threads, long cap = 2048) {
 }
 
 
-// ------------------------------------------------------------------ latent-sized forward in one launch (experiment)
-// heads GEMM (fc21 | fc22) -> reparameterisation + KL partial -> fc3 + bias + ReLU for 16 batch rows per block
-// (model.py:21-29).  Everything here is row-local, so the three steps need no cross-block hand-off; the price is that
-// every block streams the whole head weight (128 x Hp) and W3 (Hp x 64) through its CU: 832 KB at C2, ~13 us at the
-// ~65 GB/s a CU's L2 port delivers (MI355X_MICROARCH.md "Indexed rows"), against 8 + 5 + 8 us for the three launches
-// it replaces.  MEASURED: 45 us, so the plan does not use it by default (rv_plan_set_latent_fused).  No LDS staging
-// here: the operands of v_mfma_f32_16x16x32_bf16 are 16 rows x 8 consecutive k per 16-lane group, which is what a
-// lane gets from 16 B of a K-contiguous row, so fragments go from global memory straight into registers, double
-// buffered in 256-k pieces.  That form streams 21 GB/s per CU in the heads loop and 30 in the fc3 loop (timed with
-// either loop cut short: 27 + 10 us of loops, 9 us fixed) -- the same ~25 GB/s the optimizer blocks of
-// rv_linear_wgrad_adam get from plain loads: hipcc drains the load queue once per trip (vmcnt(0) at the loop end),
-// and what keeps a CU's port busy is the LDS-DMA ring with counted vmcnt of gemm_bf16.h (60 GB/s), not loads the
-// compiler schedules.  Staggering the blocks' walks over the shared weights (below) changed nothing: it is not L2
-// hot-spotting.  MFMA operands are (weight rows, batch rows): a lane ends up with four consecutive output columns
-// of one batch row.  Lp must be 64 (so 2 Lp = 128 = 8 waves x 16 columns and a block's 16 x 64 latents are one
-// 1024-element KL partial, the granularity k_reparam_fwd uses); eps draws and the KL partial are those of
-// k_reparam_fwd bit for bit.
-constexpr int LAT_ROWS = 16;
-
-__global__ void __launch_bounds__(512)
-k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __restrict__ Wh, const long ldwh,
-             const float* __restrict__ bh, const bf16_t* __restrict__ W3, const long ldw3,
-             const float* __restrict__ b3, const long Hp, const long B, const long L,
-             const float* __restrict__ eps_in, float* __restrict__ eps_out, const uint64_t seed,
-             const long long* __restrict__ step_counter, float* __restrict__ mulv, bf16_t* __restrict__ z,
-             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3) {
-  constexpr long Lp = 64, L2p = 128;
-  __shared__ __attribute__((aligned(16))) float sm_mulv[LAT_ROWS][L2p];
-  __shared__ __attribute__((aligned(16))) bf16_t sm_z[LAT_ROWS][Lp];
-  __shared__ float red[8];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = lane >> 4, j = lane & 15;
-  const long r0 = (long)blockIdx.x * LAT_ROWS;
-
-  // ---- heads: out[r0 + j][16 wave + 4 q + e] = sum_k Wh[16 wave + 4 q + e][k] h1[r0 + j][k]
-  // Two register buffers of four 64-wide k windows each: the loads of the next 256 k are in flight while the MFMAs
-  // of the current 256 run (16 x 16 B per lane and buffer; the compiler's vmcnt counts keep the order).
-  {
-    const bf16_t* xa = h1 + (r0 + j) * ldh + q * 8;
-    const bf16_t* wa = Wh + (long)(wave * 16 + j) * ldwh + q * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 x0[8], w0[8], x1[8], w1[8];
-    // Every block walks the same head weight; block i of an XCD starts its walk over k at window i (64 k per window)
-    // and wraps, so that the blocks do not ask the L2 for the same lines at the same moment (no measurable effect).
-    // The summation order of a row's dot products then depends on its block, which the fixed block -> rows map
-    // keeps reproducible.
-    const long rot = (long)((blockIdx.x >> 3) & 31) * 64 % Hp;
-#define LAT_LD(X, W, K)                                                         \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                             \
-      long kk = (K) + 64 * u + rot;                                             \
-      kk = kk >= Hp ? kk - Hp : kk;                                             \
-      X[2 * u] = *reinterpret_cast<const bf16x8*>(xa + kk);                     \
-      X[2 * u + 1] = *reinterpret_cast<const bf16x8*>(xa + kk + 32);            \
-      W[2 * u] = *reinterpret_cast<const bf16x8*>(wa + kk);                     \
-      W[2 * u + 1] = *reinterpret_cast<const bf16x8*>(wa + kk + 32);            \
-    }
-#define LAT_MM(X, W)                                                            \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[u], X[u], acc, 0, 0, 0);
-    LAT_LD(x0, w0, 0)
-    for (long k = 0; k < Hp; k += 512) {   // Hp is a multiple of 512; branch-free body, so the waits are counted
-      LAT_LD(x1, w1, k + 256)
-      LAT_MM(x0, w0)
-      const long kn = k + 512 < Hp ? k + 512 : Hp - 256;   // last trip: a harmless reload instead of a branch
-      LAT_LD(x0, w0, kn)
-      LAT_MM(x1, w1)
-    }
-#undef LAT_LD
-#undef LAT_MM
-    const int c = wave * 16 + q * 4;
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + c);
-    *reinterpret_cast<f32x4*>(&sm_mulv[j][c]) = f32x4{acc[0] + b4[0], acc[1] + b4[1], acc[2] + b4[2], acc[3] + b4[3]};
-  }
-  __syncthreads();
-
-  // ---- reparameterise: threads 0..255 take the 256 four-column groups of the block, in k_reparam_fwd's order
-  float kl = 0.f;
-  if (tid < 256) {
-    const int rr = tid >> 4;
-    const long b = r0 + rr, l = (long)(tid & 15) * 4;
-    const long i = (long)blockIdx.x * 256 + tid;   // group index over the padded [Bp, Lp / 4] grid
-    float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (b < B && l < L) {
-      const f32x4 m4 = *reinterpret_cast<const f32x4*>(&sm_mulv[rr][l]);
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(&sm_mulv[rr][Lp + l]);
-      float ev[4];
-      if (!eps_in) normal4_fast(seed, (uint64_t)i, step_counter ? (uint64_t)*step_counter : 0, ev);
-#pragma unroll
-      for (int e_ = 0; e_ < 4; ++e_) {
-        if (l + e_ < L) {
-          float e;
-          if (eps_in) {
-            e = eps_in[b * L + l + e_];
-          } else {
-            e = ev[e_];
-            eps_out[b * L + l + e_] = e;
-          }
-          mua[e_] = m4[e_];
-          lva[e_] = v4[e_];
-          const float sd = __expf(0.5f * lva[e_]);
-          zz[e_] = mua[e_] + e * sd;
-          kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
-        }
-      }
-    }
-    *reinterpret_cast<float4*>(mulv + b * L2p + l) = make_float4(mua[0], mua[1], mua[2], mua[3]);
-    *reinterpret_cast<float4*>(mulv + b * L2p + Lp + l) = make_float4(lva[0], lva[1], lva[2], lva[3]);
-    const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
-    *reinterpret_cast<bf16x4*>(z + b * Lp + l) = zb;
-    *reinterpret_cast<bf16x4*>(&sm_z[rr][l]) = zb;
-  }
-  kl = wave_sum(kl);
-  if (lane == 0) red[wave] = kl;
-  __syncthreads();   // sm_z complete, red complete
-  if (tid == 0) kl_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-
-  // ---- fc3: h3[r0 + j][n] = relu(sum_k W3[n][k] z[r0 + j][k] + b3[n]); wave w owns columns [w Hp/8, (w+1) Hp/8),
-  // 32 columns (two MFMA column blocks) per trip, double-buffered like the heads loop
-  {
-    const bf16x8 z0 = *reinterpret_cast<const bf16x8*>(&sm_z[j][q * 8]);
-    const bf16x8 z1 = *reinterpret_cast<const bf16x8*>(&sm_z[j][32 + q * 8]);
-    const long per_wave = Hp / 8;          // a multiple of 64
-    // the same staggering for W3: which eighth of the columns a wave takes, and where in it it starts, rotate with
-    // the block's index inside its XCD
-    const int bi = (int)(blockIdx.x >> 3);
-    const long c0 = (long)((wave + bi) & 7) * per_wave;
-    const long nrot = (long)((bi >> 3) & 3) * 64 % per_wave;
-    bf16_t* out = h3 + (r0 + j) * ldh3;
-    bf16x8 wA[4], wB[4];
-    f32x4 bA[2], bB[2];
-#define LAT_COL(NB) (c0 + (((NB) + nrot) >= per_wave ? (NB) + nrot - per_wave : (NB) + nrot))
-#define LAT_LD3(W, BB, NB)                                                                        \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                               \
-      const bf16_t* wr = W3 + (LAT_COL(NB) + 16 * u + j) * ldw3 + q * 8;                          \
-      W[2 * u] = *reinterpret_cast<const bf16x8*>(wr);                                            \
-      W[2 * u + 1] = *reinterpret_cast<const bf16x8*>(wr + 32);                                   \
-      BB[u] = *reinterpret_cast<const f32x4*>(b3 + LAT_COL(NB) + 16 * u + q * 4);                 \
-    }
-#define LAT_MM3(W, BB, NB)                                                                        \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                               \
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                           \
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * u], z0, acc, 0, 0, 0);                  \
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[2 * u + 1], z1, acc, 0, 0, 0);              \
-      const bf16x4 o = {(bf16_t)fmaxf(acc[0] + BB[u][0], 0.f), (bf16_t)fmaxf(acc[1] + BB[u][1], 0.f), \
-                        (bf16_t)fmaxf(acc[2] + BB[u][2], 0.f), (bf16_t)fmaxf(acc[3] + BB[u][3], 0.f)}; \
-      *reinterpret_cast<bf16x4*>(out + LAT_COL(NB) + 16 * u + q * 4) = o;                         \
-    }
-    LAT_LD3(wA, bA, 0)
-    for (long nb = 0; nb < per_wave; nb += 64) {   // per_wave is a multiple of 64
-      LAT_LD3(wB, bB, nb + 32)
-      LAT_MM3(wA, bA, nb)
-      const long nn = nb + 64 < per_wave ? nb + 64 : per_wave - 32;
-      LAT_LD3(wA, bA, nn)
-      LAT_MM3(wB, bB, nb + 32)
-    }
-#undef LAT_LD3
-#undef LAT_MM3
-#undef LAT_COL
-  }
-}
-
-
 // ------------------------------------------------------------------ sharded optimizer: 16-bit parameter message
 // What a rank sends after updating its shard [own, own + n) of a bucket [lo, hi) cut into shards of `cnt` elements:
 //   slots [0, cnt)              bf16 (round to nearest even, the rounding of every operand shadow) of param[own + i]
@@ -920,30 +708,6 @@ int rv_randn(float* out, long n, unsigned long long seed, unsigned long long off
   return RV_OK;
 }
 
-int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
-                  const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
-                  const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
-                  float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream) {
-  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && w3_bf16 && bias3 && mulv && z_bf16 && kl_partial && h3_bf16, RV_ERR_NULL,
-             "rv_latent_fwd: null pointer");
-  RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
-  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_fwd: built for a padded latent width of 64 (got %ld)", Lp);
-  RV_REQUIRE(Hp % 512 == 0, RV_ERR_UNSUPPORTED, "rv_latent_fwd: the hidden width must be a multiple of 512 (got %ld)", Hp);
-  RV_REQUIRE(Bp > 0 && Bp % LAT_ROWS == 0 && Hp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp &&
-                 ldw3 >= Lp && ldh3 >= Hp && ldh % 8 == 0 && ldwh % 8 == 0 && ldw3 % 8 == 0 && ldh3 % 4 == 0,
-             RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld", Bp, Hp);
-  RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
-               (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16) & 15) == 0,
-             RV_ERR_SHAPE, "rv_latent_fwd: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), 0, (hipStream_t)stream,
-                     (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
-                     Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-
 int rv_reparam_fwd(const float* slabs, int splits, long Bp, long Lp, long B, long L,
                    const float* eps_in, float* eps_out, unsigned long long seed,
                    const long long* step_counter, float* mulv, void* z, float* kl_partial,
@@ -975,7 +739,7 @@ int rv_reparam_bwd_ext(const float* dz_slabs, int splits, long Bp, long Lp, long
   RV_REQUIRE(dz_slabs && mulv && eps && dmulv, RV_ERR_NULL, "rv_reparam_bwd: null pointer");
   RV_REQUIRE(splits >= 1 && B <= Bp && L <= Lp && Bp % RB_ROWS == 0 && 256 % Lp == 0, RV_ERR_SHAPE,
              "rv_reparam_bwd: bad extents (Lp must divide 256)");
-  hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / RB_ROWS)), dim3(256), 0,
+  hipLaunchKernelGGL(k_reparam_bwd, dim3((unsigned)(Bp / RB_ROWS) + 1), dim3(256), 0,
                      (hipStream_t)stream, dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta,
                      (bf16_t*)dmulv, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
                      step_counter, ring, dmu_ext, dlv_ext);

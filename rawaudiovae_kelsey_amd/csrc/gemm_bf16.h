@@ -171,6 +171,13 @@ __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// 16-byte epilogue store, optionally non-temporal (streamed past the caches: for outputs nobody reads soon)
+template <typename V>
+__device__ __forceinline__ void st16(V* dst, const V v, const bool nt) {
+  if (nt) __builtin_nontemporal_store(v, dst);
+  else *dst = v;
+}
+
 // One accumulate step on a pair of 16-byte fragments.  bf16: 16x16x32.  fp8: the two fragments of a staged tile
 // (kk = 0, 1: 2 x 16 fp8 values per lane) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
 // (E8M0 127): twice the MFMA rate of bf16 per k.  A and B fragments take their bytes from the same k positions,
@@ -867,7 +874,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           for (int e = 0; e < 8; ++e) mb |= ((float)o[e] > 0.f ? 1u : 0u) << e;
           p.out_maskbits[rowi[it] * p.ld_out_maskbits + (coli[it] >> 3)] = (unsigned char)mb;
         }
-        if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
+        if (mem) st16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.dbg & 32);
         else asm volatile("" ::"v"(o));
         if (p.out_fp8 || p.amax_part) {   // fp8 forward only
           float q8[8];
@@ -891,10 +898,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           f16x8 h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * f16s); h[4 + e] = (_Float16)(hi[e] * f16s); }
-          *(f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]) = h;
+          st16((f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]), h, p.dbg & 8);
         } else if (mem) {
-          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
-          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;
+          st16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]), lo, p.dbg & 8);
+          st16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4), hi, p.dbg & 8);
         } else {
           asm volatile("" ::"v"(lo), "v"(hi));
         }
@@ -1049,7 +1056,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             o[2 * w] = (bf16_t)t0;
             o[2 * w + 1] = (bf16_t)t1;
           }
-          if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
+          if (mem) st16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.dbg & 16);
           else asm volatile("" ::"v"(o));
         }
       }

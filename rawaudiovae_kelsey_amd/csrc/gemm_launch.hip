@@ -278,7 +278,7 @@ extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
   if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }
   if (tile == 400 || tile == 401) { g_adam_stream = tile - 400; return RV_OK; }  // experiment hook: optimizer blocks' loader  // experiment hook: 256x128 main loop
-  if (tile >= 200 && tile < 216) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
+  if (tile >= 200 && tile < 264) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
   if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
   g_force_tile = tile;
   return RV_OK;

@@ -1,0 +1,304 @@
+// Row-local fused kernels of the latent-sized part of the step (gfx950).  C ABI: include/rawvae_hip.h.
+//
+//   rv_latent_fwd : heads GEMM (fc21 | fc22) -> reparameterisation + KL partial -> fc3 + bias + ReLU
+//                   (rawvae/model.py:21-29) for 16 batch rows per workgroup, ONE launch instead of three.
+//
+// Everything here is row-local: a 16-row block needs no other block's data, so the three steps need no
+// hand-off between workgroups.  The price is that every workgroup streams the whole head weight (128 x Hp)
+// and W3 (Hp x 64) through its CU, 832 KB at C2; a CU takes in ~60-70 GB/s from L2 whatever the loop looks like
+// (MI355X_MICROARCH.md "Indexed rows: gather into LDS"), so the kernel is a STREAMING kernel whose MFMAs are
+// noise, and its design is about keeping that port busy:
+//   * the K dimension of the heads GEMM is cut over the 8 waves (wave w owns k in [w Hp/8, (w+1) Hp/8) for all
+//     128 output columns), the N dimension of fc3 likewise (wave w owns 1/8 of the Hp columns): every byte a wave
+//     stages is consumed by that wave alone, so each wave runs PRIVATE two-slot LDS rings (weights, activations) fed
+//     by global_load_lds with counted vmcnt waits and the streaming loops contain no workgroup barrier at all;
+//   * the first fc3 weight slot (and the wave's fc3 bias slice) is already in flight while the 8 partial head
+//     sums are reduced through LDS and reparameterised (two barriers in the whole kernel).
+// Round 2's version of this kernel fed its MFMAs from compiler-scheduled register loads and streamed 21-30 GB/s
+// per CU (45 us against 21 us for the three launches); this one is what DESIGN.md section 6 said it needed.
+#include "gemm_bf16.h"
+#include "philox.h"
+#include "../../include/rawvae_hip.h"
+
+using namespace rv;
+
+namespace {
+
+constexpr int LAT_ROWS = 16;
+// LDS of one wave: two 8-KiB weight slots (64 rows x 128 B) and two 2-KiB activation slots (16 rows x 128 B), all in
+// the K-major image of gemm_bf16.h (128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); fragments
+// by load_frag<.., true>).  128-byte rows on purpose: a first version staged 64-byte (32-k) row pieces and streamed
+// 37 GB/s per CU -- every 128-byte line of the weights was fetched twice, by the pieces of two consecutive steps.
+constexpr int LW_SLOT = 8 * 1024, LX_SLOT = 2 * 1024;
+constexpr int LX_OFF = 2 * LW_SLOT;
+constexpr int L_RING = 2 * LW_SLOT + 2 * LX_SLOT;   // 20 KiB per wave
+constexpr int L_LDS = 8 * L_RING;                   // all 160 KiB of the CU
+// after the streaming loops the slots are reused: partial sums in the wave's weight slot 1, the fc3 bias slice in its
+// activation slot 0, z (16 x 64 bf16) in wave 0's activation slot 1, the KL partials in wave 1's
+constexpr int L_Z = 0 * L_RING + LX_OFF + LX_SLOT;
+constexpr int L_RED = 1 * L_RING + LX_OFF + LX_SLOT;
+
+__device__ __forceinline__ void dma16(const bf16_t* g, lds_char* l) {
+  __builtin_amdgcn_global_load_lds((glb_cptr)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// `rows` (a multiple of 8) rows of 64 bf16 starting at g (row stride ld) -> K-major LDS image at sl
+template <int ROWS>
+__device__ __forceinline__ void stage_rows(const bf16_t* g, long ld, lds_char* sl, int lane) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 8; ++i) {
+    const int r = 8 * i + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    dma16(g + r * ld + c * 8, sl + i * 1024);
+  }
+}
+
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n from the handful of counts the loops need; a SMALLER count
+// than the true number of younger operations is always safe (the queue retires in order)
+__device__ __forceinline__ void wait_vm(int n) {
+  if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ void __launch_bounds__(512)
+k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __restrict__ Wh, const long ldwh,
+             const float* __restrict__ bh, const bf16_t* __restrict__ W3, const long ldw3,
+             const float* __restrict__ b3, const long Hp, const long B, const long L,
+             const float* __restrict__ eps_in, float* __restrict__ eps_out, const uint64_t seed,
+             const long long* __restrict__ step_counter, float* __restrict__ mulv, bf16_t* __restrict__ z,
+             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3) {
+  constexpr long Lp = 64, L2p = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  lds_char* smem = (lds_char*)smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const long r0 = (long)blockIdx.x * LAT_ROWS;
+  lds_char* ring = smem + wave * L_RING;
+  lds_char* const W0 = ring, * const W1 = ring + LW_SLOT;
+  const long kw = Hp / 8;          // width of a wave's K slice of the heads GEMM = of its column slice of fc3
+  const int NU = (int)(kw / 64);   // 64-deep steps of the heads GEMM = 64-column slots of fc3 (1..4)
+  // Every workgroup streams the same weights.  Workgroups b, b + 8, ... share an XCD (and its L2): the one with index
+  // bi = b >> 3 among them gives wave w the slice (w + bi) % 8 and starts its walk over the slice at step (bi >> 3) % NU,
+  // so that at any moment the 32 CUs of an XCD ask its L2 for 32 x 8 different pieces of the weights instead of the
+  // same few lines.  The summation order of a row's dot products then depends on its block: fixed, so reproducible.
+  const int bi = (int)(blockIdx.x >> 3);
+  const int ks = (wave + bi) & 7;              // slice index
+  const int rot = (bi >> 3) % NU;              // first step / slot of the walk
+
+  // ---- heads: partial[j][n] = sum over this wave's k of h1[r0 + j][k] Wh[n][k], n = 0..127.  Step s = 64 k; its
+  // weight columns come as two half-steps (head-weight rows 0..63 into W0, rows 64..127 into W1).
+  const bf16_t* xg = h1 + r0 * ldh + ks * kw;
+  const bf16_t* wg = Wh + ks * kw;
+  auto walk = [&](int s) { const int t = s + rot; return t >= NU ? t - NU : t; };   // s-th step of the rotated walk
+  auto issue_x = [&](int s) { stage_rows<16>(xg + 64 * walk(s), ldh, ring + LX_OFF + (s & 1) * LX_SLOT, lane); };
+  auto issue_w = [&](int s, int half) { stage_rows<64>(wg + (long)(64 * half) * ldwh + 64 * walk(s), ldwh, half ? W1 : W0, lane); };
+  auto issue_fc3 = [&](int u) { stage_rows<64>(W3 + (ks * kw + 64 * walk(u)) * ldw3, ldw3, (u & 1) ? W1 : W0, lane); };
+  f32x4 acc[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // issue order of the whole loop:  X0 W(0,A) [X1] W(0,B) | X2 W(1,A) | W(1,B) | X3 W(2,A) | W(2,B) ...
+  issue_x(0);
+  issue_w(0, 0);
+  if (NU > 1) issue_x(1);
+  issue_w(0, 1);
+  for (int s = 0; s < NU; ++s) {
+    bf16x8 x[2], w[4][2];
+    // half A: needs X(s) and W(s,A); the only younger pieces are W(s,B)'s 8 (at s = 0 also X1's 2: waited for too)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) x[kk] = load_frag<16, true>(ring + LX_OFF + (s & 1) * LX_SLOT, 0, kk, lane);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(W0, cb * 16, kk, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: both slots may be refilled
+    if (s + 2 < NU) issue_x(s + 2);
+    if (s + 1 < NU) {
+      issue_w(s + 1, 0);
+    } else {
+      // behind the last step: fc3 weight slot 0 and the wave's fc3 bias slice (kw floats <= 1 KiB) start to fly
+      issue_fc3(0);
+      dma16((const bf16_t*)(b3 + ks * kw + (lane * 4 < kw ? lane * 4 : 0)), ring + LX_OFF);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[cb], 0, 0, 0);
+    // half B: needs W(s,B); younger: [X(s+2): 2] + W(s+1,A): 8, or fc3 slot 0 + bias: 9
+    if (s + 2 < NU) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(W1, cb * 16, kk, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (s + 1 < NU) issue_w(s + 1, 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        acc[4 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[4 + cb], 0, 0, 0);
+  }
+  // lane (q, j) holds partial[j][16 cb + 4 q + e]: park the wave's 16 x 128 partial sums in its weight slot 1
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+    *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + cb * 16 + q * 4) * 4) = acc[cb];
+  // raw barriers: __syncthreads() would also drain vmcnt, i.e. wait for the fc3 weight slot that is meant to fly
+  // across the reduction
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- reduce the 8 partial sums (fixed order), bias, reparameterise: threads 0..255 take the 256 four-column
+  // groups of the block in k_reparam_fwd's order (same eps draws, same KL partial granularity)
+  float kl = 0.f;
+  if (tid < 256) {
+    const int rr = tid >> 4;
+    const long b = r0 + rr, l = (long)(tid & 15) * 4;
+    const long i = (long)blockIdx.x * 256 + tid;   // group index over the padded [Bp, Lp / 4] grid
+    float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (b < B && l < L) {
+      f32x4 pm[8], pv[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const lds_char* ps = smem + w * L_RING + LW_SLOT;
+        pm[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + l) * 4);
+        pv[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + 64 + l) * 4);
+      }
+      const f32x4 bm = *reinterpret_cast<const f32x4*>(bh + l), bv = *reinterpret_cast<const f32x4*>(bh + Lp + l);
+      float ev[4];
+      if (!eps_in) normal4_fast(seed, (uint64_t)i, step_counter ? (uint64_t)*step_counter : 0, ev);
+#pragma unroll
+      for (int e_ = 0; e_ < 4; ++e_) {
+        if (l + e_ < L) {
+          float e;
+          if (eps_in) {
+            e = eps_in[b * L + l + e_];
+          } else {
+            e = ev[e_];
+            eps_out[b * L + l + e_] = e;
+          }
+          mua[e_] = (((pm[0][e_] + pm[1][e_]) + (pm[2][e_] + pm[3][e_])) + ((pm[4][e_] + pm[5][e_]) + (pm[6][e_] + pm[7][e_]))) + bm[e_];
+          lva[e_] = (((pv[0][e_] + pv[1][e_]) + (pv[2][e_] + pv[3][e_])) + ((pv[4][e_] + pv[5][e_]) + (pv[6][e_] + pv[7][e_]))) + bv[e_];
+          const float sd = __expf(0.5f * lva[e_]);
+          zz[e_] = mua[e_] + e * sd;
+          kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(mulv + b * L2p + l) = make_float4(mua[0], mua[1], mua[2], mua[3]);
+    *reinterpret_cast<float4*>(mulv + b * L2p + Lp + l) = make_float4(lva[0], lva[1], lva[2], lva[3]);
+    const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
+    *reinterpret_cast<bf16x4*>(z + b * Lp + l) = zb;
+    *(__attribute__((address_space(3))) bf16x4*)(smem + L_Z + (rr * 64 + l) * 2) = zb;
+  }
+  kl = wave_sum(kl);
+  if (lane == 0) *(__attribute__((address_space(3))) float*)(smem + L_RED + wave * 4) = kl;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // z complete, the partial sums are consumed (their slots may be refilled), kl partials complete
+  asm volatile("" ::: "memory");
+  if (tid == 0) {
+    const __attribute__((address_space(3))) float* red = (const __attribute__((address_space(3))) float*)(smem + L_RED);
+    kl_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+
+  // ---- fc3: h3[r0 + j][n] = relu(sum_k W3[n][k] z[r0 + j][k] + b3[n]) for this wave's columns, 64 per slot
+  if (NU > 1) issue_fc3(1);
+  const lds_char* zl = smem + L_Z;
+  const bf16x8 z0 = *(const __attribute__((address_space(3))) bf16x8*)(zl + j * 128 + q * 16);
+  const bf16x8 z1 = *(const __attribute__((address_space(3))) bf16x8*)(zl + j * 128 + 64 + q * 16);
+  const lds_char* bl = ring + LX_OFF;   // the wave's bias slice (kw floats)
+  bf16_t* out = h3 + (r0 + j) * ldh3 + ks * kw;
+  for (int u = 0; u < NU; ++u) {
+    const lds_char* sl = (u & 1) ? W1 : W0;
+    // Outstanding operations issued after slot u's pieces, in order (stores: 2 per iteration):
+    //   u = 0: bias slice (must have landed too), [phase-2 loads and stores], slot 1   -> wait for <= 8 (slot 1 only)
+    //   u = 1: slot 2 (8, if any), stores of iteration 0 (2)
+    //   u >= 2: stores of u - 2 (2), slot u + 1 (8, if any), stores of u - 1 (2)
+    wait_vm(u == 0 ? (NU > 1 ? 8 : 0) : u == 1 ? (NU > 2 ? 10 : 2) : (u + 1 < NU ? 12 : 4));
+    bf16x8 w[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(sl, cb * 16, kk, lane);
+    // bias of the four accumulator columns a lane holds BEFORE the pairing swap below: 16 cb + 4 q ..
+    f32x4 bias[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bias[cb] = *(const __attribute__((address_space(3))) f32x4*)(bl + (walk(u) * 64 + cb * 16 + q * 4) * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (u + 2 < NU) issue_fc3(u + 2);
+    f32x4 a[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      a[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], z0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      a[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], z1, a[cb], 0, 0, 0);
+    }
+    // bias + ReLU first (plain VALU on the MFMA results: the compiler pads that hazard itself, which it cannot do in
+    // front of the inline-asm swap), then the accumulator-direct store of gemm_bf16.h: one permlane16 swap per
+    // register between the fragments of a column-block pair gives lane (q, j) the EIGHT consecutive columns
+    // (2t + (q&1)) * 16 + (q>>1) * 8 .. + 8 of row j
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[cb][e] = fmaxf(a[cb][e] + bias[cb][e], 0.f);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 lo = a[2 * t], hi = a[2 * t + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a_ = lo[r], b_ = hi[r];
+        swap_rows16(a_, b_);
+        lo[r] = a_;
+        hi[r] = b_;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16_t)lo[e];
+        o[4 + e] = (bf16_t)hi[e];
+      }
+      *(bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8) = o;
+    }
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave's is in flight towards LDS when it ends
+}
+
+}  // namespace
+
+extern "C" {
+
+int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
+                  const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
+                  const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                  float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream) {
+  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && w3_bf16 && bias3 && mulv && z_bf16 && kl_partial && h3_bf16, RV_ERR_NULL,
+             "rv_latent_fwd: null pointer");
+  RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
+  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_fwd: built for a padded latent width of 64 (got %ld)", Lp);
+  RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
+             "rv_latent_fwd: the hidden width must be a multiple of 512 up to 2048 (got %ld)", Hp);
+  RV_REQUIRE(Bp > 0 && Bp % LAT_ROWS == 0 && Hp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp &&
+                 ldw3 >= Lp && ldh3 >= Hp && ldh % 8 == 0 && ldwh % 8 == 0 && ldw3 % 8 == 0 && ldh3 % 8 == 0,
+             RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld", Bp, Hp);
+  RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
+               (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16) & 15) == 0,
+             RV_ERR_SHAPE, "rv_latent_fwd: operands must be 16-byte aligned");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_latent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
+                     (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
+                     Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
+                     (bf16_t*)h3_bf16, ldh3);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+}  // extern "C"

@@ -54,7 +54,7 @@ struct rv_plan {
   const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
   const float* ext_dmu = nullptr; const float* ext_dlv = nullptr;
   float* ext_grad_out = nullptr;
-  int latent_fused = 0;          // rv_plan_set_latent_fused: heads + reparam + fc3 as one launch (measured slower)
+  int latent_fused = 1;          // rv_plan_set_latent_fused: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   int adam_split = 1000;  // permille of fc4.weight's rows updated by the optimizer blocks of the dW1 launch
   int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
@@ -438,7 +438,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                 nullptr, nullptr, nullptr, 0, stream));
     }
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64, bf16), else three
-    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && !p->fp8;
+    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && !p->fp8;
     if (latent_fused)
       RV_TRY(rv_latent_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
                            B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp, stream));

@@ -57,14 +57,17 @@ def test_deep_fwd_bwd_vs_quantised_oracle(shape):
 
 def test_depth1_is_the_reference_topology():
     """DeepTrainEngine(depth=1) and the fused TrainEngine give the same step, bit for bit in the loss and
-    to fp32 rounding in the updated parameters (same kernels, same split choices)."""
+    to fp32 rounding in the updated parameters, when the TrainEngine is put on the deep engine's kernels (three
+    launches for heads / reparam / fc3 instead of the row-local fused one, fp32 split-K slabs): same kernels, same
+    split choices."""
     from rawaudiovae_kelsey_amd.engine import TrainEngine
     S, H, L, B = 512, 1024, 16, 256
     p = make_params(S, H, L, 0)
     ren = {"fc1": "enc.0", "fc3": "dec.0"}
     pd = {(ren.get(k.split(".")[0], k.split(".")[0]) + "." + k.split(".")[1]): v for k, v in p.items()}
     d = _engine(S, H, L, 1, B, pd)
-    e = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR)
+    e = TrainEngine(S, H, L, B, kl_beta=KL, lr=LR, slab_dtype="fp32")
+    e.set_latent_fused(False)
     e.load_params(p)
     x = torch.from_numpy(make_frames(B, S, 5)).cuda()
     eps = torch.from_numpy(make_eps(B, L, 6)).cuda()
