@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay each step from a hipGraph (N=1); ~8 us/step slower than back-to-back eager launches "
                          "of the same 12 kernels (gap between replays), so eager is the default")
+    ap.add_argument("--graph-pool", action="store_true",
+                    help="(N=1) ONE hipGraph holding the steps of the whole batch pool (8 steps per replay), so the gap "
+                         "between replays is paid once per 8 steps; steps beyond a multiple of 8 run eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
     ap.add_argument("--latent-fused", type=int, default=None, choices=[0, 1],
@@ -55,7 +58,8 @@ def parse():
                     help="permille of fc4.weight rows whose Adam update rides in the fc1 wgrad launch (default: library's)")
     ap.add_argument("--sched", type=int, default=0,
                     help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
-    ap.add_argument("--fp8", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="ignored (kept for old command lines): the headline is bf16; the fp8 forward is timed as the side line `alt_fp8`")
     ap.add_argument("--no-alts", action="store_true",
                     help="skip the side lines `alt_fp8` (fc1 / fc4 forward on e4m3 operands, BASELINE configs[4]) and "
                          "`alt_fp32_slabs`; they are timed after the headline at N=1 and never replace it")
@@ -113,6 +117,73 @@ def time_dominant_kernel(eng, reps=50):
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
     return ms.value / reps, 4.0 * S * H * B, desc
+
+
+def time_deep_c4(dev, comp, steps, warmup):
+    """Side line `alt_deep_c4` (BASELINE configs[3], never the headline): the deep variant's training step at
+    S=2048, H=2048, L=256, three H x H layers per side, B=4096, bf16 -- eager launches on `comp`, median of >= 5
+    passes -- and its dominant kernel (the paired backward launch of one H x H layer: dX = relu'(dY W) 4096x2048x2048
+    + dW = dY^T X, 68.7 GFLOP) timed live with HIP events on that stream, on the engine's own operands."""
+    import torch
+    from rawaudiovae_kelsey_amd.deep import DeepVAE
+    from rawaudiovae_kelsey_amd._lib import lib, ptr
+    Sd, Hd, Ld, depth, Bd = 2048, 2048, 256, 3, 4096
+    torch.manual_seed(0)
+    m = DeepVAE(Sd, Hd, Ld, depth).to(dev)
+    eng = m.engine(Bd, kl_beta=KL_BETA, lr=LR, seed=0)
+    g = torch.Generator(device=dev).manual_seed(99)
+    xs = [torch.rand(Bd, Sd, device=dev, generator=g) * 2 - 1 for _ in range(4)]
+    with torch.cuda.stream(comp):
+        for i in range(warmup):
+            eng.step(xs[i % 4], stream=comp)
+        torch.cuda.synchronize()
+        reps = []
+        for r in range(5):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                eng.step(xs[i % 4], stream=comp)
+            torch.cuda.synchronize()
+            reps.append(time.perf_counter() - t0)
+        reps.sort()
+        med = reps[len(reps) // 2]
+        # dominant kernel: backward of dec.1 (dy = d_dec[2] [Bp,Hp], W = dec.2.weight [Hp,Hp], x = dec_act[1])
+        Lb = lib()
+        Bp, Hp = eng.Bp, eng.Hp
+        wname = "dec.%d.weight" % (depth - 1)
+        st = comp.cuda_stream
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        Lb.rv_event_create(C.byref(e0))
+        Lb.rv_event_create(C.byref(e1))
+
+        def launch():
+            Lb.rv_linear_dgrad_wgrad(ptr(eng.d_dec[depth - 1]), Hp, ptr(eng.shadow[wname]), Hp, ptr(eng.dec_act[depth - 2]), Hp,
+                                     Bp, Hp, Hp, ptr(eng.d_dec[depth - 2]), Hp, ptr(eng.bias_part["dec.%d.bias" % (depth - 2)]),
+                                     ptr(eng.slabs[wname]), Hp, eng.splits[wname], st)
+        for _ in range(5):
+            launch()
+        Lb.rv_event_record(e0, st)
+        for _ in range(30):
+            launch()
+        Lb.rv_event_record(e1, st)
+        ms = C.c_float()
+        Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
+        Lb.rv_event_destroy(e0)
+        Lb.rv_event_destroy(e1)
+    kern_us = ms.value / 30 * 1e3
+    w = Sd * Hd + (depth - 1) * Hd * Hd + 2 * Hd * Ld + Ld * Hd + (depth - 1) * Hd * Hd + Hd * Sd
+    fpf = 6 * w - 2 * Sd * Hd            # fwd + dgrad + wgrad per weight; the first layer has no dgrad
+    kern_flops = 4.0 * Bd * Hd * Hd
+    ach = kern_flops / (kern_us * 1e-6) / 1e12
+    return {"what": "deep variant (BASELINE configs[3]): S=2048 H=2048 L=256, 3 H x H layers per side, B=4096, bf16, "
+                    "fp32 split-K slabs, eager launches",
+            "ms_per_step": med / steps * 1e3, "value": float(Bd) * steps / med, "unit": "frames/s",
+            "step_tflops": float(Bd) * steps / med * fpf / 1e12,
+            "step_mfma_frac": float(Bd) * steps / med * fpf / 1e12 / PEAK_BF16_TFLOPS,
+            "final_loss": eng.last_loss()[0], "repeats": len(reps),
+            "roofline": {"bound": "mfma", "kernel": "gemm_dgrad_wgrad_kernel<256,256> (backward of one 2048 x 2048 layer, one "
+                         "launch: dX=relu'(dY W) 4096x2048x2048 + dW=dY^T X split-K %d)" % eng.splits[wname],
+                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                         "us_per_launch": kern_us}}
 
 
 def main():
@@ -192,7 +263,9 @@ def main():
                 reasons = [None] * world
                 dist.all_gather_object(reasons, my_reason)
                 native_fallback_reason = "; ".join(r for r in reasons if r) or "another rank failed"
-        sharded = os.environ.get("RV_DDP_MODE", "sharded") != "allreduce"
+        # ONE default schedule for bench.py and train.py alike, fixed before anything is measured: all-reduce
+        # (RV_DDP_MODE=sharded selects the sharded optimizer; the other schedule is timed as a side line)
+        sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
         if ok and os.environ.get("RV_DDP_CHECK", "1") == "1":
             # The library-driven step has only ever run on ONE rank before this job (one-GPU development boxes), so
             # before it is timed it is checked here, on scratch engines: three steps of it against three steps of the
@@ -270,12 +343,19 @@ def main():
         else:
             eng.step(pool[0], stream=comp)
         torch.cuda.synchronize()
+        pool_graph = None
         if use_graph:
             for x in pool:
                 g = E.Graph(comp)
                 with g:
                     eng.step(x, stream=comp)
                 graphs.append(g)
+        elif args.graph_pool and world == 1 and not force_ddp:
+            pool_graph = E.Graph(comp)
+            with pool_graph:
+                for x in pool:
+                    eng.step(x, stream=comp)
+            eng.host_steps -= POOL   # the capture itself ran nothing
 
         def one_step(i):
             if sync is not None:
@@ -296,8 +376,15 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(args.steps):
-                one_step(first + i)
+            if pool_graph is not None:
+                for _ in range(args.steps // POOL):     # 8 steps per replay, in pool order
+                    pool_graph.launch()
+                eng.host_steps += (args.steps // POOL) * POOL
+                for i in range(args.steps % POOL):
+                    one_step(i)
+            else:
+                for i in range(args.steps):
+                    one_step(first + i)
             host = time.perf_counter() - t0   # all K steps enqueued (the host runs ahead of the GPU)
             torch.cuda.synchronize()
             if world > 1:
@@ -342,7 +429,7 @@ def main():
                 print("bench.py: replicas diverged: %r vs %r" % (lo.tolist(), hi.tolist()), file=sys.stderr)
         # Not the headline: the same K steps again with the bf16 gradient payload (half the all-reduce
         # bytes), so that one run shows what the exchange costs at this GPU count.
-        alt, alt_key, ddp_pick, alt_bf16 = None, None, None, None
+        alt, alt_key, ddp_pick, alt_bf16, alt_sh = None, None, None, None, None
         if isinstance(runner, ddp.NativeDdpRunner) and runner.sharded and os.environ.get("RV_DDP_ALT", "1") == "1":
             alt_key = "alt_allreduce"
             # Not the headline: the same K steps with the all-reduce + full-update schedule on a second engine
@@ -422,7 +509,7 @@ def main():
                 # Both schedules are the product's (same step, same arithmetic up to the order of the reduction);
                 # which one is faster depends on the GPU count and the links, and this is the first hardware either
                 # has run on at N > 1: the headline is the faster of the two, the other stays beside it.
-                if adt < dt and a_consistent is not False and os.environ.get("RV_DDP_PICK", "1") == "1":
+                if adt < dt and a_consistent is not False and os.environ.get("RV_DDP_PICK", "0") == "1":
                     alt_key = "alt_sharded"
                     alt = {"grad_allreduce": ddp_mode, "ms_per_step": dt / args.steps * 1e3,
                            "value": float(B) * world * args.steps / dt, "repeats": len(passes),
@@ -437,6 +524,50 @@ def main():
             except Exception as exc:   # the headline above is already measured: report, do not lose it
                 alt = {"grad_allreduce": ar_what, "error": str(exc)[:200]}
         elif isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
+            # side line, never the headline: the same K steps with the sharded optimizer on a second engine
+            try:
+                eng2 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
+                eng2.load_params(make_params(S, H, L, 0))
+                run2 = ddp.NativeDdpRunner(eng2, comm, comp, sharded=True)
+                for i in range(args.warmup + 1):
+                    run2.step(pool[i % POOL])
+                torch.cuda.synchronize()
+                sp_ = []
+                for r in range(min(len(passes), 25)):
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(args.steps):
+                        run2.step(pool[(args.warmup + r * args.steps + i) % POOL])
+                    torch.cuda.synchronize()
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t1
+                    if world > 1:
+                        t = torch.tensor([el], dtype=torch.float64, device=dev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        el = float(t.item())
+                    sp_.append(el)
+                sp_.sort()
+                s_consistent = None
+                if world > 1:
+                    ddp.gather_sharded_params(eng2)
+                    chk = torch.stack([eng2.param.double().sum(), eng2.param.double().abs().sum()])
+                    lo, hi = chk.clone(), chk.clone()
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                    s_consistent = bool(torch.equal(lo, hi))
+                alt_sh = {"grad_allreduce": "sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the "
+                                            "arena -> all-gather of the %s" % (world, "16-bit parameter message (bf16 weights + fp32 biases)"
+                                                                               if getattr(eng2, "shard_gather", "fp32") == "bf16" else "fp32 parameters"),
+                          "ms_per_step": sp_[len(sp_) // 2] / args.steps * 1e3,
+                          "value": float(B) * world * args.steps / sp_[len(sp_) // 2], "repeats": len(sp_),
+                          **({"replicas_consistent": s_consistent} if s_consistent is not None else {})}
+                del run2, eng2
+            except Exception as exc:
+                alt_sh = {"grad_allreduce": "sharded optimizer", "error": str(exc)[:200]}
             try:
                 runner.set_payload("bf16")
                 for i in range(5):
@@ -488,6 +619,10 @@ def main():
             alts["alt_fp8"] = time_alt(
                 "fc1 and fc4 forward on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor scales, delayed "
                 "activation scaling); backward and everything else bf16", fp8=True)
+            try:
+                alts["alt_deep_c4"] = time_deep_c4(dev, comp, max(10, args.steps // 4), 5)
+            except Exception as exc:
+                alts["alt_deep_c4"] = {"what": "deep variant (BASELINE configs[3])", "error": str(exc)[:200]}
             alts["alt_fp32_slabs"] = time_alt(
                 "split-K partial sums of dW1 / dW4 stored as fp32 instead of block-floating-point fp16 (round 2's "
                 "default); everything else as the headline", slab_dtype="fp32")
@@ -524,14 +659,18 @@ def main():
             "config": {"workload": "C2 raw-audio VAE train step: S=1024 H=2048 L=64, per-GPU batch 4096, "
                                    "kl_beta=1e-4, Adam lr=1e-4", "global_batch": B * world,
                        "parallelism": "dp%d" % world,
-                       "launch": "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
+                       "launch": "hipGraph (one graph of %d steps)" % POOL if pool_graph is not None else
+                                 "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
                        "schedule": int(0 if args.serial else args.sched), "wgrad_slabs": eng.slab_dtype,
+                       **({"ddp_mode": "sharded" if getattr(runner, "sharded", False) else "allreduce",
+                           "shard_gather": getattr(eng, "shard_gather", None)} if runner is not None else {}),
                        "grad_allreduce": ddp_mode},
             # `value` / `ms_per_step` are the MEDIAN over `repeats` passes of exactly `steps` steps each
             "timing": {"repeats": len(passes), "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
                        "timed_seconds_total": sum(passes)},
             "host_us_per_step": host_dt / args.steps * 1e6,
             **({(alt_key or "alt_bf16_payload"): alt} if alt else {}),
+            **({"alt_sharded": alt_sh} if alt_sh else {}),
             **({"ddp_schedule_pick": ddp_pick} if ddp_pick else {}),
             **({"alt_allreduce_bf16_payload": alt_bf16} if alt_bf16 else {}),
             **alts,
@@ -556,7 +695,23 @@ def main():
             # BASELINE configs[0] (the reference's own CPU-runnable case: 512-sample frames, latent 8, batch 32)
             s_fps, s_ms, s_n, _ = time_cpu_step(512, H, 8, 32, make_params(512, H, 8, 0), make_frames(32, 512, 1234),
                                                 seconds=min(3.0, args.cpu_seconds), threads=threads)
+            # the same C2 step on ALL the CPUs this process may use (SURVEY 8d asks for os.cpu_count() threads); a
+            # one-GPU box can be a 16-CPU share of a 256-thread host, where this oversubscribes: bounded to a few steps
+            all_cores = None
+            try:
+                usable = len(os.sched_getaffinity(0))
+            except AttributeError:
+                usable = os.cpu_count()
+            if usable and usable != threads:
+                try:
+                    a_fps, a_ms, a_n, a_thr = time_cpu_step(S, H, L, B, make_params(S, H, L, 0), make_frames(B, S, 1234),
+                                                          seconds=min(4.0, args.cpu_seconds), warmup=1, threads=usable, min_steps=1)
+                    all_cores = {"value": a_fps, "unit": "frames/s", "cores": a_thr, "ms_per_step": a_ms,
+                                 "sample": "%d steps of the same C2 step on every usable CPU" % a_n}
+                except Exception as exc:
+                    all_cores = {"error": str(exc)[:200]}
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
+                                   **({"all_cores": all_cores} if all_cores else {}),
                                    "sample": "%d steps of the same C2 step (B=4096) in stock PyTorch fp32 on the "
                                              "host, median %.1f ms/step" % (n, ms_c),
                                    "smoke_shape": {"value": s_fps, "unit": "frames/s", "ms_per_step": s_ms,

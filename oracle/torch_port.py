@@ -75,7 +75,7 @@ def cpu_description():
 
 
 def time_cpu_step(S, H, L, B, params, x, seconds=15.0, warmup=2, kl_beta=1e-4, lr=1e-4,
-                  threads=None):
+                  threads=None, min_steps=3):
     """Time zero_grad/forward/loss/backward/Adam.step on the host CPU.
     Returns (frames_per_s, ms_per_step_median, steps_timed, threads)."""
     import os
@@ -108,7 +108,7 @@ def time_cpu_step(S, H, L, B, params, x, seconds=15.0, warmup=2, kl_beta=1e-4, l
                 t_end = time.perf_counter() + seconds
             continue
         times.append(dt)
-        if time.perf_counter() >= t_end and len(times) >= 3:
+        if time.perf_counter() >= t_end and len(times) >= min_steps:
             break
     times.sort()
     med = times[len(times) // 2]

@@ -726,8 +726,26 @@ int rv_plan_set_shard_message(rv_plan* p, void* msg_send, void* msg_recv) {
   return RV_OK;
 }
 
-// One sharded data-parallel step (see rv_plan_attach_comm_sharded in the header).  Collectives run on the internal
-// stream in the order RS(fc4) RS(rest) AG(fc4) AG(rest); it forks from and joins into the caller's stream only.
+// Schedule shared by both data-parallel modes (round 3: one-rank cost 255-262 -> see profiles/r03_ddp_one_rank.txt):
+//   * every cross-stream edge costs ~6 us on this runtime (a hipEventRecord on the compute stream is a bubble), so the
+//     step has ONE fork and ONE join: only fc4's bucket, ready after the paired fc4 backward, travels on the collective
+//     stream behind the rest of backward; the second bucket's collective (nothing is left to hide it behind) is issued
+//     on the compute stream itself, and so are the sharded mode's all-gathers;
+//   * collectives of one communicator are never in flight on two streams at once: the compute stream joins the
+//     collective stream (fc4's exchange done) before it issues its own;
+//   * in the all-reduce mode the fc1 weight-gradient launch keeps carrying an optimizer update on the CUs its GEMM
+//     leaves idle, as in the local step: Adam(fc4) from the reduced flat gradient.
+
+// this rank's shard of a bucket [lo, hi) cut into shards of cnt: [own, own + n) with n clipped to the bucket's end
+static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) {
+  *own = lo + (long)rank * cnt;
+  *n = hi - *own;
+  if (*n > cnt) *n = cnt;
+  if (*n < 0) *n = 0;
+}
+
+// One sharded data-parallel step (see rv_plan_attach_comm_sharded in the header): RS(fc4) on the collective stream
+// behind the rest of backward, RS(rest), Adam on the own shards, AG(fc4), AG(rest) on the caller's stream.
 static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                             unsigned long long seed, void* stream) {
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
@@ -745,27 +763,19 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   float* ag[2] = {p->ag_buf, p->ag_buf + (long)p->world * cnt[0]};
   int rc;
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
-  // Every cross-stream edge costs ~6 us on this runtime, so the step has five: a fork per gradient bucket, ONE
-  // join for both reduce-scatters, one fork for both all-gathers and one join for them.
-  auto scatter_bucket = [&](int b) -> int {
-    RV_TRY(rv_grad_finalize(p->d_slab + t0_b[b], nt_b[b], p->b.grad, stream));
-    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
-    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
-    const int nrc = p->reduce_scatter(p->b.grad + lo_b[b], rs[b], (size_t)cnt[b], /*ncclFloat32*/ 7, /*ncclSum*/ 0, p->comm, (void*)sc);
+  auto scatter_bucket = [&](int b, hipStream_t on) -> int {
+    const int nrc = p->reduce_scatter(p->b.grad + lo_b[b], rs[b], (size_t)cnt[b], /*ncclFloat32*/ 7, /*ncclSum*/ 0, p->comm, (void*)on);
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "reduce-scatter of gradient bucket %d failed (collective library code %d)", b, nrc);
     return RV_OK;
-  };
-  // this rank's shard of a bucket: [own, own + n) with n clipped to the bucket's end
-  auto own_of = [&](int b, long* own, long* n) {
-    *own = lo_b[b] + (long)p->rank * cnt[b];
-    *n = hi_b[b] - *own;
-    if (*n > cnt[b]) *n = cnt[b];
-    if (*n < 0) *n = 0;
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  RV_TRY(scatter_bucket(0));   // fc4's 8.4 MB travel behind the rest of backward
+  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, stream));
+  RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
+  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
+  RV_TRY(scatter_bucket(0, sc));                              // fc4's 8.4 MB travel behind the rest of backward
+  RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
                                    (float*)p->ws("dW3"), Lp, p->s_w3, stream));
   RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
@@ -773,12 +783,12 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
   RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-  RV_TRY(scatter_bucket(1));
-  RV_HIP(hipEventRecord(p->ev_done[1], sc));           // both reduce-scatters (the collective stream is in order)
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
+  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, stream));
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: fc4's reduce-scatter is done
+  RV_TRY(scatter_bucket(1, s0));
   for (int b = 0; b < 2; ++b) {
     long own, n;
-    own_of(b, &own, &n);
+    own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
     RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, stream));
   }
   if (p->msg_send && !p->fp8) {
@@ -789,28 +799,20 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     unsigned short* rcv[2] = {p->msg_recv, p->msg_recv + (long)p->world * slots[0]};
     for (int b = 0; b < 2; ++b) {
       long own, n;
-      own_of(b, &own, &n);
+      own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
       RV_TRY(rv_shard_encode(p->d_slab + t0_b[b], nt_b[b], p->b.param, lo_b[b] + (long)p->rank * cnt[b], n, cnt[b], snd[b], stream));
     }
-    RV_HIP(hipEventRecord(p->ev_upd[0], s0));
-    RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
     for (int b = 0; b < 2; ++b) {
-      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, (void*)sc);
+      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, stream);
       if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter message %d failed (collective library code %d)", b, nrc);
     }
-    RV_HIP(hipEventRecord(p->ev_gath[0], sc));
-    RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
     for (int b = 0; b < 2; ++b)
       RV_TRY(rv_shadows_from_msg(p->d_slab + t0_b[b], nt_b[b], rcv[b], lo_b[b], cnt[b], slots[b], p->b.param, stream));
   } else {
-    RV_HIP(hipEventRecord(p->ev_upd[0], s0));
-    RV_HIP(hipStreamWaitEvent(sc, p->ev_upd[0], 0));
     for (int b = 0; b < 2; ++b) {
-      const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)sc);
+      const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, stream);
       if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
     }
-    RV_HIP(hipEventRecord(p->ev_gath[0], sc));
-    RV_HIP(hipStreamWaitEvent(s0, p->ev_gath[0], 0));
     for (int b = 0; b < 2; ++b)
       RV_TRY(rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, stream));
   }
@@ -846,48 +848,25 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   const float scale = 1.0f / (float)p->world;
   int rc;
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
-  // Bucket b = tensors [t0, t1) of the flat arena, summed over ranks on the collective stream, which
-  // forks from and joins into the caller's stream only (a helper stream forking from another helper
-  // stream makes hipStreamEndCapture recurse without end in this HIP runtime).
-  auto reduce_bucket = [&](int b, int t0, int t1) -> int {
+  // Bucket = tensors [t0, t1) of the flat arena: slabs -> flat payload (caller's stream), then the SUM over ranks
+  // on stream `on`
+  auto payload = [&](int t0, int t1) -> int {
+    if (p->payload_bf16) return rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, stream);
+    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, stream);
+  };
+  auto reduce = [&](int b, int t0, int t1, hipStream_t on) -> int {
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
-    int frc, nrc;
-    // slabs -> flat payload on the caller's stream: with exchanges that take as long as the backward that
-    // hides them (tools/ddp_occupancy_probe.py) the collective stream is the critical path, and a payload
-    // kernel queued there behind the previous exchange costs 20+ us per step; here it costs ~9
-    if (p->payload_bf16) frc = rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, stream);
-    else frc = rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, stream);
-    if (frc) return frc;
-    RV_HIP(hipEventRecord(p->ev_ready[b], s0));
-    RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[b], 0));
+    int nrc;
     if (p->payload_bf16) {
       char* g = (char*)p->grad_bf16 + 2 * lo;
-      nrc = p->allreduce(g, g, (size_t)(hi - lo), /*ncclBfloat16*/ 9, /*ncclSum*/ 0, p->comm, (void*)sc);
+      nrc = p->allreduce(g, g, (size_t)(hi - lo), /*ncclBfloat16*/ 9, /*ncclSum*/ 0, p->comm, (void*)on);
     } else {
       nrc = p->allreduce(p->b.grad + lo, p->b.grad + lo, (size_t)(hi - lo), /*ncclFloat32*/ 7, /*ncclSum*/ 0,
-                         p->comm, (void*)sc);
+                         p->comm, (void*)on);
     }
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-reduce of gradient bucket %d failed (collective library code %d)", b, nrc);
-    RV_HIP(hipEventRecord(p->ev_done[b], sc));
     return RV_OK;
   };
-  // forward + loss and the paired fc4 backward (as rv_plan_step)
-  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  RV_TRY(reduce_bucket(0, 8, 10));       // fc4 (8.4 MB at C2) travels behind the rest of backward
-  // the rest of backward on the caller's stream (every cross-stream edge costs 6-10 us on this runtime,
-  // eager or captured, so the compute side forks nothing here; only the two exchanges run beside it)
-  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
-                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
-  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
-                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-  RV_TRY(reduce_bucket(1, 0, 8));          // fc1, fc21, fc22, fc3: contiguous in the arena
-  // optimizer per bucket as its sum arrives; the fc4 launch overlaps the second exchange
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));
   auto adam_bucket = [&](int t0, int n) -> int {
     if (p->payload_bf16)
       return rv_adam_multi_bf16grad(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, p->grad_bf16, lr,
@@ -895,8 +874,33 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
                          p->b.step_counter, stream);
   };
-  RV_TRY(adam_bucket(8, 2));
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[1], 0));
+  // forward + loss and the paired fc4 backward (as rv_plan_step)
+  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
+  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+  RV_TRY(payload(8, 10));
+  RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) travels behind the rest of backward
+  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
+  RV_TRY(reduce(0, 8, 10, sc));
+  RV_HIP(hipEventRecord(p->ev_done[0], sc));
+  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
+                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
+  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
+  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
+                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));        // the join: fc4's sum has arrived
+  const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
+  if (!p->payload_bf16 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && n_gemm <= 192) {
+    // dW1's launch carries Adam(fc4) from the reduced flat gradient on the CUs its GEMM leaves idle
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_flat + 8,
+                                2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, scale, p->b.step_counter, 256 - n_gemm, stream));
+  } else {
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(adam_bucket(8, 2));
+  }
+  RV_TRY(payload(0, 8));                                   // fc1, fc21, fc22, fc3: contiguous in the arena
+  RV_TRY(reduce(1, 0, 8, s0));                             // nothing left to hide it behind: on the caller's stream
   RV_TRY(adam_bucket(0, 8));
 #undef RV_TRY
   return RV_OK;

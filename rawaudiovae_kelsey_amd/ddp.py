@@ -328,7 +328,7 @@ class RcclComm:
 _COMM_STREAMS = {}   # (device index, compute stream handle) -> (collective stream, us per ping-pong, candidates tried)
 
 
-def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0):
+def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0, bad_us=100.0):
     """A high-priority stream for the collectives whose cross-stream waits against `compute_stream` stay on the
     device.  The HIP runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); when two
     streams that wait on each other share one, the runtime resolves the waits on the host and every kernel behind
@@ -336,7 +336,9 @@ def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0):
     many streams the process had created before).  So: time a short ping-pong (kernel, event, wait, kernel, event,
     wait) between the compute stream and a candidate; a healthy pair takes ~15 us per round trip, an affected one
     >100.  Candidates are created one after the other (each lands on the next hardware queue) until one is healthy;
-    the rejected ones are kept alive so that the mapping of the chosen one does not move.  Cached per compute stream."""
+    the rejected ones are kept alive so that the mapping of the chosen one does not move.  Cached per compute stream.
+    If even the best candidate takes `bad_us` or more per round trip the call raises instead of silently running a
+    step that is several times slower (RV_COMM_STREAM_ALLOW_SLOW=1 overrides)."""
     key = (device.index, compute_stream.cuda_stream)
     if key in _COMM_STREAMS:
         return _COMM_STREAMS[key][0]
@@ -368,6 +370,12 @@ def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0):
         if us < good_us:
             break
     _COMM_STREAMS[key] = (best[0], best[1], tried)
+    if best[1] >= bad_us and os.environ.get("RV_COMM_STREAM_ALLOW_SLOW") != "1":
+        from ._lib import RvError
+        raise RvError("pick_comm_stream: none of %d candidate streams is healthy against the compute stream (best round "
+                      "trip %.0f us, a healthy pair takes ~15): their cross-stream waits would be resolved on the host and "
+                      "every kernel of a data-parallel step would start ~50 us late.  Raise GPU_MAX_HW_QUEUES, or set "
+                      "RV_COMM_STREAM_ALLOW_SLOW=1 to run anyway." % (len(tried), best[1]))
     return best[0]
 
 

@@ -163,7 +163,15 @@ class TrainEngine:
         return self.buffer("fp8_state", torch.float32, (8,)).tolist()
 
     def refresh_shadows(self, stream=None):
-        """Rebuild this engine's bf16/padded weight shadows from the fp32 arena."""
+        """Rebuild this engine's bf16/padded weight shadows from the fp32 arena.  If an engine sharing the arena
+        runs the sharded optimizer with the 16-bit parameter message, the fp32 weight masters are current on their
+        owner rank only: they are gathered first (a collective -- every rank reaches this point together, because
+        the engines of all ranks step in the same order), or this engine would compute with stale weights for
+        (world - 1) / world of the arena."""
+        owner = self._shared.get("bf16_gather_engine")
+        if owner is not None:
+            from . import ddp
+            ddp.gather_sharded_params(owner)
         if self.fp8:
             with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
                 st = self.buffer("fp8_state", torch.float32, (8,))
@@ -271,6 +279,7 @@ class TrainEngine:
                 self._msg_recv = torch.zeros(comm.world * sum(slots), **i16)
                 self.msg_slots = slots
                 lib().rv_plan_set_shard_message(self._plan, ptr(self._msg_send), ptr(self._msg_recv))
+                self._shared["bf16_gather_engine"] = self   # refresh_shadows of every engine on this arena gathers first
             else:
                 lib().rv_plan_set_shard_message(self._plan, None, None)
         else:

@@ -64,8 +64,9 @@ class _Holder:
             eng.adopt(module)
             self.ptrs = tuple(p.data_ptr() for p in params)
             self.versions = None
-        vers = tuple(p._version for p in params)
-        if vers != self.versions:       # optimizer.step / load_state_dict / any in-place write
+        from . import ops
+        vers = tuple(p._version for p in params) + (ops._EPOCH[0],)
+        if vers != self.versions:       # optimizer.step / load_state_dict / any in-place write / ops.invalidate_shadows()
             eng.params_changed()
             self.versions = vers
         return eng

@@ -50,9 +50,15 @@ def _pad_bias(b, n_p):
 
 
 # Operand shadows of the PARAMETERS (padded bf16 weights, padded fp32 biases) are rebuilt only when a parameter
-# has changed: keyed by storage address + shape + padding and validated by the tensors' `_version` counters,
-# which every in-place update (optimizer.step, load_state_dict, .copy_) increments.  Without it each forward
-# re-cast all five weights (~60 small launches per step, host-bound at ~1 ms/step on the reference-style loop).
+# has changed: keyed by storage address + shape + padding and validated by (a) the IDENTITY of the tensors -- each
+# entry holds weak references to the tensors it was built from, so a new model that happens to be allocated at a
+# freed model's addresses never inherits its shadows, and an entry whose tensors died is dropped -- and (b) the
+# tensors' `_version` counters, which every in-place update (optimizer.step, load_state_dict, .copy_) increments.
+# Writes through `.data` (p.data.copy_, EMA / clipping on .data) do NOT move the version counter: call
+# `invalidate_shadows()` after them.  Without the cache each forward re-cast all five weights (~60 small launches
+# per step, host-bound at ~1 ms/step on the reference-style loop).
+import weakref
+
 _SHADOWS = {}
 _SHADOW_SLOTS = 64
 
@@ -62,19 +68,26 @@ def _shadow(kind, tensors, dims, build):
            torch.cuda.current_stream().cuda_stream)
     ver = tuple(t._version for t in tensors)
     hit = _SHADOWS.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[2], tensors)):
         return hit[1]
     val = build()
+    for k in [k for k, v in _SHADOWS.items() if any(r() is None for r in v[2])]:
+        del _SHADOWS[k]           # entries of freed models
     if len(_SHADOWS) >= _SHADOW_SLOTS:
         _SHADOWS.pop(next(iter(_SHADOWS)))
-    _SHADOWS[key] = (ver, val)
+    _SHADOWS[key] = (ver, val, tuple(weakref.ref(t) for t in tensors))
     return val
+
+
+_EPOCH = [0]   # bumped by invalidate_shadows(); the one-node forward (fused.py) re-derives its operands when it moved
 
 
 def invalidate_shadows():
     """Forget every cached shadow: for writers that change parameters behind PyTorch's back (the fused
-    engine updates its arena through the C ABI, which does not touch the tensors' version counters)."""
+    engine updates its arena through the C ABI, and writes through `.data` do not touch the tensors' version
+    counters either).  Also makes the one-node `VAE.forward` (fused.py) rebuild its operand shadows on its next call."""
     _SHADOWS.clear()
+    _EPOCH[0] += 1
 
 
 def weight_shadow(W, rows_p, cols_p):

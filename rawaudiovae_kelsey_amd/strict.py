@@ -105,6 +105,7 @@ class StrictFp32Engine:
         g["fc22.bias"].copy_(_colsum(dlv, False, B, self.L, self.L))
         dh1 = self._ew(2, self._lin(dmu, T(p["fc21.weight"])), self._lin(dlv, T(p["fc22.weight"])))
         dP1 = self._ew(1, dh1, c["h1"])
+        c["dP1"] = dP1   # kept for the per-element summation-error check of tests/test_strict_fp32_gpu.py
         g["fc1.weight"].copy_(self._lin(T(dP1), T(x)))
         g["fc1.bias"].copy_(_colsum(dP1, False, B, self.H, self.H))
 

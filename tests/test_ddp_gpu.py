@@ -233,3 +233,48 @@ def test_sharded_adam_kernels_equal_full_adam(world):
         for name, dt in (("W1b", torch.bfloat16), ("Whb", torch.bfloat16), ("W3b", torch.bfloat16),
                          ("W4b", torch.bfloat16), ("b1p", torch.float32), ("bhp", torch.float32), ("b4p", torch.float32)):
             assert torch.equal(sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))), name
+
+
+def test_engines_sharing_an_arena_gather_the_masters_before_rebuilding_shadows(monkeypatch):
+    """Sharded optimizer with the 16-bit parameter message, two engines on one arena (train.py's full-batch engine and
+    its ragged-tail engine): after a step of one engine the fp32 weight masters are current on their owner rank only,
+    so the OTHER engine must gather them before it rebuilds its operand shadows from the arena.  Emulated here on
+    one GPU: engine A is marked as the bf16-gather owner, the half of the arena another rank would own is poisoned
+    with NaN behind A's back, and the gather (monkeypatched to what the all-gather would deliver: the true masters)
+    must run before engine B's refresh -- B then steps on finite, correct weights."""
+    from oracle.inputs import make_frames, make_params
+    from rawaudiovae_kelsey_amd import ddp
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    S, H, L = 256, 512, 16
+    a = TrainEngine(S, H, L, 128, kl_beta=1e-4, lr=1e-4)
+    b = TrainEngine(S, H, L, 64, kl_beta=1e-4, lr=1e-4, share=a)
+    a.load_params(make_params(S, H, L, 0))
+    xa = torch.from_numpy(make_frames(128, S, 1)).cuda()
+    xb = torch.from_numpy(make_frames(64, S, 2)).cuda()
+    a.step(xa)
+    torch.cuda.synchronize()
+    truth = a.param.clone()
+    a._shared["bf16_gather_engine"] = a                 # what attach_comm(sharded=True, gather="bf16") records
+    half = a.n_params // 2
+    a.param[half:].fill_(float("nan"))                  # masters another rank owns: stale / unusable here
+    calls = []
+
+    def fake_gather(engine, group=None):
+        calls.append(engine)
+        engine.param.copy_(truth)                       # the all-gather of every owner's shard
+
+    monkeypatch.setattr(ddp, "gather_sharded_params", fake_gather)
+    b.step(xb)                                          # version moved: B refreshes its shadows first
+    torch.cuda.synchronize()
+    assert calls == [a]
+    loss = b.last_loss()[0]
+    assert loss == loss and 0 < loss < 1
+    assert torch.isfinite(b.buffer("W4b", torch.bfloat16, (-1,)).float()).all()
+    # the same step without the poisoning gives the same loss bit for bit
+    c = TrainEngine(S, H, L, 128, kl_beta=1e-4, lr=1e-4)
+    d = TrainEngine(S, H, L, 64, kl_beta=1e-4, lr=1e-4, share=c)
+    c.load_params(make_params(S, H, L, 0))
+    c.step(xa)
+    d.step(xb)
+    torch.cuda.synchronize()
+    assert d.last_loss() == b.last_loss()

@@ -285,3 +285,46 @@ def test_fused_forward_node_guards_and_fallbacks():
     m2 = m.cpu().cuda()
     r, mu, lv = m2(x)
     np.testing.assert_allclose(mu.detach().cpu().numpy(), m2.encode(x)[0].detach().cpu().numpy(), atol=2e-2)
+
+
+def test_shadow_cache_is_tied_to_the_tensors_not_to_their_addresses():
+    """The per-layer API path caches the padded bf16 / fp32 operand shadows of the parameters.  (1) A second model
+    built after the first one was freed -- the allocator hands it the same addresses, with the same version
+    counters -- must run on ITS weights (entries hold weak references to the tensors they were built from).
+    (2) Writes through `.data` do not move a tensor's version counter: `ops.invalidate_shadows()` after them, and both
+    the per-layer path and the one-node forward pick the new weights up."""
+    import gc
+    from rawvae.model import VAE
+    from rawaudiovae_kelsey_amd import ops
+    S, H, L, B = 128, 256, 8, 64
+    x = torch.from_numpy(make_frames(B, S, 3)).cuda()
+
+    def build(seed):
+        m = VAE(S, H, L)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(S, H, L, seed).items()})
+        m = m.to("cuda")
+        m.fused_training = False        # per-layer Functions: the cached-shadow path
+        return m
+    outs, ptrs = [], []
+    for seed in (0, 1):
+        m = build(seed)
+        ptrs.append(m.fc1.weight.data_ptr())
+        mu, _ = m.encode(x)
+        ref = O.forward(O.cast_params(make_params(S, H, L, seed), np.float32), x.cpu().numpy(),
+                        np.zeros((B, L), np.float32), quant="bf16")
+        np.testing.assert_allclose(mu.detach().cpu().numpy(), ref["mu"], atol=2e-4 * max(1, np.abs(ref["mu"]).max()))
+        outs.append(mu.detach().clone())
+        del m, mu
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert not torch.equal(outs[0], outs[1])
+    # (2) a .data write is invisible to the version counters until the cache is invalidated
+    for fused in (False, True):
+        m = build(0)
+        m.fused_training = fused
+        a = m(x)[1].detach().clone()
+        m.fc21.weight.data.mul_(2.0)
+        m.fc21.bias.data.mul_(2.0)
+        ops.invalidate_shadows()
+        b = m(x)[1].detach().clone()
+        np.testing.assert_allclose(b.cpu().numpy(), 2.0 * a.cpu().numpy(), rtol=2e-2, atol=1e-4)
