@@ -392,6 +392,19 @@ int rv_linear_dgrad_wgrad_ex(const void* dy_bf16, long lddy, const void* w_bf16,
                              float* slab_unscale, void* stream);
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
+/* rv_linear_fwd whose operand rows are read where the audio lives (AudioDataset.__getitem__,
+ * rawvae/dataset.py:108-118): row r < B is the frame audio_bf16[f*hop : f*hop + Kp], f = frame_index ? frame_index[r]
+ * : first_frame + r, of the waveform kept in HBM as bf16 (cast once when it was uploaded; rounding to bf16 is what
+ * rv_cast_pad_bf16 does per batch, so the operand is bit-identical); rows B..Mp repeat row B - 1 (padding).  The A
+ * tile loader stages each frame's 16-byte pieces straight from the waveform -- no cast / gather kernel, no fp32
+ * read.  hop % 8 == 0, 16-byte aligned waveform, and the buffer must extend Kp elements past the last frame's start.
+ * frames_bf16 (or NULL) receives the framed [Mp][ld_frames] bf16 matrix as a by-product (the weight gradient's
+ * operand): the block with tile_n == kt % tiles_n copies K tile kt of its rows out of LDS.  step_counter (or NULL)
+ * is incremented by block 0 (the step's first kernel does that). */
+int rv_linear_fwd_frames(const void* audio_bf16, const long long* frame_index, long first_frame, long hop, long B,
+                         const void* w_bf16, long ldw, const float* bias, long Mp, long Np, long Kp, int act,
+                         void* y_bf16, long ldy, void* frames_bf16, long ld_frames, long long* step_counter,
+                         void* stream);
 int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
                                const float* dq, long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx,
                                float* recon, long ld_recon, void* dP4_bf16, long ld_dp4, float* mse_partial,
@@ -492,12 +505,15 @@ int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* 
                  unsigned long long seed, void* stream);
 /* rv_plan_step whose batch is B hop-strided frames of a waveform resident in HBM (AudioDataset semantics,
  * rawvae/dataset.py:99-121; frame i = audio[f*hop : f*hop + S], f = frame_index ? frame_index[i] : first_frame + i,
- * samples past n_samples read as 0): fc1's bf16 operand is cast straight from the waveform
- * (rv_gather_cast_frames) and fc4's loss epilogue reads its fp32 target there too
- * (rv_decode_out_loss_fwd_frames), so no framed copy of the batch is ever written. */
-int rv_plan_step_frames(rv_plan*, int phases, const float* audio, long n_samples, const long long* frame_index,
-                        long first_frame, long hop, const float* eps, float* recon_out, float kl_beta, float lr,
-                        float grad_scale, int adam_from_flat, unsigned long long seed, void* stream);
+ * samples past n_samples read as 0).  With audio_bf16 (the same waveform as bf16, n_samples + Sp + 8 elements, zero
+ * past n_samples; hop % 8 == 0) the step launches NO cast or gather kernel: fc1's A-tile loader reads frame f at
+ * f*hop of the bf16 waveform (rv_linear_fwd_frames) and fc4's loss epilogue reads its fp32 target at f*hop of `audio`
+ * (rv_decode_out_loss_fwd_frames).  audio_bf16 == NULL (or an unaligned hop, or the fp8 forward) falls back to one
+ * cast kernel per step (rv_gather_cast_frames). */
+int rv_plan_step_frames(rv_plan*, int phases, const float* audio, const void* audio_bf16, long n_samples,
+                        const long long* frame_index, long first_frame, long hop, const float* eps, float* recon_out,
+                        float kl_beta, float lr, float grad_scale, int adam_from_flat, unsigned long long seed,
+                        void* stream);
 int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
                           long n_frames, long S, long hop, void* dst_bf16, long rows_p, long cols_p, long ld_dst,
                           void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part, int n_amax,

@@ -101,6 +101,8 @@ _SIGS = {
                                          c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int,
                                          c_void_p, c_void_p]),
     "rv_plan_set_slab_dtype": (c_int, [c_void_p, c_int]),
+    "rv_linear_fwd_frames": (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
+                                     c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_wgrad_adam_fits": (c_int, [c_long, c_long, c_long, c_int]),
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
                                      c_int, c_void_p, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
@@ -140,7 +142,7 @@ _SIGS = {
                                    c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_float, c_int, c_u64, c_void_p]),
-    "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,
+    "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_int, c_u64, c_void_p]),
     "rv_gather_cast_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_long, c_long,
                                       c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -88,6 +88,20 @@ struct GemmArgs {
   long ld_fp8;
   const float* q_scale;  // device scalar
   float* amax_part;      // [number of blocks]: max|out| of each block (delayed scaling: reduced by the next step's first kernel), or null
+  // A operand gathered from a resident waveform (fc1 forward on the real-data path, rv_plan_step_frames): when
+  // a_hop != 0, `A` is the waveform as bf16 (cast once when it was uploaded) and row r of the operand is the frame
+  // A[f * a_hop : f * a_hop + K], f = a_idx ? a_idx[r] : a_first + r (AudioDataset.__getitem__, rawvae/dataset.py:
+  // 108-118); rows >= a_rows repeat row a_rows - 1 (their outputs are padding).  a_hop is a multiple of 8 and A is
+  // 16-byte aligned (16-byte LDS-DMA pieces), the buffer extends K elements past the last frame's start.  No cast /
+  // gather kernel runs and no fp32 frame is read; the framed bf16 matrix the fc1 weight gradient needs later is a
+  // by-product: the block with tile_n == kt % tiles_n copies K tile kt of its rows from LDS to a_copy (every block
+  // writes 32 KB instead of one kernel writing 8.4 MB).
+  const long long* a_idx;
+  long a_first, a_hop;
+  int a_rows;
+  bf16_t* a_copy;
+  long ld_copy;
+  long long* step_inc;   // EPI_BIAS_ACT_BF16: block 0 bumps the device step counter (the step's first kernel does)
   int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
                     // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
 };
@@ -126,6 +140,19 @@ struct StageOffsets {
         const int c32 = (p16 >> 1) ^ swz_mn<ROWS>(kr);
         off[i] = (unsigned)(kr * (int)ld + (c32 * 2 + (p16 & 1)) * 8);
       }
+    }
+  }
+
+  // K-major tile whose row r (tile-relative) starts at element offset rowoff(r) instead of r * ld
+  template <typename F>
+  __device__ __forceinline__ void init_rows(F rowoff, int wave, int lane) {
+    static_assert(KMAJ, "row gather: K-major operands");
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int t = wave + NW * i;
+      const int r = 8 * t + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      off[i] = (unsigned)(rowoff(r) + c * 8);
     }
   }
 
@@ -583,14 +610,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
-  sa.init(p.lda, wave, lane);
+  const bf16_t* Agr = Ag;
+  bool gathered = false;
+  if constexpr (A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) {
+    if (p.a_hop) {   // rows are frames of the resident bf16 waveform
+      gathered = true;
+      Agr = p.A + k0;
+      sa.init_rows([&](int r) {
+        long row = m0 + r;
+        row = row < p.a_rows ? row : p.a_rows - 1;
+        return (p.a_idx ? (long)p.a_idx[row] : p.a_first + row) * p.a_hop;
+      }, wave, lane);
+    }
+    if (p.step_inc && bid == 0 && tid == 0) *p.step_inc += 1;
+  }
+  if (!gathered) sa.init(p.lda, wave, lane);
   sb.init(p.ldb, wave, lane);
+  // by-product of the gathered operand: K tile kt of this block's rows, from its LDS slot to the framed matrix
+  auto copy_out = [&](int kt, const lds_char* slot_) {
+    if constexpr (A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) {
+      if (gathered && p.a_copy && kt % tiles_n == tile_n) {
+#pragma unroll
+        for (int i = 0; i < StageOffsets<BM, A_KMAJ, NW>::PER_WAVE; ++i) {
+          const int t = wave + NW * i;
+          const int r = 8 * t + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          const bf16x8 v_ = *(const __attribute__((address_space(3))) bf16x8*)(slot_ + t * 1024 + lane * 16);
+          *(bf16x8*)(p.a_copy + (m0 + r) * p.ld_copy + (long)kt * 64 + c * 8) = v_;
+        }
+      }
+    }
+  };
 
   const int nk = p.k_tiles;
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < nk) {
-      sa.stage(Ag + s * a_step, smem + s * STAGE, wave);
+      sa.stage(Agr + s * a_step, smem + s * STAGE, wave);
       sb.stage(Bg + s * b_step, smem + s * STAGE + A_BYTES, wave);
     }
   // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
@@ -643,7 +698,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     constexpr bool REFILL = decltype(refill_c)::value, NEXT = decltype(next_c)::value;
     if constexpr (REFILL) {
       lds_char* rf = smem + slot * STAGE;
-      sa.stage(Ag + (long)(kt + NSTAGE) * a_step, rf, wave);
+      sa.stage(Agr + (long)(kt + NSTAGE) * a_step, rf, wave);
       sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + A_BYTES, wave);
     }
     // fp8: this tile's first-half fragments are still needed by the MFMAs below, so the next tile's go to a
@@ -713,6 +768,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // steady state: a refill is issued every tile
   for (; kt + NSTAGE < nk; ++kt) {
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    copy_out(kt, smem + slot * STAGE);
     first_half(smem + slot * STAGE);
     hand_off(NSTAGE - 2);
     second_half(T_{}, T_{}, kt, slot, nslot);
@@ -721,12 +777,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // drain: tiles already staged, nothing left to prefetch
   for (; kt + 1 < nk; ++kt) {
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    copy_out(kt, smem + slot * STAGE);
     first_half(smem + slot * STAGE);
     hand_off(nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2);
     second_half(F_{}, T_{}, kt, slot, nslot);
     slot = nslot;
   }
   // last tile
+  copy_out(kt, smem + slot * STAGE);
   first_half(smem + slot * STAGE);
   second_half(F_{}, F_{}, kt, slot, slot);
   }

@@ -327,6 +327,30 @@ int rv_linear_fwd_ex(const void* x, long ldx, const void* w, long ldw, const flo
   return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
 }
 
+// fc1 forward on the real-data path: the A operand's rows are hop-strided frames of the resident bf16 waveform
+// (GemmArgs::a_hop), the framed bf16 matrix is written as a by-product, block 0 bumps the step counter.
+int rv_linear_fwd_frames(const void* audio_bf16, const long long* frame_index, long first_frame, long hop, long B,
+                         const void* w, long ldw, const float* bias, long Mp, long Np, long Kp, int act, void* y, long ldy,
+                         void* frames_bf16, long ld_frames, long long* step_counter, void* stream) {
+  RV_REQUIRE(audio_bf16 && w && y, RV_ERR_NULL, "rv_linear_fwd_frames: null operand");
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_frames: act %d", act);
+  RV_REQUIRE(hop > 0 && hop % 8 == 0 && ((uintptr_t)audio_bf16 & 15) == 0, RV_ERR_SHAPE,
+             "rv_linear_fwd_frames: hop %ld must be a multiple of 8 and the waveform 16-byte aligned (16-byte LDS-DMA pieces)", hop);
+  RV_REQUIRE(B >= 1 && B <= Mp && first_frame >= 0, RV_ERR_SHAPE, "rv_linear_fwd_frames: %ld frames for %ld rows", B, Mp);
+  RV_REQUIRE(!frames_bf16 || (ld_frames >= Kp && ld_frames % 8 == 0 && ((uintptr_t)frames_bf16 & 15) == 0), RV_ERR_SHAPE,
+             "rv_linear_fwd_frames: the framed copy needs 16-byte aligned rows of at least Kp elements");
+  GemmArgs a{};
+  a.A = (const bf16_t*)audio_bf16; a.lda = 8; a.B = (const bf16_t*)w; a.ldb = ldw;
+  a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
+  a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
+  a.a_idx = frame_index; a.a_first = first_frame; a.a_hop = hop; a.a_rows = (int)B;
+  a.a_copy = (bf16_t*)frames_bf16; a.ld_copy = ld_frames; a.step_inc = step_counter;
+  const int tile = choose_tile(Mp, Np, 1);
+  RV_REQUIRE(tile != 5 && tile != 7 && !(tile == 2 && g_n128_loop != 3), RV_ERR_UNSUPPORTED,
+             "rv_linear_fwd_frames: the gathered operand is implemented in the ring main loop only (tile %d)", tile);
+  return launch_tile<true, true, EPI_BIAS_ACT_BF16>(tile, a, Mp, Np, Kp, 1, (hipStream_t)stream);
+}
+
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y, long ldy, void* stream) {
   return rv_linear_fwd_fp8_ex(x_fp8, ldx, w_fp8, ldw, bias, dq, Mp, Np, Kp, act, y, ldy, nullptr, 0, stream);

@@ -82,6 +82,7 @@ struct rv_plan {
   // frame source of the step in flight (rv_plan_step_frames): `x` is then the resident waveform
   const long long* fr_idx = nullptr;
   long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
+  const void* fr_bf16 = nullptr;   // the waveform as bf16 (fc1's operand is gathered from it), or null
   int payload_bf16 = 0;
   void* grad_bf16 = nullptr;   // caller's flat bf16 payload arena (rv_plan_set_ddp_payload)
 
@@ -416,7 +417,12 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       n_amax = (int)((Bp / bm3) * (Hp / bn3));
       RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 4096 fc3 output tiles (got %d)", n_amax);
     }
-    if (p->fr_hop) {
+    if (p->fr_hop && p->fr_bf16 && !p->fp8 && p->fr_hop % 8 == 0 && ((uintptr_t)p->fr_bf16 & 15) == 0) {
+      // N1 as SURVEY 8f words it: fc1's A-tile loader reads frame i at i * hop of the resident bf16 waveform; the
+      // framed bf16 matrix dW1 needs later is a by-product of that launch; no cast / gather kernel
+      RV_TRY(rv_linear_fwd_frames(p->fr_bf16, p->fr_idx, p->fr_first, p->fr_hop, B, p->ws("W1b"), Sp, (float*)p->ws("b1p"),
+                                  Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, xb, Sp, p->b.step_counter, stream));
+    } else if (p->fr_hop) {
       // frames come straight from the resident waveform: waveform -> bf16 (and fp8) operand in one kernel
       RV_TRY(rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb, Bp, Sp, Sp,
                                    p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
@@ -645,14 +651,14 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   return RV_OK;
 }
 
-int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, long n_samples, const long long* frame_index,
-                        long first_frame, long hop, const float* eps, float* recon_out, float kl_beta, float lr,
-                        float grad_scale, int adam_from_flat, unsigned long long seed, void* stream) {
+int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, const void* audio_bf16, long n_samples,
+                        const long long* frame_index, long first_frame, long hop, const float* eps, float* recon_out,
+                        float kl_beta, float lr, float grad_scale, int adam_from_flat, unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_frames: plan not bound");
   RV_REQUIRE(audio && n_samples > 0 && hop > 0, RV_ERR_SHAPE, "rv_plan_step_frames: bad waveform / hop");
-  p->fr_idx = frame_index; p->fr_first = first_frame; p->fr_hop = hop; p->fr_nsamples = n_samples;
+  p->fr_idx = frame_index; p->fr_first = first_frame; p->fr_hop = hop; p->fr_nsamples = n_samples; p->fr_bf16 = audio_bf16;
   const int rc = rv_plan_step(p, phases, audio, eps, recon_out, kl_beta, lr, grad_scale, adam_from_flat, seed, stream);
-  p->fr_idx = nullptr; p->fr_first = 0; p->fr_hop = 0; p->fr_nsamples = 0;
+  p->fr_idx = nullptr; p->fr_first = 0; p->fr_hop = 0; p->fr_nsamples = 0; p->fr_bf16 = nullptr;
   return rc;
 }
 

@@ -95,6 +95,12 @@ class DeviceAudio:
         buf = np.zeros(self.padded, dtype=np.float32)
         buf[:len(audio_np)] = audio_np
         self.audio = torch.from_numpy(buf).to(self.device)
+        # The same waveform as bf16, cast ONCE here (round to nearest even: what the per-batch cast kernel did to every
+        # frame), followed by zeros: fc1's GEMM stages its operand tiles straight from it (rv_linear_fwd_frames), and a
+        # frame's padded tail (segment length rounded up to the tile grid) reads past the last sample.
+        slack = (self.segment_length + 127) // 128 * 128 + 8
+        self.audio_bf16 = torch.zeros(self.padded + slack, dtype=torch.bfloat16, device=self.device)
+        self.audio_bf16[:self.padded].copy_(self.audio)
 
     def __len__(self):
         return max(self.n_frames, 0)

@@ -227,7 +227,8 @@ class TrainEngine:
                     grad_scale=1.0, adam_from_flat=False, stream=None):
         """One step on B hop-strided frames of a `data.DeviceAudio` (waveform resident in HBM): `index` is an
         int64 device tensor of B frame numbers (one slice of the epoch's shuffle) or None for the B consecutive
-        frames from `first_frame`.  No framed copy of the batch is made (`rv_plan_step_frames`)."""
+        frames from `first_frame`.  The frames are read where the waveform lives (`rv_plan_step_frames`): fc1's operand
+        from its bf16 copy by the GEMM's own tile loader, the loss target from the fp32 waveform -- no cast kernel."""
         if audio.segment_length != self.S:
             raise _lib.RvError("step_frames: dataset frames are %d samples, the engine's %d" % (audio.segment_length, self.S))
         if index is not None and (index.dtype != torch.int64 or not index.is_contiguous() or index.numel() != self.B):
@@ -236,7 +237,9 @@ class TrainEngine:
             raise _lib.RvError("step_frames: eps must be contiguous fp32 [B, L]")
         if (phases & PHASE_FWD) and self._shadow_version != self._shared["version"]:
             self.refresh_shadows(stream)
-        lib().rv_plan_step_frames(self._plan, int(phases), ptr(audio.audio), audio.padded, ptr(index), int(first_frame),
+        # the waveform's bf16 copy (data.DeviceAudio.audio_bf16) lets fc1's tile loader read the frames in place: no cast kernel
+        a16 = getattr(audio, "audio_bf16", None)
+        lib().rv_plan_step_frames(self._plan, int(phases), ptr(audio.audio), ptr(a16), audio.padded, ptr(index), int(first_frame),
                                   audio.hop_size, ptr(eps), ptr(recon_out), self.kl_beta, self.lr, float(grad_scale),
                                   int(bool(adam_from_flat)), self.seed, stream_ptr(stream))
         if phases & PHASE_FWD:

@@ -182,14 +182,18 @@ def test_device_framing_vs_reference_dataset_fixtures():
     assert str(ei.value) == ds["bad_segment_raises"]
 
 
+@pytest.mark.parametrize("shape", [(512, 384, 12, 128), (256, 1024, 64, 64), (500, 256, 8, 100)])
 @pytest.mark.parametrize("fp8", [False, True])
-def test_step_on_resident_waveform_equals_step_on_gathered_frames(fp8):
-    """N1 as SURVEY 8f specifies it: `step_frames` (fc1's operand cast straight from the waveform, fc4's loss
-    epilogue reading its target there) gives bit for bit what gather -> `step` gives, for a shuffled index with the
-    zero-padded tail frames in it, a ragged batch, and consecutive frames."""
+def test_step_on_resident_waveform_equals_step_on_gathered_frames(fp8, shape):
+    """N1 as SURVEY 8f specifies it: `step_frames` (fc1's GEMM tile loader reading frame i at i * hop of the resident
+    bf16 waveform -- no cast kernel --, fc4's loss epilogue reading its fp32 target there) gives bit for bit what
+    gather -> `step` gives, for a shuffled index with the zero-padded tail frames in it, a ragged batch, and
+    consecutive frames.  Shapes: hop a multiple of 8 (the in-place path; with fp8 the cast kernel that also quantises),
+    a hidden width that gets the 256 x 128 tile, and hop = 100 with S = 500 (16-byte pieces impossible: cast-kernel
+    fallback, padded columns)."""
     from rawaudiovae_kelsey_amd import data as D
     from rawaudiovae_kelsey_amd.engine import TrainEngine
-    S, H, L, hop = 512, 384, 12, 128
+    S, H, L, hop = shape
     wave = np.random.default_rng(5).uniform(-1, 1, 40000).astype(np.float32)
     d = D.DeviceAudio(wave, S, hop)
     n = len(d)
