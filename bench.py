@@ -51,13 +51,8 @@ def parse():
                     help="(N=1) ONE hipGraph holding the steps of the whole batch pool (8 steps per replay), so the gap "
                          "between replays is paid once per 8 steps; steps beyond a multiple of 8 run eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
-    ap.add_argument("--serial", action="store_true", help="(default) whole step on one stream")
     ap.add_argument("--latent-fused", type=int, default=None, choices=[0, 1],
-                    help="heads + reparam + fc3 of the forward as one launch (1: experiment, measured slower) or three (0, default)")
-    ap.add_argument("--adam-split", type=int, default=None,
-                    help="permille of fc4.weight rows whose Adam update rides in the fc1 wgrad launch (default: library's)")
-    ap.add_argument("--sched", type=int, default=0,
-                    help="schedule (rv_plan_set_concurrency): 0 default, 3 round-1 single stream, 1/2 two-stream experiments")
+                    help="heads + reparam + fc3 of the forward as one row-local launch (1, default) or three launches (0)")
     ap.add_argument("--fp8", action="store_true",
                     help="ignored (kept for old command lines): the headline is bf16; the fp8 forward is timed as the side line `alt_fp8`")
     ap.add_argument("--no-alts", action="store_true",
@@ -65,9 +60,6 @@ def parse():
                          "`alt_fp32_slabs`; they are timed after the headline at N=1 and never replace it")
     ap.add_argument("--slab-dtype", default=None, choices=["fp32", "fp16"],
                     help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
-    ap.add_argument("--n128-loop", type=int, default=0,
-                    help="experiment: main loop of the 256x128 GEMM tile (3 one-barrier ring = default, 9 ping-pong)")
-    ap.add_argument("--gemm-hook", type=int, default=0, help="experiment: rv_gemm_force_tile(N) before anything runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--repeats", type=int, default=0,
@@ -95,24 +87,21 @@ def time_dominant_kernel(eng, reps=50):
     half = eng.slab_dtype == "fp16"      # the slab element type the step itself uses
     us = torch.empty(splits * (Sp // 32) * (Hp // 32), dtype=torch.float32, device="cuda")
     st = stream_ptr()
-    e0, e1 = C.c_void_p(), C.c_void_p()
-    Lb.rv_event_create(C.byref(e0))
-    Lb.rv_event_create(C.byref(e1))
+    ts = torch.cuda.current_stream()      # the stream the launches below go to (`st` is its handle)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
 
     def launch():
-        Lb.rv_linear_dgrad_wgrad_ex(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, None, 0, Bp, Hp, Sp,
+        Lb.rv_linear_dgrad_wgrad_ex(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, Bp, Hp, Sp,
                                     dP3.data_ptr(), Hp, cs.data_ptr(), dW4.data_ptr(), Hp, splits, int(half),
                                     us.data_ptr() if half else None, st)
     for _ in range(5):
         launch()
-    Lb.rv_event_record(e0, st)
+    e0.record(ts)
     for _ in range(reps):
         launch()
-    Lb.rv_event_record(e1, st)
-    ms = C.c_float()
-    Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
-    Lb.rv_event_destroy(e0)
-    Lb.rv_event_destroy(e1)
+    e1.record(ts)
+    e1.synchronize()
+    ms = C.c_float(e0.elapsed_time(e1))
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
@@ -151,9 +140,7 @@ def time_deep_c4(dev, comp, steps, warmup):
         Bp, Hp = eng.Bp, eng.Hp
         wname = "dec.%d.weight" % (depth - 1)
         st = comp.cuda_stream
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        Lb.rv_event_create(C.byref(e0))
-        Lb.rv_event_create(C.byref(e1))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events on `comp`
 
         def launch():
             Lb.rv_linear_dgrad_wgrad(ptr(eng.d_dec[depth - 1]), Hp, ptr(eng.shadow[wname]), Hp, ptr(eng.dec_act[depth - 2]), Hp,
@@ -161,14 +148,12 @@ def time_deep_c4(dev, comp, steps, warmup):
                                      ptr(eng.slabs[wname]), Hp, eng.splits[wname], st)
         for _ in range(5):
             launch()
-        Lb.rv_event_record(e0, st)
+        e0.record(comp)
         for _ in range(30):
             launch()
-        Lb.rv_event_record(e1, st)
-        ms = C.c_float()
-        Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
-        Lb.rv_event_destroy(e0)
-        Lb.rv_event_destroy(e1)
+        e1.record(comp)
+        e1.synchronize()
+        ms = C.c_float(e0.elapsed_time(e1))
     kern_us = ms.value / 30 * 1e3
     w = Sd * Hd + (depth - 1) * Hd * Hd + 2 * Hd * Ld + Ld * Hd + (depth - 1) * Hd * Hd + Hd * Sd
     fpf = 6 * w - 2 * Sd * Hd            # fwd + dgrad + wgrad per weight; the first layer has no dgrad
@@ -200,7 +185,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from oracle.inputs import flops_per_frame, make_frames, make_params
+    from rawaudiovae_kelsey_amd.synth import flops_per_frame, make_frames, make_params
     from rawaudiovae_kelsey_amd import engine as E
 
     # one process per GPU; the modulo only matters for the 2-rank plumbing rehearsal on a one-GPU box
@@ -214,18 +199,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.n128_loop:
-        from rawaudiovae_kelsey_amd._lib import lib as _rvlib
-        _rvlib().rv_gemm_force_tile(100 + args.n128_loop)
-    if args.gemm_hook:
-        from rawaudiovae_kelsey_amd._lib import lib as _rvlib
-        _rvlib().rv_gemm_force_tile(args.gemm_hook)
     ekw = {"slab_dtype": args.slab_dtype} if args.slab_dtype else {}
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **ekw)
     eng.load_params(make_params(S, H, L, 0))
-    eng.set_concurrency(0 if args.serial else args.sched)
-    if args.adam_split is not None:
-        eng.set_adam_split(args.adam_split)
     if args.latent_fused is not None:
         eng.set_latent_fused(args.latent_fused)
     pool = [torch.from_numpy(make_frames(B, S, 1234 + 100 * rank + i)).to(dev) for i in range(POOL)]
@@ -661,7 +637,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph (one graph of %d steps)" % POOL if pool_graph is not None else
                                  "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
-                       "schedule": int(0 if args.serial else args.sched), "wgrad_slabs": eng.slab_dtype,
+                       "wgrad_slabs": eng.slab_dtype,
                        **({"ddp_mode": "sharded" if getattr(runner, "sharded", False) else "allreduce",
                            "shard_gather": getattr(eng, "shard_gather", None)} if runner is not None else {}),
                        "grad_allreduce": ddp_mode},

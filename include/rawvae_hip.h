@@ -14,8 +14,8 @@
  *     device memory at all -- only the opaque rv_plan / rv_graph host objects and a
  *     plan's internal streams and events.
  *   - one process per GPU, one host thread calling in at a time: the per-kernel
- *     "dynamic LDS attribute set" latches and the rv_gemm_force_tile test hook are
- *     plain process-wide statics (not per device, not thread-safe).
+ *     "dynamic LDS attribute set" latches (and the test hook of
+ *     rawvae_hip_diag.h) are plain process-wide statics (not per device, not thread-safe).
  *   - every function returns 0 on success or a negative RV_ERR_* code;
  *     rv_last_error() gives the message.  Nothing throws, aborts or synchronises
  *     unless its name ends in _sync; all launches are safe under stream capture.
@@ -53,14 +53,9 @@ int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, lo
  * rv_gemm_pick: recommended split-K count (<= max_splits, power of two) and the block tile
  * (bm x bn) for a padded Mp x Np x Kp GEMM.  rv_gemm_tile: the tile the library uses when a
  * GEMM is launched with a given split count; per-row-tile outputs (column-sum partials,
- * MSE partials) then have Mp/bm row tiles and Np/bn column tiles.
- * rv_gemm_force_tile: test hook, pins the tile configuration (0: 64x64, 1: 128x128,
- * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves, 4: 128x128 with 8 waves, 5: 256x256 with the
- * two-slot ring loop, 7: 256x256 with the ping-pong loop) wherever it divides the extents;
- * -1 = auto.  108 / 102 select the ping-pong (default) / ring main loop of the paired kernel. */
+ * MSE partials) then have Mp/bm row tiles and Np/bn column tiles. */
 int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
 int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
-int rv_gemm_force_tile(int tile);
 
 /* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (leading dim ld_dst).
  * Replaces the implicit fp32 operand read of F.linear (model.py:20) for frames and
@@ -143,9 +138,6 @@ int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16
  * reads.  Autograd of F.linear w.r.t. weight, train.py:191. */
 int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp,
                     long Np, long Kp, int splits, float* dw_f32_slabs, long lddw, void* stream);
-/* The same on a named block tile instead of the picker's choice (extents must be multiples of it; `splits`
- * must divide Kp/64).  RV_TILE_256x256 runs the ping-pong main loop when Kp/64/splits is even. */
-enum { RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x256 = 7 };
 /* Split-K slab element type of a weight gradient: fp32, or block-floating-point fp16 -- fp16(partial * 2^e) with
  * one exponent e per wave tile of one slab, taken from that tile's own largest magnitude, so gradients of ANY
  * magnitude keep fp16's 11 significant bits relative to their tile (same element strides as fp32 slabs).  The GEMM
@@ -154,11 +146,12 @@ enum { RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x
  * in rv_adam_multi / rv_grad_finalize, which are told by rv_param_desc.grad_half / grad_unscale.  Halves the bytes
  * the GEMM writes and the optimizer reads back. */
 enum { RV_SLAB_F32 = 0, RV_SLAB_F16 = 1 };
-int rv_linear_wgrad_tile(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np,
-                         long Kp, int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
-                         void* stream);
+/* rv_linear_wgrad with every option: a named block tile instead of the picker's choice (extents must be multiples of
+ * it; `splits` must divide Kp/64; RV_TILE_256x256 runs the ping-pong main loop when Kp/64/splits is even) and the
+ * slab element type. */
+enum { RV_TILE_AUTO = -1, RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x256 = 7 };
 int rv_linear_wgrad_ex(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
-                       int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale, void* stream);
+                       int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale, void* stream);
 
 /* Reparameterisation forward, model.py:23-26, fused with the KL half of
  * loss_function (model.py:45):
@@ -188,13 +181,15 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
 
 /* The latent-sized forward in ONE launch for a padded latent width of 64 (L <= 64; BASELINE's C2): heads GEMM
  * (model.py:21) + reparameterisation and KL partials (model.py:23-26,45) + fc3 with bias and ReLU (model.py:29),
- * 16 batch rows per workgroup, all three steps row-local, MFMA operands loaded straight from global memory.
- * Replaces rv_heads_reparam_fwd followed by rv_linear_fwd(fc3): same outputs (mulv [Bp][128], z bf16 [Bp][64],
- * kl_partial[Bp / 16], eps_out, h3 bf16 [Bp][Hp]); mu / logvar differ from the split-K route by fp32 summation
- * order only; eps draws and the KL partial layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a
- * padded hidden width that is not a multiple of 512.  Correct and tested, but SLOWER than the three launches it
- * replaces (45 vs 21 us at C2: loads scheduled by the compiler stream 21-30 GB/s per CU where the GEMM kernels'
- * LDS-DMA ring streams 60), so nothing in the library calls it unless rv_plan_set_latent_fused(plan, 1). */
+ * 16 batch rows per workgroup, all three steps row-local.  Every workgroup streams the whole head weight and W3
+ * through its CU (832 KB at C2, the L2 -> LDS port's ~60 GB/s sets the time): the K dimension of the heads GEMM and
+ * the columns of fc3 are cut over the 8 waves, each wave running private LDS-DMA rings with counted vmcnt, no
+ * workgroup barrier in the streaming loops (csrc/latent.hip).  Replaces rv_heads_reparam_fwd followed by
+ * rv_linear_fwd(fc3): same outputs (mulv [Bp][128], z bf16 [Bp][64], kl_partial[Bp / 16], eps_out, h3 bf16
+ * [Bp][Hp]); mu / logvar differ from the split-K route by fp32 summation order only; eps draws and the KL partial
+ * layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a padded hidden width that is not a multiple
+ * of 512 up to 2048.  18.8 us against 21-22 us for the three launches at C2 (profiles/r03_*): the training plan's
+ * default where it applies (rv_plan_set_latent_fused). */
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
@@ -208,16 +203,11 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
  * loss_out[1] = mse term, loss_out[2] = KL term (pass NULL partials to skip).  When
  * step_counter != NULL and ring > 0, loss_out is a ring of [ring][4] floats and the
  * slot written is (*step_counter - 1) % ring, so graph replays log every step. */
-int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
-                   const float* mulv, const float* eps, float kl_beta, void* dmulv_bf16,
-                   float* dbh_partial, const float* mse_partial, int n_mse,
-                   const float* kl_partial, int n_kl, float* loss_out,
-                   const long long* step_counter, int ring, void* stream);
-/* The same with gradients that arrive from outside added in (exact [B, L] fp32, either may be NULL):
+/* Gradients that arrive from outside are added in (exact [B, L] fp32, either may be NULL):
  * dmu += dmu_ext, dlv += dlv_ext -- what autograd hands the backward of reparameterize when mu / logvar also feed
  * a loss term directly (the KL half of loss_function, model.py:45).  Pass kl_beta = 0 when the KL gradient is
  * already inside dmu_ext / dlv_ext. */
-int rv_reparam_bwd_ext(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
+int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
                        const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
                        const float* dlv_ext, void* dmulv_bf16, float* dbh_partial, const float* mse_partial,
                        int n_mse, const float* kl_partial, int n_kl, float* loss_out,
@@ -309,8 +299,7 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, vo
 /* dW = dY^T X on 256x256 tiles (as rv_linear_wgrad_tile with RV_TILE_256x256) in a launch that ALSO runs the
  * fused Adam update (rv_adam_multi) of the `n_desc` tensors in `descs` -- tensors whose gradients earlier
  * launches completed, never the one this GEMM produces -- on `n_adam_blocks` extra 512-thread blocks that take
- * the CUs the GEMM's tiles * splits blocks leave idle.  rv_wgrad_adam_fits says whether the extents tile. */
-int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);
+ * the CUs the GEMM's tiles * splits blocks leave idle (extents must tile by 256 x 256 x 64). */
 int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
                          int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
                          const rv_param_desc* descs, int n_desc,
@@ -365,29 +354,16 @@ int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* d
 int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long rows_p,
                         long cols_p, long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state,
                         const float* amax_part, int n_amax, long long* step_counter, void* stream);
-/* rv_linear_fwd that can also store its output as fp8(y * *q_scale) (the next layer's fp8 operand) and write
- * max|y| of every block to amax_part[block] (rv_gemm_tile gives the block count: (Mp/bm)*(Np/bn)), from which the
- * next step derives its scale (delayed scaling). */
-int rv_linear_fwd_q8(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp, long Np,
-                     long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
-                     float* amax_part, void* stream);
 /* rv_linear_fwd / rv_decode_out_loss_fwd on fp8 operands. */
-/* The general forms: every optional output of a bias/ReLU forward GEMM (NULL = not wanted).  `maskbits`:
- * [Mp][ld_maskbits >= Np/8] bytes, bit e of byte (r, c/8) = (y(r, c+e) > 0), the ReLU mask a later
- * rv_linear_dgrad_wgrad_mb reads instead of the 16x larger bf16 activation. */
+/* rv_linear_fwd with every optional output of a bias/ReLU forward GEMM (NULL = not wanted): the output also as
+ * fp8(y * *q_scale) (the next layer's fp8 operand) and max|y| of every block in amax_part[block] (rv_gemm_tile gives
+ * the block count: (Mp/bm)*(Np/bn)), from which the next step derives its scale (delayed scaling). */
 int rv_linear_fwd_ex(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp, long Np,
                      long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
-                     float* amax_part, void* maskbits, long ld_maskbits, void* stream);
-int rv_linear_fwd_fp8_ex(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
-                         long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* maskbits, long ld_maskbits,
-                         void* stream);
-/* rv_linear_dgrad_wgrad with the ReLU mask given as bits (x is still the weight gradient's operand). */
-int rv_linear_dgrad_wgrad_mb(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
-                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
-                             float* colsum_partial, float* dw_slabs, long lddw, int splits, void* stream);
-/* rv_linear_dgrad_wgrad with every option: mask as bits (or NULL) and the slab element type. */
+                     float* amax_part, void* stream);
+/* rv_linear_dgrad_wgrad with the slab element type of the weight gradient (RV_SLAB_*). */
 int rv_linear_dgrad_wgrad_ex(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
-                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
+                             long Mp, long Np, long Kp, void* dx_bf16, long lddx,
                              float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype,
                              float* slab_unscale, void* stream);
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
@@ -446,26 +422,9 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
 void rv_plan_destroy(rv_plan*);
 long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
-/* Schedule of the full local step (FWD|BWD_A|BWD_B|ADAM; needs a non-default `stream` when non-zero).
- * 0 (default): every kernel on the caller's stream; fc4's dgrad and wgrad share one launch, and the launch of
- *    the fc1 weight gradient also carries the Adam update of fc21/fc22/fc3/fc4 (rv_linear_wgrad_adam) when the
- *    extents tile by 256 -- otherwise as 3.
- * 3: every kernel on the caller's stream, Adam as one launch of its own at the end (the round-1 schedule).
- * 2: the backward's dependency chain (dP3 -> dz -> dmu/dlogvar -> dP1 -> dW1 -> Adam) runs alone on the
- *    caller's stream; dW4 and the fc4 half of Adam, which nothing in the step waits for, run on an internal
- *    side stream (one fork after dP3, one join at the end of the call).
- * 1: only the fc3/fc4 half of Adam is forked, beside the fc1 weight-gradient GEMM (round-1 experiment; its
- *    join sits on the critical path and it measures slower than 0 at C2).
- * rv_plan_step_ddp refuses to run while a non-zero schedule is set (see there). */
-int rv_plan_set_concurrency(rv_plan*, int enable);
-/* Schedule 0 only: the first `permille`/1000 of fc4.weight's rows are updated by the optimizer blocks that ride in
- * the fc1 weight-gradient launch, the remaining rows by the step's last (optimizer-only) launch; above 1000 (up to
- * 2000) all of fc4 and the heads' tensors (fc21, fc22) ride as well.  Same arithmetic either way; the value only
- * balances the two launches (default 1000 measured best: profiles/r02_adam_split_sweep.txt). */
-int rv_plan_set_adam_split(rv_plan*, int permille);
-/* 0 (default): heads GEMM, reparameterisation and fc3 of the forward are three launches (rv_heads_reparam_fwd + fc3);
- * 1: one launch (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 and the
- * fp8 path off -- an experiment kept for the record: 45 us against 21 us at C2 (see rv_latent_fwd). */
+/* 1 (default): heads GEMM, reparameterisation and fc3 of the forward are ONE launch (rv_latent_fwd) when the padded
+ * latent width is 64, the padded hidden width a multiple of 512 up to 2048 and the fp8 path off; 0, or any other
+ * shape: three launches (rv_heads_reparam_fwd + fc3). */
 int rv_plan_set_latent_fused(rv_plan*, int enable);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and
@@ -581,12 +540,6 @@ int rv_graph_begin(void* stream);
 int rv_graph_end(void* stream, rv_graph** out);
 int rv_graph_launch(rv_graph*, void* stream);
 void rv_graph_destroy(rv_graph*);
-
-/* Timing helper for bench.py: HIP events on the caller's stream. */
-int rv_event_create(void** ev);
-int rv_event_record(void* ev, void* stream);
-int rv_event_elapsed_ms_sync(void* ev_start, void* ev_stop, float* ms);
-void rv_event_destroy(void* ev);
 
 #ifdef __cplusplus
 }

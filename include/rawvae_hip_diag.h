@@ -1,0 +1,16 @@
+/* Test hook of librawvae_hip.so -- NOT part of the product ABI (nothing in rawaudiovae_kelsey_amd/ calls it; the GPU
+ * tests use it to run every block-tile configuration on small shapes).  Process-wide, not thread-safe. */
+#ifndef RAWVAE_HIP_DIAG_H
+#define RAWVAE_HIP_DIAG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Pin the block tile every later GEMM launch uses wherever it divides the extents (0: 64x64, 1: 128x128 with 4 waves,
+ * 2: 256x128 with 8 waves, 3: 256x128 with 4 waves, 4: 128x128 with 8 waves, 5: 256x256 with the two-slot ring loop,
+ * 7: 256x256 with the ping-pong loop); -1 = the picker's choice.  108 / 102 select the ping-pong (default) / ring
+ * main loop of the paired 256x256 launch (the ring is what odd K-tile counts get). */
+int rv_gemm_force_tile(int tile);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -49,7 +49,7 @@ _SIGS = {
     "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
     "rv_gemm_pick": (c_int, [c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 3),
     "rv_gemm_tile": (c_int, [c_long, c_long, c_int] + [C.POINTER(c_int)] * 2),
-    "rv_gemm_force_tile": (c_int, [c_int]),
+    "rv_gemm_force_tile": (c_int, [c_int]),   # test hook (include/rawvae_hip_diag.h), not part of the product ABI
     "rv_dgrad_wgrad_pick": (c_int, [c_long, c_long, c_long] + [C.POINTER(c_int)] * 3),
     "rv_linear_dgrad_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
                                       c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
@@ -60,14 +60,8 @@ _SIGS = {
     "rv_cast_pad_fp8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_cast_pad_bf16_q8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long,
                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "rv_linear_fwd_q8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
-                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_linear_fwd_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
-                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
-    "rv_linear_fwd_fp8_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
-                                     c_void_p, c_long, c_void_p, c_long, c_void_p]),
-    "rv_linear_dgrad_wgrad_mb": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
-                                         c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_linear_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
                                   c_void_p, c_long, c_void_p]),
     "rv_decode_out_loss_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
@@ -93,17 +87,14 @@ _SIGS = {
                                 c_int, c_void_p]),
     "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
                                 c_void_p, c_long, c_void_p]),
-    "rv_linear_wgrad_tile": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int,
-                                     c_void_p, c_long, c_int, c_void_p, c_void_p]),
-    "rv_linear_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
+    "rv_linear_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
                                    c_int, c_void_p, c_void_p]),
-    "rv_linear_dgrad_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+    "rv_linear_dgrad_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
                                          c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int,
                                          c_void_p, c_void_p]),
     "rv_plan_set_slab_dtype": (c_int, [c_void_p, c_int]),
     "rv_linear_fwd_frames": (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                                      c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
-    "rv_wgrad_adam_fits": (c_int, [c_long, c_long, c_long, c_int]),
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
                                      c_int, c_void_p, C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_void_p, c_int, c_void_p]),
@@ -115,9 +106,6 @@ _SIGS = {
                               c_void_p, c_long, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
-                               c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rv_loss_fused_workspace_bytes": (c_long, []),
     "rv_loss_fused": (c_int, [c_void_p] * 4 + [c_long, c_long, c_long, c_float] + [c_void_p] * 6),
     "rv_reparameterize": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_u64, c_u64,
@@ -133,11 +121,9 @@ _SIGS = {
     "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
-    "rv_plan_set_concurrency": (c_int, [c_void_p, c_int]),
-    "rv_plan_set_adam_split": (c_int, [c_void_p, c_int]),
     "rv_plan_set_latent_fused": (c_int, [c_void_p, c_int]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
-    "rv_reparam_bwd_ext": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
+    "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                    c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rv_plan_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
@@ -170,10 +156,6 @@ _SIGS = {
     "rv_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "rv_graph_launch": (c_int, [c_void_p, c_void_p]),
     "rv_graph_destroy": (None, [c_void_p]),
-    "rv_event_create": (c_int, [C.POINTER(c_void_p)]),
-    "rv_event_record": (c_int, [c_void_p, c_void_p]),
-    "rv_event_elapsed_ms_sync": (c_int, [c_void_p, c_void_p, C.POINTER(c_float)]),
-    "rv_event_destroy": (None, [c_void_p]),
 }
 
 EXPORTED = tuple(_SIGS)
@@ -201,7 +183,7 @@ class _Lib:
             fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-            checked = res is c_int and name not in ("rv_version", "rv_wgrad_adam_fits")
+            checked = res is c_int and name != "rv_version"
             setattr(self, name, _wrap(fn, name) if checked else fn)
 
 

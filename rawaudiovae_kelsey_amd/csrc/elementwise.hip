@@ -723,15 +723,6 @@ int rv_reparam_fwd(const float* slabs, int splits, long Bp, long Lp, long B, lon
 }
 
 int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
-                   const float* mulv, const float* eps, float kl_beta, void* dmulv,
-                   float* dbh_partial, const float* mse_partial, int n_mse,
-                   const float* kl_partial, int n_kl, float* loss_out,
-                   const long long* step_counter, int ring, void* stream) {
-  return rv_reparam_bwd_ext(dz_slabs, splits, Bp, Lp, B, L, S, mulv, eps, kl_beta, nullptr, nullptr, dmulv, dbh_partial,
-                            mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring, stream);
-}
-
-int rv_reparam_bwd_ext(const float* dz_slabs, int splits, long Bp, long Lp, long B, long L, long S,
                        const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
                        const float* dlv_ext, void* dmulv, float* dbh_partial, const float* mse_partial, int n_mse,
                        const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,

@@ -62,13 +62,6 @@ struct GemmArgs {
   const float* bias;  // [N] (padded), may be null
   const bf16_t* mask;
   long ld_mask;
-  // ReLU masks as bits: [rows][ld] bytes, bit e of byte (r, c/8) = (relu output (r, c + e) > 0).  A producing
-  // EPI_BIAS_ACT_BF16 GEMM writes them (out_maskbits); a consuming EPI_MASK_BF16 GEMM reads them instead of the
-  // 16x larger bf16 activation (`maskbits` wins over `mask`).
-  const unsigned char* maskbits;
-  long ld_maskbits;
-  unsigned char* out_maskbits;
-  long ld_out_maskbits;
   const float* x;  // EPI_TANH_LOSS target frames, exact [M_valid, N_valid]
   long ld_x;
   // ... or, when x_hop != 0, hop-strided frames of a waveform: `x` is the waveform (x_nsamples samples, zero past
@@ -102,8 +95,6 @@ struct GemmArgs {
   bf16_t* a_copy;
   long ld_copy;
   long long* step_inc;   // EPI_BIAS_ACT_BF16: block 0 bumps the device step counter (the step's first kernel does)
-  int dbg;          // diagnostics only (tools/gemm_decomp.py): 1 = epilogue without global memory traffic,
-                    // 2 = no epilogue at all, 4 = no main loop; results are wrong whenever it is non-zero
 };
 
 template <int ROWS>
@@ -196,13 +187,6 @@ __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int k
 // s_nop covers the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside an asm.
 __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-// 16-byte epilogue store, optionally non-temporal (streamed past the caches: for outputs nobody reads soon)
-template <typename V>
-__device__ __forceinline__ void st16(V* dst, const V v, const bool nt) {
-  if (nt) __builtin_nontemporal_store(v, dst);
-  else *dst = v;
 }
 
 // One accumulate step on a pair of 16-byte fragments.  bf16: 16x16x32.  fp8: the two fragments of a staged tile
@@ -385,107 +369,6 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same ping-pong structure for the 256 x 128 tile (NSTAGE == 9; 8 waves as 2 x 4 of 128 x 32): the tile
-// every full-chip GEMM of the C2 step gets (256 of them), where the one-barrier ring loop below is bound by
-// how fast one CU can fill its LDS and loses a third of its time on MN-major (transposing) operands.
-// Two phases per 64-deep K tile, one 64 x 32 half of the wave's output per phase (16 MFMAs each):
-//      phase 0: read B + A(m0)   MFMA (m0)   stage A-half 0 and B of tile kt+2   wait: A-half 1 of tile kt landed
-//      phase 1: read A(m1)       MFMA (m1)   stage A-half 1 of tile kt+2         wait: A-half 0 and B of tile kt+1 landed
-// LDS: 3 buffers x {A half 0, A half 1, B} x 16 KiB (tile kt lives in buffer kt % 3), so the LDS-DMA runs two
-// K tiles (four phases) ahead.  Hazards, as in the 256 x 256 loop: a piece is restaged two phases after its last
-// fragment read (A-half 0 / B of tile kt-1: read in its phase 0, restaged in phase 0 of tile kt; A-half 1: phase 1
-// -> phase 1) and read one phase after the counted vmcnt that retires its LDS-DMA; the two wave rows run one
-// barrier apart.  Each piece is 2 LDS-DMA instructions per wave, issued in the order
-// ... A1(kt) | A0(kt+1) B(kt+1) | A1(kt+1) | A0(kt+2) B(kt+2) | A1(kt+2) ..., which fixes the vmcnt counts below.
-template <bool A_KMAJ, bool B_KMAJ>
-__device__ __forceinline__ void mainloop_pingpong_n128(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
-                                                       const long lda, const long ldb, const int nk, lds_char* smem,
-                                                       const int wave, const int lane, f32x4 (&acc)[8][2]) {
-  constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k piece
-  constexpr int BUF = 3 * HALF;          // A0 A1 B
-  const int wr = wave >> 2, wc = wave & 3;
-  StageOffsets<128, A_KMAJ, 8> sa;
-  StageOffsets<128, B_KMAJ, 8> sb;
-  sa.init(lda, wave, lane);
-  sb.init(ldb, wave, lane);
-  const long a_step = A_KMAJ ? 64 : 64 * lda, b_step = B_KMAJ ? 64 : 64 * ldb;
-  const long a_half = A_KMAJ ? 128 * lda : 128;
-  auto buf_of = [&](int t) { return smem + (t % 3) * BUF; };
-  auto stage_a = [&](int h, int t) {
-    if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, buf_of(t) + h * HALF, wave);
-  };
-  auto stage_b = [&](int t) {
-    if (t < nk) sb.stage(Bg + (long)t * b_step, buf_of(t) + 2 * HALF, wave);
-  };
-  bf16x8 a[4][2], b[2][2];
-  auto rd_a = [&](const lds_char* buf, int mq) {
-    const lds_char* base = buf + wr * HALF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) a[i][kk] = load_frag<128, A_KMAJ>(base, mq * 64 + i * 16, kk, lane);
-  };
-  auto rd_b = [&](const lds_char* buf) {
-    const lds_char* base = buf + 2 * HALF;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) b[j][kk] = load_frag<128, B_KMAJ>(base, wc * 32 + j * 16, kk, lane);
-  };
-  auto mma = [&](auto mq_c) {
-    constexpr int MQ = decltype(mq_c)::value;
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[MQ * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[MQ * 4 + i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-
-  // prologue: tiles 0 and 1 staged in the steady-state order; A-half 0 and B of tile 0 landed
-  stage_a(0, 0); stage_b(0); stage_a(1, 0);
-  stage_a(0, 1); stage_b(1); stage_a(1, 1);
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const lds_char* cur = buf_of(kt);
-    // phase 0
-    rd_b(cur);
-    rd_a(cur, 0);
-    stage_a(0, kt + 2);
-    stage_b(kt + 2);
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    mma(I0{});
-    // phase 1
-    rd_a(cur, 1);
-    stage_a(1, kt + 2);
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    mma(I1{});
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 // Block tile BM x BN computed by a WGM x WGN grid of waves (wave tile BM/WGM x BN/WGN).
 //
 // NSTAGE-deep LDS ring, software-pipelined so it also runs at one wave per SIMD:
@@ -507,10 +390,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
   constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
   constexpr bool PINGPONG = NSTAGE == 8;    // 256x256 ping-pong main loop (2 LDS buffers)
-  constexpr bool PINGPONG_N128 = NSTAGE == 9;  // 256x128 ping-pong main loop (3 LDS buffers)
-  static_assert(PINGPONG || PINGPONG_N128 || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
+  static_assert(PINGPONG || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
   static_assert(!PINGPONG || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4), "ping-pong loop: 256x256, 2x4 waves");
-  static_assert(!PINGPONG_N128 || (BM == 256 && BN == 128 && WGM == 2 && WGN == 4), "ping-pong loop: 256x128, 2x4 waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,7 +444,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // the round trip to memory is over long before the epilogue, which used to start with it (3.7 us of the fc4
   // forward, profiles/r02_gemm_decomp.txt).  Costs CH x 8 (target) / CH x 4 (mask) VGPRs across the loop.
   // (The 256 x 256 ping-pong kernels have no registers to spare: their mask goes through LDS, below.)
-  constexpr bool PF_ROOM = !PINGPONG && !PINGPONG_N128 && MI * NI <= 16;   // accumulators take at most 64 VGPRs
+  constexpr bool PF_ROOM = !PINGPONG && MI * NI <= 16;   // accumulators take at most 64 VGPRs
   constexpr bool PF_X = EPI == EPI_TANH_LOSS && PF_ROOM;
   constexpr bool PF_MASK = EPI == EPI_MASK_BF16 && PF_ROOM;
   float xpf[CH][8];
@@ -583,7 +464,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
   }
   if constexpr (PF_MASK) {
-    if (p.mask && !p.maskbits) {
+    if (p.mask) {
       pf_on = true;
 #pragma unroll
       for (int it = 0; it < CH; ++it)
@@ -601,12 +482,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (p.dbg & 4) {
-    // diagnostic: epilogue only
-  } else if constexpr (PINGPONG) {
+  if constexpr (PINGPONG) {
     mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
-  } else if constexpr (PINGPONG_N128) {
-    mainloop_pingpong_n128<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
@@ -789,15 +666,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   second_half(F_{}, F_{}, kt, slot, slot);
   }
   __syncthreads();  // every wave is done with the ring before the epilogue's reductions reuse LDS
-  if (p.dbg & 2) {  // diagnostic: main loop only (the accumulators stay live)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
-    return;
-  }
-  const bool mem = !(p.dbg & 1);  // diagnostic: epilogue arithmetic without global traffic
-
   // ------------------------------ epilogue ------------------------------
   // The MFMAs are issued with the operands swapped (first operand = the B fragment), so the accumulator
   // of fragment (mi, ni) holds C^T: lane l owns row mi*16 + (l&15) of the wave tile and the FOUR CONSECUTIVE
@@ -819,7 +687,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   lds_char* mk_lds = smem + wave * (WTM * 128);
   bool mask_lds = false;
   if constexpr (MASK_LDS) {
-    if (p.mask && !p.maskbits) {
+    if (p.mask) {
       mask_lds = true;
       const int mrow = lane >> 3, mpc = (lane & 7) ^ (lane >> 3);
       const bf16_t* mg = p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8;
@@ -926,14 +794,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           tt[e] = __builtin_fmaxf(v[it][e] + bias[it % NP][e], floor_);
           o[e] = (bf16_t)tt[e];
         }
-        if (p.out_maskbits) {   // from the ROUNDED output: exactly what a consumer of the bf16 activation would test
-          unsigned mb = 0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) mb |= ((float)o[e] > 0.f ? 1u : 0u) << e;
-          p.out_maskbits[rowi[it] * p.ld_out_maskbits + (coli[it] >> 3)] = (unsigned char)mb;
-        }
-        if (mem) st16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.dbg & 32);
-        else asm volatile("" ::"v"(o));
+        *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         if (p.out_fp8 || p.amax_part) {   // fp8 forward only
           float q8[8];
 #pragma unroll
@@ -956,12 +817,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           f16x8 h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * f16s); h[4 + e] = (_Float16)(hi[e] * f16s); }
-          st16((f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]), h, p.dbg & 8);
-        } else if (mem) {
-          st16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]), lo, p.dbg & 8);
-          st16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4), hi, p.dbg & 8);
+          *(f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]) = h;
         } else {
-          asm volatile("" ::"v"(lo), "v"(hi));
+          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
+          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;
         }
       }
     } else if constexpr (EPI == EPI_TANH_LOSS) {
@@ -977,7 +836,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         for (int it = 0; it < CH; ++it)
 #pragma unroll
           for (int e = 0; e < 8; ++e) xin[it][e] = xpf[it][e];
-      } else if (p.x && mem) {
+      } else if (p.x) {
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
           const long r = rowi[it], col = coli[it];
@@ -1044,9 +903,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             o[e] = (bf16_t)g;
           }
         }
-        if (p.x && mem) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
-        else asm volatile("" ::"v"(o));
-        if (p.recon && rv_ && mem) {
+        if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
+        if (p.recon && rv_) {
           if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
             *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
             *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
@@ -1058,26 +916,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         }
       }
     } else {  // EPI_MASK_BF16
-      // Two separate loops under one wave-uniform branch: as one loop with a per-element `by_bits ? ... : ...` the
-      // compiler evaluates both tests and selects (9 VALU per element instead of 3-4, and a wave64 VALU instruction
-      // is 4 cycles: on a 256x256 tile every instruction per element costs 0.4 us).
-      if (p.maskbits != nullptr) {
-        unsigned mbits[CH];
-#pragma unroll
-        for (int it = 0; it < CH; ++it) mbits[it] = mem ? p.maskbits[rowi[it] * p.ld_maskbits + (coli[it] >> 3)] : 0xFFu;
-#pragma unroll
-        for (int it = 0; it < CH; ++it) {
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float tt = ((mbits[it] >> e) & 1u) != 0u ? v[it][e] : 0.f;
-            cs[it % NP][e] += tt;
-            o[e] = (bf16_t)tt;
-          }
-          if (mem) *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
-          else asm volatile("" ::"v"(o));
-        }
-      } else {
+      {
         // activation > 0 tested on the bf16 bit patterns, two per 32-bit word: the high half is positive iff the word,
         // as a signed integer, exceeds 0xFFFF; the low half iff it is a positive int16 (NaNs never occur in a ReLU output)
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1097,8 +936,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         } else {
 #pragma unroll
           for (int it = 0; it < CH; ++it) {
-            mk[it] = i32x4{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
-            if (mem) mk[it] = *(const i32x4*)(p.mask + rowi[it] * p.ld_mask + coli[it]);
+            mk[it] = *(const i32x4*)(p.mask + rowi[it] * p.ld_mask + coli[it]);
           }
         }
 #pragma unroll
@@ -1114,8 +952,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             o[2 * w] = (bf16_t)t0;
             o[2 * w + 1] = (bf16_t)t1;
           }
-          if (mem) st16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.dbg & 16);
-          else asm volatile("" ::"v"(o));
+          *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
         }
       }
     }

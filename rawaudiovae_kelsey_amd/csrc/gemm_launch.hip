@@ -16,18 +16,11 @@ namespace {
 //      (measured 4-10 % faster than config 1 on every 128-tile GEMM of the step)
 //   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring); only
 //      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
-int g_force_tile = -1;
-// Main loop of the 256x128 tile: 3 = one-barrier ring (default), 9 = ping-pong on three buffers.  Measured stand-alone
-// at C2 (tools/gemm_bench.py, same box, interleaved): NT 19.7 vs 21.5 us, TN 28.7 vs 29.5, NN 27.3 vs 25.4 -- at this
-// tile the loop is bound by how fast one CU fills its LDS (~60 GB/s), which the phase structure does not change.
-int g_n128_loop = 3;
-int g_adam_stream = 1;   // optimizer blocks of rv_linear_wgrad_adam: 1 = LDS-DMA ring per wave (adam_stream), 0 = plain loads
-int g_dbg = 0;        // GemmArgs::dbg of every launch (diagnostics: rv_gemm_force_tile(200 + bits))
-int g_pair_only = 0;  // paired launch: 1 = dgrad blocks only, 2 = wgrad blocks only (diagnostics: 300 + v)
+int g_force_tile = -1;   // test hook (include/rawvae_hip_diag.h): pin one tile configuration, -1 = the picker's choice
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
-  constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE == 9 ? 3 : NSTAGE;  // NSTAGE 8 / 9 = ping-pong main loops on 2 / 3 buffers
+  constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE;  // NSTAGE 8 = the ping-pong main loop on 2 buffers
   constexpr int smem_max = RING * (BM + BN) * 128;
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
@@ -45,7 +38,6 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
   g.splits = splits;
-  g.dbg = g_dbg;
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * splits), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), smem, st, g);
   RV_CHECK_LAUNCH();
@@ -87,9 +79,7 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
   switch (tile) {
     case 0: return launch<64, 64, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 1: return launch<128, 128, 2, 2, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
-    case 2:
-      if (g_n128_loop == 3) return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
-      return launch<256, 128, 2, 4, 9, AK, BK, EPI>(a, Mp, Np, splits, st);
+    case 2: return launch<256, 128, 4, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 4: return launch<128, 128, 2, 4, 4, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 5: return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 7:
@@ -169,10 +159,7 @@ template <int NSTAGE>
 int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
   GemmArgs d = d_in, g = g_in;
-  d.dbg = g.dbg = g_dbg;
-  int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
-  if (g_pair_only == 1) n_w = 0;
-  if (g_pair_only == 2) n_d = 0;
+  const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
   constexpr int smem = 2 * (BM + BN) * 128;  // the ring; the epilogue's reductions reuse its first bytes
   auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
   static bool attr_done = false;
@@ -202,7 +189,6 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
     attr_done = true;
   }
   GemmArgs g1 = a, g2 = b;
-  g1.dbg = g2.dbg = g_dbg;
   g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
   g2.tiles_m = (int)(Mp2 / BM); g2.tiles_n = (int)(Np2 / BN); g2.splits = splits2;
   const int n1 = g1.tiles_m * g1.tiles_n * splits1, n2 = g2.tiles_m * g2.tiles_n * splits2;
@@ -274,12 +260,10 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
   return RV_OK;
 }
 
+// Test hook (include/rawvae_hip_diag.h, not part of the product ABI): pin the block tile every later launch uses
+// (-1: the picker's choice), or -- 102 / 108 -- the main loop of the paired 256x256 launch (two-slot ring / ping-pong).
 extern "C" int rv_gemm_force_tile(int tile) {
-  if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }  // experiment hook: pair main loop
-  if (tile == 103 || tile == 109) { g_n128_loop = tile - 100; return RV_OK; }
-  if (tile == 400 || tile == 401) { g_adam_stream = tile - 400; return RV_OK; }  // experiment hook: optimizer blocks' loader  // experiment hook: 256x128 main loop
-  if (tile >= 200 && tile < 264) { g_dbg = tile - 200; return RV_OK; }         // diagnostics: GemmArgs::dbg
-  if (tile >= 300 && tile < 303) { g_pair_only = tile - 300; return RV_OK; }   // diagnostics: one half of the pair
+  if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }
   g_force_tile = tile;
   return RV_OK;
 }
@@ -304,26 +288,18 @@ int rv_linear_fwd(const void* x, long ldx, const void* w, long ldw, const float*
   return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
 }
 
-int rv_linear_fwd_q8(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp, long Np, long Kp,
-                     int act, void* y, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale, float* amax_part,
-                     void* stream) {
-  return rv_linear_fwd_ex(x, ldx, w, ldw, bias, Mp, Np, Kp, act, y, ldy, y_fp8, ldy_fp8, q_scale, amax_part, nullptr, 0, stream);
-}
-
 int rv_linear_fwd_ex(const void* x, long ldx, const void* w, long ldw, const float* bias, long Mp, long Np, long Kp,
                      int act, void* y, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale, float* amax_part,
-                     void* maskbits, long ld_maskbits, void* stream) {
-  RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd_q8: null operand");
-  RV_REQUIRE(!maskbits || ld_maskbits >= Np / 8, RV_ERR_SHAPE, "rv_linear_fwd_ex: mask rows are Np/8 bytes");
-  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_q8: act %d", act);
+                     void* stream) {
+  RV_REQUIRE(x && w && y, RV_ERR_NULL, "rv_linear_fwd_ex: null operand");
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_ex: act %d", act);
   RV_REQUIRE(!y_fp8 || (q_scale && ldy_fp8 % 8 == 0 && ((uintptr_t)y_fp8 & 7) == 0), RV_ERR_SHAPE,
-             "rv_linear_fwd_q8: fp8 output needs a scale and 8-byte aligned rows");
+             "rv_linear_fwd_ex: fp8 output needs a scale and 8-byte aligned rows");
   GemmArgs a{};
   a.A = (const bf16_t*)x; a.lda = ldx; a.B = (const bf16_t*)w; a.ldb = ldw;
   a.k_tiles = (int)(Kp / 64); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy;
   a.out_fp8 = (unsigned char*)y_fp8; a.ld_fp8 = ldy_fp8; a.q_scale = q_scale; a.amax_part = amax_part;
-  a.out_maskbits = (unsigned char*)maskbits; a.ld_out_maskbits = ld_maskbits;
   return launch_auto<true, true, EPI_BIAS_ACT_BF16>(a, Mp, Np, Kp, 1, (hipStream_t)stream);
 }
 
@@ -346,19 +322,13 @@ int rv_linear_fwd_frames(const void* audio_bf16, const long long* frame_index, l
   a.a_idx = frame_index; a.a_first = first_frame; a.a_hop = hop; a.a_rows = (int)B;
   a.a_copy = (bf16_t*)frames_bf16; a.ld_copy = ld_frames; a.step_inc = step_counter;
   const int tile = choose_tile(Mp, Np, 1);
-  RV_REQUIRE(tile != 5 && tile != 7 && !(tile == 2 && g_n128_loop != 3), RV_ERR_UNSUPPORTED,
+  RV_REQUIRE(tile != 5 && tile != 7, RV_ERR_UNSUPPORTED,
              "rv_linear_fwd_frames: the gathered operand is implemented in the ring main loop only (tile %d)", tile);
   return launch_tile<true, true, EPI_BIAS_ACT_BF16>(tile, a, Mp, Np, Kp, 1, (hipStream_t)stream);
 }
 
 int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
                       long Mp, long Np, long Kp, int act, void* y, long ldy, void* stream) {
-  return rv_linear_fwd_fp8_ex(x_fp8, ldx, w_fp8, ldw, bias, dq, Mp, Np, Kp, act, y, ldy, nullptr, 0, stream);
-}
-
-int rv_linear_fwd_fp8_ex(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
-                         long Mp, long Np, long Kp, int act, void* y, long ldy, void* maskbits, long ld_maskbits,
-                         void* stream) {
   RV_REQUIRE(x_fp8 && w_fp8 && y && dq, RV_ERR_NULL, "rv_linear_fwd_fp8: null operand");
   RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_RELU, RV_ERR_UNSUPPORTED, "rv_linear_fwd_fp8: act %d", act);
   RV_REQUIRE(Kp % 128 == 0 && ldx % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_linear_fwd_fp8: K and leading dims must be multiples of 128 / 16 fp8 elements");
@@ -366,7 +336,6 @@ int rv_linear_fwd_fp8_ex(const void* x_fp8, long ldx, const void* w_fp8, long ld
   a.A = (const bf16_t*)x_fp8; a.lda = ldx / 2; a.B = (const bf16_t*)w_fp8; a.ldb = ldw / 2;
   a.k_tiles = (int)(Kp / 128); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   a.relu = act == RV_ACT_RELU; a.bias = bias; a.out_bf16 = (bf16_t*)y; a.ld_bf16 = ldy; a.dq = dq;
-  a.out_maskbits = (unsigned char*)maskbits; a.ld_out_maskbits = ld_maskbits;
   return launch_tile_fp8<EPI_BIAS_ACT_BF16>(choose_tile(Mp, Np, 1), a, Mp, Np, Kp / 2, (hipStream_t)stream);
 }
 
@@ -457,36 +426,26 @@ int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp,
 
 int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp,
                     int splits, float* dw, long lddw, void* stream) {
-  return rv_linear_wgrad_ex(dy, lddy, x, ldx, Mp, Np, Kp, splits, dw, lddw, RV_SLAB_F32, nullptr, stream);
+  return rv_linear_wgrad_ex(dy, lddy, x, ldx, Mp, Np, Kp, splits, RV_TILE_AUTO, dw, lddw, RV_SLAB_F32, nullptr, stream);
 }
 
-int rv_linear_wgrad_ex(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits, void* dw,
-                       long lddw, int slab_dtype, float* slab_unscale, void* stream) {
+// Weight gradient with every option: a named block tile (RV_TILE_AUTO = the picker's choice) and the slab element type.
+int rv_linear_wgrad_ex(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                       int tile, void* dw, long lddw, int slab_dtype, float* slab_unscale, void* stream) {
   RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad: null operand");
-  GemmArgs a{};
-  a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
-  a.k_tiles = (int)(Kp / 64 / (splits > 0 ? splits : 1)); a.M_valid = (int)Mp; a.N_valid = (int)Np;
-  int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
-  if (rc) return rc;
-  return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
-}
-
-// Weight gradient on a named block tile (the training plan runs dW4 on 256x256 ping-pong tiles on its side stream).
-int rv_linear_wgrad_tile(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
-                         int tile, void* dw, long lddw, int slab_dtype, float* slab_unscale, void* stream) {
-  RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad_tile: null operand");
-  RV_REQUIRE(tile == RV_TILE_256x256 || tile == RV_TILE_256x128 || tile == RV_TILE_128x128 || tile == RV_TILE_64x64,
-             RV_ERR_UNSUPPORTED, "rv_linear_wgrad_tile: unknown tile %d", tile);
-  RV_REQUIRE(splits >= 1, RV_ERR_SHAPE, "rv_linear_wgrad_tile: splits %d", splits);
+  RV_REQUIRE(tile == RV_TILE_AUTO || tile == RV_TILE_256x256 || tile == RV_TILE_256x128 || tile == RV_TILE_128x128 ||
+                 tile == RV_TILE_64x64, RV_ERR_UNSUPPORTED, "rv_linear_wgrad_ex: unknown tile %d", tile);
+  RV_REQUIRE(splits >= 1, RV_ERR_SHAPE, "rv_linear_wgrad_ex: splits %d", splits);
   GemmArgs a{};
   a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
   a.k_tiles = (int)(Kp / 64 / splits); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
+  if (tile == RV_TILE_AUTO) return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
   return launch_tile<false, false, EPI_F32>(tile, a, Mp, Np, Kp, splits, (hipStream_t)stream);
 }
 
-int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {
+int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {   // (plan.hip's schedule; not in the public header)
   return Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 64 == 0 && splits >= 1 &&
          (Kp / 64) % splits == 0 && g_force_tile < 0;
 }
@@ -511,12 +470,12 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
   g.k_tiles = (int)(Kp / 64 / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np;
   rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
-  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.dbg = g_dbg;
+  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits;
   const int n_gemm = g.tiles_m * g.tiles_n * splits;
   constexpr int smem = 2 * (256 + 256) * 128;
   static_assert(8 * 2 * AS_SLOT <= smem, "the optimizer waves' LDS rings live in the launch's dynamic LDS");
   // fp16 slabs are 8 B per group, below the 16-byte LDS-DMA piece: such tables take the plain-load walk (adam_group)
-  int stream_mode = g_adam_stream;
+  int stream_mode = 1;
   for (int i = 0; i < n_desc; ++i)
     if (descs[i].grad_half) stream_mode = 0;
   const bool pp = g.k_tiles % 2 == 0;
@@ -569,23 +528,15 @@ int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, i
 int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
                           long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
                           float* dw_slabs, long lddw, int splits, void* stream) {
-  return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, nullptr, 0, Mp, Np, Kp, dx_bf16, lddx, colsum_partial, dw_slabs,
+  return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, Mp, Np, Kp, dx_bf16, lddx, colsum_partial, dw_slabs,
                                   lddw, splits, RV_SLAB_F32, nullptr, stream);
 }
 
-int rv_linear_dgrad_wgrad_mb(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
-                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
-                             float* colsum_partial, float* dw_slabs, long lddw, int splits, void* stream) {
-  return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, maskbits, ld_maskbits, Mp, Np, Kp, dx_bf16, lddx, colsum_partial,
-                                  dw_slabs, lddw, splits, RV_SLAB_F32, nullptr, stream);
-}
-
 int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
-                             const void* maskbits, long ld_maskbits, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
+                             long Mp, long Np, long Kp, void* dx_bf16, long lddx,
                              float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype, float* slab_unscale,
                              void* stream) {
   RV_REQUIRE(dy && w && x && dx_bf16 && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad: null operand");
-  RV_REQUIRE(!maskbits || ld_maskbits >= Np / 8, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_mb: mask rows are Np/8 bytes");
   int paired, bm, sp;
   int rc = rv_dgrad_wgrad_pick(Mp, Np, Kp, &paired, &bm, &sp);
   if (rc) return rc;
@@ -597,7 +548,6 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
     d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
     d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
     d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
-    d.maskbits = (const unsigned char*)maskbits; d.ld_maskbits = ld_maskbits;
     g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
     g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;
     rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_unscale, Kp, Np);
@@ -607,7 +557,7 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
       return rc;
     rc = launch_tile<true, false, EPI_MASK_BF16>(td, d, Mp, Np, Kp, 1, (hipStream_t)stream);
     if (rc) return rc;
-    return rv_linear_wgrad_ex(dy, lddy, x, ldx, Kp, Np, Mp, splits, dw_slabs, lddw, slab_dtype, slab_unscale, stream);
+    return rv_linear_wgrad_ex(dy, lddy, x, ldx, Kp, Np, Mp, splits, RV_TILE_AUTO, dw_slabs, lddw, slab_dtype, slab_unscale, stream);
   }
   RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: leading dims must be multiples of 8");
   RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: operands must be 16-byte aligned");
@@ -616,7 +566,6 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
   d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
   d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
   d.mask = (const bf16_t*)x; d.ld_mask = ldx; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
-  d.maskbits = (const unsigned char*)maskbits; d.ld_maskbits = ld_maskbits;
   d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1;
   g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
   g.k_tiles = (int)(Mp / 64 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np;

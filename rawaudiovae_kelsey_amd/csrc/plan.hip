@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+extern "C" int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);   // gemm_launch.hip (internal)
+
 namespace {
 
 struct Buf {
@@ -25,6 +27,12 @@ int splits_of(long Mp, long Np, long Kp) {
   rv_gemm_pick(Mp, Np, Kp, 16, nullptr, nullptr, &s);
   return s;
 }
+
+// Block tile of the fc1 weight gradient when it runs as a launch of its own: the 256x256 tile of the launch that also
+// carries optimizer blocks (rv_linear_wgrad_adam) wherever that one applies, so that every schedule of the step --
+// full, phase by phase, data-parallel -- writes bit-identical slabs (the per-wave-tile exponents of fp16 slabs
+// follow the tile).
+int w1_tile(const rv_plan* p);
 
 int row_tiles(long Mp, long Np) {
   int bm = 128;
@@ -45,10 +53,6 @@ struct rv_plan {
   rv_plan_buffers b;
   bool bound;
   rv_param_desc d_slab[10], d_flat[10];
-  // fork/join machinery: independent backward GEMMs and the fc3/fc4 half of Adam run on a
-  // side stream, ordered against the caller's stream with events (graph-capture safe)
-  hipStream_t side = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // gradients supplied by the caller for the next backward phases (rv_plan_set_external_grads); all null = the
   // fused loss of the forward phase
   const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
@@ -56,8 +60,6 @@ struct rv_plan {
   float* ext_grad_out = nullptr;
   int latent_fused = 1;          // rv_plan_set_latent_fused: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
-  int adam_split = 1000;  // permille of fc4.weight's rows updated by the optimizer blocks of the dW1 launch
-  int concurrent = 0;  // 0: whole step on the caller's stream (default); otherwise the fc3/fc4 half of Adam is forked
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
   // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
   rv_allreduce_fn allreduce = nullptr;
@@ -99,6 +101,13 @@ struct rv_plan {
     ws_bytes += align256(bytes);
   }
 };
+
+namespace {
+int w1_tile(const rv_plan* p) {
+  return rv_wgrad_adam_fits(p->Hp, p->Sp, p->Bp, p->s_w1) && (p->Hp / 256) * (p->Sp / 256) * p->s_w1 <= 192 ? RV_TILE_256x256
+                                                                                                          : RV_TILE_AUTO;
+}
+}  // namespace
 
 extern "C" {
 
@@ -187,8 +196,6 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
 
 void rv_plan_destroy(rv_plan* p) {
   if (!p) return;
-  for (hipEvent_t e : p->ev)
-    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_ready)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_done)
@@ -197,38 +204,22 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_gath)
     if (e) (void)hipEventDestroy(e);
-  // p->side / p->comm_stream are the process-wide helper streams (helper_stream below): not destroyed here
+  // p->comm_stream is the process-wide collective stream (helper_stream below): not destroyed here
   delete p;
 }
 
-// The two helper streams (side: the two-stream experiments; comm: collectives, highest priority) exist ONCE per process
-// and are created on first need.  One per plan was measured harmful: every extra HIP stream may land on another of
-// the runtime's few hardware queues (GPU_MAX_HW_QUEUES, default 4), and with an unlucky mapping -- it depended on how
-// many plans had been created before -- every kernel of a data-parallel step started ~50 us late (880 instead of
-// 255 us per step at one rank).  One process drives one GPU (header, Conventions), so the streams are not per device.
-static hipStream_t g_side_stream = nullptr, g_comm_stream = nullptr;
-static int helper_stream(bool comm, hipStream_t* out) {
-  hipStream_t& s = comm ? g_comm_stream : g_side_stream;
-  if (!s) {
-    if (comm) {
-      int lo = 0, hi = 0;  // collectives ahead of compute when both are runnable
-      RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      RV_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
-    } else {
-      RV_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    }
+// The collective stream (highest priority) exists ONCE per process and is created on first need.  One per plan was
+// measured harmful: every extra HIP stream may land on another of the runtime's few hardware queues
+// (GPU_MAX_HW_QUEUES, default 4), and with an unlucky mapping every kernel of a data-parallel step started ~50 us
+// late (profiles/r02_hw_queue_hazard.txt).  One process drives one GPU (header, Conventions).
+static hipStream_t g_comm_stream = nullptr;
+static int helper_stream(bool, hipStream_t* out) {
+  if (!g_comm_stream) {
+    int lo = 0, hi = 0;  // collectives ahead of compute when both are runnable
+    RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RV_HIP(hipStreamCreateWithPriority(&g_comm_stream, hipStreamNonBlocking, hi));
   }
-  *out = s;
-  return RV_OK;
-}
-
-int rv_plan_set_concurrency(rv_plan* p, int enable) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_concurrency: null plan");
-  if (enable && !p->side) {
-    const int rc = helper_stream(false, &p->side);
-    if (rc) return rc;
-  }
-  p->concurrent = enable;
+  *out = g_comm_stream;
   return RV_OK;
 }
 
@@ -255,27 +246,6 @@ int rv_plan_set_latent_fused(rv_plan* p, int enable) {
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_latent_fused: null plan");
   p->latent_fused = enable ? 1 : 0;
   return RV_OK;
-}
-
-int rv_plan_set_adam_split(rv_plan* p, int permille) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_adam_split: null plan");
-  RV_REQUIRE(permille >= 0 && permille <= 2000, RV_ERR_SHAPE, "rv_plan_set_adam_split: %d not in [0, 2000]", permille);
-  p->adam_split = permille;
-  return RV_OK;
-}
-
-// Rows [0, r0) and [r0, rows) of one tensor as two descriptors (r0 * cols a multiple of 4 keeps both 16-byte aligned).
-static void split_rows(const rv_param_desc& d, long r0, rv_param_desc* top, rv_param_desc* bottom) {
-  *top = d;
-  top->rows = r0;
-  *bottom = d;
-  bottom->rows = d.rows - r0;
-  bottom->offset = d.offset + r0 * d.cols;
-  bottom->grad_slabs = (const float*)((const char*)d.grad_slabs + r0 * d.grad_ld * (d.grad_half ? 2 : 4));
-  if (d.grad_half) bottom->grad_unscale = d.grad_unscale + (r0 / 32) * d.us_ld;   // r0 is a multiple of 32 then (caller)
-  if (d.shadow_bf16) bottom->shadow_bf16 = (char*)d.shadow_bf16 + r0 * d.shadow_ld * 2;
-  if (d.shadow_f32) bottom->shadow_f32 = d.shadow_f32 + r0 * d.shadow_ld;
-  if (d.shadow_fp8) bottom->shadow_fp8 = (char*)d.shadow_fp8 + r0 * d.shadow_ld;
 }
 
 int rv_plan_set_fp8(rv_plan* p, int enable) {
@@ -318,8 +288,6 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   RV_REQUIRE(((uintptr_t)b->workspace & 255) == 0, RV_ERR_SHAPE, "rv_plan_bind: workspace must be 256-byte aligned");
   p->b = *b;
   p->bound = true;
-  if (!p->ev[0])
-    for (hipEvent_t& e : p->ev) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const long H = p->H, S = p->S, L = p->L, Hp = p->Hp, Sp = p->Sp, Lp = p->Lp, L2p = p->L2p, Bp = p->Bp;
   float* dW1 = (float*)p->ws("dW1"); float* dWh = (float*)p->ws("dWh");
   float* dW3 = (float*)p->ws("dW3"); float* dW4 = (float*)p->ws("dW4");
@@ -428,20 +396,20 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                    p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
                                    p->b.step_counter, stream));
       if (p->fp8)
-        RV_TRY(rv_linear_fwd_fp8_ex(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
-                                    h1, Hp, nullptr, 0, stream));
+        RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                                 h1, Hp, stream));
       else
         RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
-                                nullptr, nullptr, nullptr, 0, stream));
+                                nullptr, nullptr, stream));
     } else if (p->fp8) {
       RV_TRY(rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
                                  p->b.step_counter, stream));
-      RV_TRY(rv_linear_fwd_fp8_ex(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
-                                    h1, Hp, nullptr, 0, stream));
+      RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+                               h1, Hp, stream));
     } else {
       RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
       RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
-                                nullptr, nullptr, nullptr, 0, stream));
+                                nullptr, nullptr, stream));
     }
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64, bf16), else three
     const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && !p->fp8;
@@ -454,23 +422,23 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     if (p->fr_hop) {
       if (p->fp8)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), nullptr, 0, stream));
+                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       else if (!latent_fused)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
-                                nullptr, nullptr, nullptr, 0, stream));
+                                nullptr, nullptr, stream));
       RV_TRY(rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
                                            (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
                                            p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
                                            mse_part, (float*)p->ws("db4p"), stream));
     } else if (p->fp8) {
       RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), nullptr, 0, stream));
+                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
                                         x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     } else {
       if (!latent_fused)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
-                                nullptr, nullptr, nullptr, 0, stream));
+                                nullptr, nullptr, stream));
       RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     }
@@ -491,97 +459,25 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   RV_REQUIRE(!(full_local && (p->ext_d_recon || p->ext_dmu || p->ext_dlv)), RV_ERR_STATE,
              "rv_plan_step: external gradients are set (rv_plan_set_external_grads); run the backward phases without ADAM");
   auto reparam_bwd = [&](void* st) {
-    return rv_reparam_bwd_ext(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, dmulv,
+    return rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, dmulv,
                               (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring,
                               p->b.step_counter, p->b.ring, st);
   };
-  if (full_local && p->concurrent == 0 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) &&
-      (Hp / 256) * (Sp / 256) * p->s_w1 <= 192) {
+  if (full_local && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && (Hp / 256) * (Sp / 256) * p->s_w1 <= 192) {
     // Default schedule, one stream.  dW1 is the last GEMM of the backward: 32 tiles x 4 K splits of 256x256 fill
     // half the chip, so its launch also carries the optimizer step of every tensor whose gradient is already
-    // complete on the other CUs (fc3 and fc4, below); fc1's and the heads' updates are the step's last launch.
+    // complete on the other CUs (fc3 and fc4); fc1's and the heads' updates are the step's last launch.  An
+    // optimizer block streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take
+    // to finish; the heads' update on top made the launch wait for the optimizer (profiles/r02_adam_split_sweep.txt).
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
-    // fc3 + fc4 ride along (92 MB at C2): an optimizer block streams ~25 GB/s from its CU, so half the chip
-    // moves ~3 TB/s -- about what the GEMM blocks take to finish; the heads' update on top made the launch wait
-    // for the optimizer (43 us against 36)
-    // How much rides along is a balance: the optimizer blocks get half the chip's CUs at ~20 GB/s each while the
-    // GEMM blocks need ~30 us, and the last launch updates at the whole chip's rate -- so only the first
-    // `adam_split` permille of fc4.weight's rows are updated here and the rest by the last launch.
-    // Above 1000 the heads' tensors (fc21, fc22: gradients complete since heads_bwd) ride as well.
-    rv_param_desc ride[8], last[7];
-    int n_ride = 0, n_last = 0;
-    const bool heads_ride = p->adam_split > 1000;
-    for (int i = 0; i < 6; ++i) {
-      if (heads_ride && i >= 2) ride[n_ride++] = p->d_slab[i];
-      else last[n_last++] = p->d_slab[i];
-    }
-    ride[n_ride++] = p->d_slab[6];
-    ride[n_ride++] = p->d_slab[7];
-    const long r0 = heads_ride ? p->d_slab[8].rows : (p->d_slab[8].rows * p->adam_split / 1000) & ~31L;   // whole scale granules
-    if (r0 >= p->d_slab[8].rows) {
-      ride[n_ride++] = p->d_slab[8];
-    } else if (r0 > 0) {
-      split_rows(p->d_slab[8], r0, &ride[n_ride], &last[n_last]);
-      ++n_ride;
-      ++n_last;
-    } else {
-      last[n_last++] = p->d_slab[8];
-    }
-    ride[n_ride++] = p->d_slab[9];
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, ride,
-                                n_ride, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 6,
+                                4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                 p->b.step_counter, 256 - n_gemm, stream));
-    RV_TRY(rv_adam_multi(last, n_last, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, stream));
-    return RV_OK;
-  }
-  if (full_local && p->concurrent == 2 && stream) {
-    // Off the critical path: the fc4 weight gradient and the fc4 half of Adam.  The backward's dependency chain
-    // is dP3 -> dz -> dmu/dlogvar -> dP1 -> dW1; dW4 = dP4^T h3 needs only forward outputs and nothing in this
-    // step needs W4's update.  So the chain runs alone on the caller's stream (dP3 as a 256-block GEMM of its
-    // own instead of sharing the chip with dW4), and dW4 + Adam(fc4) run on the side stream beside the latent-sized
-    // kernels that leave most of the chip idle.  ONE fork (after dP3: from there on nobody reads W4b, and dP4 / h3
-    // are only read) and ONE join at the end of the step, which the side work reaches long before the chain does.
-    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
-    RV_TRY(rv_linear_dgrad(dP4, Sp, p->ws("W4b"), Hp, Bp, Hp, Sp, h3, Hp, dP3, Hp, (float*)p->ws("db3p"), nullptr, 0, 1,
-                           stream));
-    RV_HIP(hipEventRecord(p->ev[1], s0));
-    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_linear_wgrad_tile(dP4, Sp, h3, Hp, Sp, Hp, Bp, p->s_w4, RV_TILE_256x256, p->ws("dW4"), Hp, p->slab_dtype, p->us_w4,
-                                (void*)s1));
-    RV_TRY(rv_adam_multi(p->d_slab + 8, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, (void*)s1));
-    RV_HIP(hipEventRecord(p->ev[3], s1));
-    RV_TRY(latent_bwd(stream));
-    RV_TRY(reparam_bwd(stream));
-    RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-    RV_TRY(rv_adam_multi(p->d_slab, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, stream));
-    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join: the caller's stream owns the whole step again
-    return RV_OK;
-  }
-  if (full_local && p->concurrent == 1 && stream) {
-    // One fork: everything on the caller's stream except the fc3/fc4 half of Adam, which runs on the side
-    // stream beside the fc1 weight-gradient GEMM (each cross-stream edge costs 6-10 us on this runtime).
-    hipStream_t s0 = (hipStream_t)stream, s1 = p->side;
-    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-    RV_TRY(latent_bwd(stream));
-    RV_HIP(hipEventRecord(p->ev[1], s0));  // dW4, db4, dW3, db3 ready; W3b, W4b no longer read
-    RV_TRY(reparam_bwd(stream));
-    RV_HIP(hipStreamWaitEvent(s1, p->ev[1], 0));
-    RV_TRY(rv_adam_multi(p->d_slab + 6, 4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
-                         p->b.step_counter, (void*)s1));
-    RV_HIP(hipEventRecord(p->ev[3], s1));
-    RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-    RV_HIP(hipStreamWaitEvent(s0, p->ev[3], 0));  // join
     RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     return RV_OK;
@@ -600,7 +496,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_colsum_partial(dP4, 1, Bp, Sp, Sp, (float*)p->ws("db4p"), Sp, stream));
   }
   if (do_pair)
-    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   if (do_chain_a && do_w3) {
     RV_TRY(latent_bwd(stream));
@@ -611,7 +507,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   }
   if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
 
@@ -775,7 +671,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     return RV_OK;
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, stream));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
@@ -784,11 +680,11 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
                                    (float*)p->ws("dW3"), Lp, p->s_w3, stream));
-  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, stream));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: fc4's reduce-scatter is done
   RV_TRY(scatter_bucket(1, s0));
@@ -839,10 +735,6 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE((p->allreduce || p->reduce_scatter) && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
-  // the collective stream must fork from / join into the caller's stream only: a second helper stream in the same
-  // capture has made hipStreamEndCapture recurse without end (unrecoverable), so the two modes exclude each other
-  RV_REQUIRE(p->concurrent == 0, RV_ERR_STATE, "rv_plan_step_ddp: not available while rv_plan_set_concurrency(%d) is set",
-             p->concurrent);
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
@@ -882,7 +774,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, nullptr, 0, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   RV_TRY(payload(8, 10));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) travels behind the rest of backward
@@ -891,7 +783,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
                                    (float*)p->ws("dW3"), Lp, p->s_w3, stream));
-  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmulv, (float*)p->ws("dbhp"),
+  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                (float*)p->ws("dWh"), Hp, p->s_wh, stream));
@@ -902,7 +794,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_flat + 8,
                                 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, scale, p->b.step_counter, 256 - n_gemm, stream));
   } else {
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
     RV_TRY(adam_bucket(8, 2));
   }
   RV_TRY(payload(0, 8));                                   // fc1, fc21, fc22, fc3: contiguous in the arena

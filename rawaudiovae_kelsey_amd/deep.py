@@ -277,7 +277,7 @@ class DeepTrainEngine:
                                      ptr(self.dz_slabs), Lp, self.s_dz, ptr(self.slabs["dec.0.weight"]), Lp,
                                      self.splits["dec.0.weight"], st)
         L_.rv_reparam_bwd(ptr(self.dz_slabs), self.s_dz, Bp, Lp, B, L, S, ptr(self.mulv),
-                          ptr(eps if eps is not None else self.eps), self.kl_beta, ptr(self.dmulv),
+                          ptr(eps if eps is not None else self.eps), self.kl_beta, None, None, ptr(self.dmulv),
                           ptr(self.dbh_part), ptr(self.mse_part), self.n_mse, ptr(self.kl_part), self.n_kl,
                           ptr(self.loss_ring), ctr, self.ring, st)
         # backward: heads and encoder

@@ -133,21 +133,11 @@ class TrainEngine:
         self.params_changed()
         self.refresh_shadows()
 
-    def set_concurrency(self, enable):
-        """0 (default): the whole step on the caller's stream; non-zero: the fc3/fc4 half of Adam is forked
-        onto a side stream beside the fc1 weight-gradient GEMM (measured slower at C2: 224 vs 217 us)."""
-        lib().rv_plan_set_concurrency(self._plan, int(enable))
-
     def set_latent_fused(self, enable):
-        """True: heads GEMM + reparameterisation + fc3 of the forward as one launch where the library has the fused
-        kernel (padded latent width 64, hidden width a multiple of 512, bf16) -- measured slower, so the default is
-        False: three launches (`rv_plan_set_latent_fused`)."""
+        """True (default): heads GEMM + reparameterisation + fc3 of the forward as one launch where the library has the
+        fused kernel (padded latent width 64, hidden width a multiple of 512 up to 2048, bf16); False: always three
+        launches (`rv_plan_set_latent_fused`)."""
         lib().rv_plan_set_latent_fused(self._plan, int(bool(enable)))
-
-    def set_adam_split(self, permille):
-        """Share (in 1/1000) of fc4.weight's rows whose Adam update rides in the fc1 weight-gradient launch; the rest
-        is updated by the step's last launch (`rv_plan_set_adam_split`; arithmetic unchanged, only the balance)."""
-        lib().rv_plan_set_adam_split(self._plan, int(permille))
 
     def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
         """Write entries of the fp8 state block (include/rawvae_hip.h, rv_plan_set_fp8).  Weight scales are

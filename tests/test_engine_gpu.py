@@ -163,24 +163,6 @@ def test_graph_replay_matches_eager():
     assert a.losses(4) == b.losses(4)
 
 
-def test_two_stream_backward_equals_serial():
-    """The forked schedule (side stream + events) must give bit-identical steps."""
-    S, H, L, B = 256, 384, 16, 256
-    a, b = _engine(S, H, L, B, seed=5), _engine(S, H, L, B, seed=5)
-    a.set_concurrency(False)
-    b.set_concurrency(True)
-    st = torch.cuda.Stream()
-    xs = [torch.from_numpy(make_frames(B, S, 40 + i)).cuda() for i in range(3)]
-    torch.cuda.synchronize()
-    with torch.cuda.stream(st):
-        for i in range(6):
-            a.step(xs[i % 3], stream=st)
-            b.step(xs[i % 3], stream=st)
-    torch.cuda.synchronize()
-    assert torch.equal(a.param, b.param) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
-    assert a.losses(6) == b.losses(6)
-
-
 def test_ddp_phased_step_equals_local_step_single_rank():
     """FWD|BWD_A|FINALIZE_A -> (all-reduce) -> BWD_B|FINALIZE_B -> (all-reduce) -> Adam-from-flat
     is the same arithmetic as the fused local step when world == 1."""
@@ -294,36 +276,32 @@ def test_long_trajectory_tracks_fp32_cpu_training():
 
 
 @pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 512, 16, 384)])
-def test_schedules_agree(shape):
-    """rv_plan_set_concurrency: the default schedule (0: the fc1 weight-gradient launch also carries the Adam
-    update of fc3/fc4 on the CUs its GEMM leaves idle) gives bit for bit what the round-1 schedule (3: Adam as
-    one launch of its own) gives -- same kernels' arithmetic, different launch grouping; the two-stream
-    experiment (2: dP3 from an unpaired dgrad kernel) agrees to fp32 summation order."""
+def test_full_step_equals_its_phases(shape):
+    """The default schedule of the full step (the fc1 weight-gradient launch also carries the Adam update of fc3 / fc4
+    on the CUs its GEMM leaves idle, rv_linear_wgrad_adam) gives bit for bit what the same step gives when it is
+    issued phase by phase (forward, backward, then Adam as launches of its own from the same slabs): same kernels'
+    arithmetic, different launch grouping."""
+    from rawaudiovae_kelsey_amd import engine as E
     S, H, L, B = shape
     x = [torch.from_numpy(make_frames(B, S, 7 + i)).cuda() for i in range(3)]
-    st = torch.cuda.Stream()
-    out = {}
-    for sched in (0, 3, 2):
+    out = []
+    for phased in (False, True):
         e = _engine(S, H, L, B, seed=11)
-        e.set_concurrency(sched)
-        with torch.cuda.stream(st):
-            for i in range(3):
-                e.step(x[i], stream=st)
-        st.synchronize()
+        for i in range(3):
+            if phased:
+                e.step(x[i], phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B)
+                e.step(x[i], phases=E.PHASE_ADAM)
+            else:
+                e.step(x[i])
         torch.cuda.synchronize()
-        out[sched] = (e.param.clone(), e.exp_avg.clone(), e.exp_avg_sq.clone(), e.losses(3))
-    assert out[0][3] == out[3][3]
-    for a, b in zip(out[0][:3], out[3][:3]):
+        out.append((e.param.clone(), e.exp_avg.clone(), e.exp_avg_sq.clone(), e.losses(3)))
+    assert out[0][3] == out[1][3]
+    for a, b in zip(out[0][:3], out[1][:3]):
         assert torch.equal(a, b)
-    assert np.allclose(out[2][3], out[0][3], rtol=1e-6)
-    # Adam's first steps move every weight by ~lr whatever the gradient's size, so a last-bit difference in a
-    # near-zero gradient can flip an update: compare the parameters on the scale of one step
-    assert float((out[2][0] - out[0][0]).abs().max()) <= 2.5 * LR * 3
-    assert float((out[2][0] - out[0][0]).abs().mean()) <= 1e-3 * LR
 
 
 def test_latent_forward_one_launch_vs_three_in_the_step():
-    """The step with heads + reparam + fc3 as one launch (`set_latent_fused(True)`, an opt-in experiment) against
+    """The step with heads + reparam + fc3 as one launch (`set_latent_fused(True)`, the default where it applies) against
     the default step with the three launches: same eps, losses equal to fp32 summation order, parameters after 5 steps
     agree like two summation orders do."""
     from oracle.inputs import make_frames, make_params

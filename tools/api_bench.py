@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.inputs import make_frames, make_params  # noqa: E402
+from rawaudiovae_kelsey_amd.synth import make_frames, make_params  # noqa: E402
 from rawvae.model import VAE, loss_function  # noqa: E402
 
 S, H, L, B = 1024, 2048, 64, 4096

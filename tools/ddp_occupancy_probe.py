@@ -13,7 +13,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from oracle.inputs import make_frames, make_params  # noqa: E402
+from rawaudiovae_kelsey_amd.synth import make_frames, make_params  # noqa: E402
 from rawaudiovae_kelsey_amd.engine import TrainEngine  # noqa: E402
 
 S, H, L, B = 1024, 2048, 64, 4096

@@ -17,8 +17,6 @@ if os.environ.get('RV_TILE'):
     Lb.rv_gemm_force_tile(int(os.environ['RV_TILE']))
 if os.environ.get('RV_PAIR_LOOP'):   # 2: two-slot ring, 8: ping-pong main loop of the paired 256x256 kernel
     Lb.rv_gemm_force_tile(100 + int(os.environ['RV_PAIR_LOOP']))
-if os.environ.get('RV_N128'):        # 3: one-barrier ring, 9: ping-pong main loop of the 256x128 tile
-    Lb.rv_gemm_force_tile(100 + int(os.environ['RV_N128']))
 st = torch.cuda.current_stream().cuda_stream or None
 
 
@@ -64,21 +62,19 @@ cases = {
     "wgrad fc1 2048x1024x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(h), LD(H), P(x), LD(S), H, S, B, SPL["w1"], P(f32buf), S, st)),
 }
 
-e0, e1 = C.c_void_p(), C.c_void_p()
-Lb.rv_event_create(C.byref(e0))
-Lb.rv_event_create(C.byref(e1))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events on the current stream
 if PAD:
     cases = {k: v for k, v in cases.items() if k.startswith(('pure', 'fc1', 'wgrad fc4', 'wgrad fc1'))}
 res = {k: [] for k in cases}
 REPS, ROUNDS = 20, 5
 for rnd_i in range(ROUNDS + 1):
     for k, (fl, fn) in cases.items():
-        Lb.rv_event_record(e0, st)
+        e0.record()
         for _ in range(REPS):
             fn()
-        Lb.rv_event_record(e1, st)
-        ms = C.c_float()
-        Lb.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
+        e1.record()
+        e1.synchronize()
+        ms = C.c_float(e0.elapsed_time(e1))
         if rnd_i:
             res[k].append(ms.value / REPS * 1e3)
 tot = 0

@@ -16,9 +16,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 L = lib()
 L.rv_gemm_force_tile(tile)
 st = torch.cuda.current_stream().cuda_stream or None
-e0, e1 = C.c_void_p(), C.c_void_p()
-L.rv_event_create(C.byref(e0))
-L.rv_event_create(C.byref(e1))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events on the current stream
 pts = []
 for K in (256, 512, 1024, 2048, 4096, 8192):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
@@ -30,12 +28,12 @@ for K in (256, 512, 1024, 2048, 4096, 8192):
         fn()
     best = 1e9
     for _ in range(5):
-        L.rv_event_record(e0, st)
+        e0.record()
         for _ in range(10):
             fn()
-        L.rv_event_record(e1, st)
-        ms = C.c_float()
-        L.rv_event_elapsed_ms_sync(e0, e1, C.byref(ms))
+        e1.record()
+        e1.synchronize()
+        ms = C.c_float(e0.elapsed_time(e1))
         best = min(best, ms.value / 10 * 1e3)
     pts.append((K // 64, best))
     print("tile %d  %dx%dx%-5d %8.1f us  %7.1f TFLOP/s" % (tile, M, N, K, best, 2.0 * M * N * K / best / 1e6))
