@@ -186,6 +186,9 @@ def main():
     import torch
     import torch.distributed as dist
     from rawaudiovae_kelsey_amd.synth import flops_per_frame, make_frames, make_params
+    # train.py refuses to run on an unhealthy collective stream (ddp.pick_comm_stream raises); a benchmark must still
+    # produce its line: it runs, and `comm_stream_pick` in the JSON shows the round trip that was measured
+    os.environ.setdefault("RV_COMM_STREAM_ALLOW_SLOW", "1")
     from rawaudiovae_kelsey_amd import engine as E
 
     # one process per GPU; the modulo only matters for the 2-rank plumbing rehearsal on a one-GPU box
@@ -499,9 +502,13 @@ def main():
                     ddp_pick = "sharded optimizer (not slower than the all-reduce schedule in this run; both timed alike)"
             except Exception as exc:   # the headline above is already measured: report, do not lose it
                 alt = {"grad_allreduce": ar_what, "error": str(exc)[:200]}
-        elif isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "1":
-            # side line, never the headline: the same K steps with the sharded optimizer on a second engine
+        elif isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") in ("1", "2"):
+            # side line, never the headline: the same K steps with the sharded optimizer on a second engine.  On
+            # several GPUs only with RV_DDP_ALT=2: a second schedule that has never run on more than one rank must
+            # not be able to take the measured headline down with it (a failure inside a collective is a hang).
             try:
+                if world > 1 and os.environ.get("RV_DDP_ALT", "1") != "2":
+                    raise RuntimeError("skipped at N > 1 (set RV_DDP_ALT=2 to time it)")
                 eng2 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
                 eng2.load_params(make_params(S, H, L, 0))
                 run2 = ddp.NativeDdpRunner(eng2, comm, comp, sharded=True)

@@ -127,6 +127,101 @@ __device__ __forceinline__ void store_fp8x4(const rv_param_desc& d, long r, long
 
 __host__ __device__ inline bool adam_coop(const rv_param_desc& d) { return d.rows == 1 && d.grad_splits >= 16; }
 
+// fp16 slabs: a thread takes EIGHT consecutive elements, so that its slab loads are 16 bytes like everything else it
+// touches (4 elements of fp16 are 8 bytes, and 8-byte accesses run at 0.54-0.70 of the 16-byte rate:
+// MI355X_MICROARCH.md, "Workgroup dispatch ..." table).  Needs rows of whole 8-element groups, 16-byte aligned.
+__host__ __device__ inline bool adam_wide(const rv_param_desc& d) {
+  return d.grad_half && d.rows > 1 && !d.shadow_f32 && d.grad_splits <= 8 &&
+         ((d.cols | d.grad_ld | d.grad_split_stride | d.offset | d.shadow_ld) & 7) == 0 &&
+         ((reinterpret_cast<uintptr_t>(d.grad_slabs) & 15) == 0);
+}
+__host__ __device__ inline long adam_groups(const rv_param_desc& d) {   // thread-sized groups of one tensor
+  return adam_wide(d) ? d.rows * (d.cols / 8) : d.rows * ((d.cols + 3) / 4);
+}
+
+// The 8-elements-per-thread form of adam_block for fp16-slab tensors (adam_wide): same arithmetic per element (slab
+// sum in slab_sum4's order, adam_update), 16-byte accesses throughout.
+template <bool UPDATE>
+__device__ __forceinline__ void adam_block_wide(const rv_param_desc& d, const long blk, const int tid,
+                                                float* __restrict__ param, float* __restrict__ m_arena,
+                                                float* __restrict__ v_arena, float* __restrict__ grad_out, float lr,
+                                                float grad_scale, const long long* __restrict__ step_counter,
+                                                bf16_t* __restrict__ grad_out_bf16) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  const long gpr = d.cols / 8;
+  const long grp = blk * 256 + tid;
+  if (grp >= gpr * d.rows) return;
+  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
+  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 8;
+  const long o = d.offset + r * d.cols + c;
+  float4 m4[2], v4[2], w4[2];
+  if constexpr (UPDATE) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      m4[h] = *reinterpret_cast<const float4*>(m_arena + o + 4 * h);
+      v4[h] = *reinterpret_cast<const float4*>(v_arena + o + 4 * h);
+      w4[h] = *reinterpret_cast<const float4*>(param + o + 4 * h);
+    }
+  }
+  const long base = r * d.grad_ld + c;
+  const float* up = slab_unscale_ptr(d, r, c);   // 8 consecutive elements share a 32-column granule
+  const _Float16* sl = reinterpret_cast<const _Float16*>(d.grad_slabs);
+  float gv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= d.grad_splits; s += 4) {   // (a + b) + (e + f), as slab_sum4
+    f16x8 q[4];
+    float us[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      q[u] = *reinterpret_cast<const f16x8*>(sl + base + (long)(s + u) * d.grad_split_stride);
+      us[u] = slab_unscale(d, up, s + u);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      gv[e] += ((float)q[0][e] * us[0] + (float)q[1][e] * us[1]) + ((float)q[2][e] * us[2] + (float)q[3][e] * us[3]);
+  }
+  for (; s < d.grad_splits; ++s) {
+    const f16x8 q = *reinterpret_cast<const f16x8*>(sl + base + (long)s * d.grad_split_stride);
+    const float us = slab_unscale(d, up, s);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] += (float)q[e] * us;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gv[e] *= grad_scale;
+  if (grad_out) {
+    *reinterpret_cast<float4*>(grad_out + o) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    *reinterpret_cast<float4*>(grad_out + o + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+  }
+  if (grad_out_bf16) {
+    const bf16x8 b8 = {(bf16_t)gv[0], (bf16_t)gv[1], (bf16_t)gv[2], (bf16_t)gv[3], (bf16_t)gv[4], (bf16_t)gv[5], (bf16_t)gv[6], (bf16_t)gv[7]};
+    *reinterpret_cast<bf16x8*>(grad_out_bf16 + o) = b8;
+  }
+  if constexpr (UPDATE) {
+    float step_size, inv_bc2s;
+    adam_step_consts(step_counter, lr, &step_size, &inv_bc2s);
+    float mv[8] = {m4[0].x, m4[0].y, m4[0].z, m4[0].w, m4[1].x, m4[1].y, m4[1].z, m4[1].w};
+    float vv[8] = {v4[0].x, v4[0].y, v4[0].z, v4[0].w, v4[1].x, v4[1].y, v4[1].z, v4[1].w};
+    float wv[8] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) adam_update(mv[e], vv[e], wv[e], gv[e], step_size, inv_bc2s);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(m_arena + o + 4 * h) = make_float4(mv[4 * h], mv[4 * h + 1], mv[4 * h + 2], mv[4 * h + 3]);
+      *reinterpret_cast<float4*>(v_arena + o + 4 * h) = make_float4(vv[4 * h], vv[4 * h + 1], vv[4 * h + 2], vv[4 * h + 3]);
+      *reinterpret_cast<float4*>(param + o + 4 * h) = make_float4(wv[4 * h], wv[4 * h + 1], wv[4 * h + 2], wv[4 * h + 3]);
+    }
+    if (d.shadow_bf16) {
+      const bf16x8 b8 = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3], (bf16_t)wv[4], (bf16_t)wv[5], (bf16_t)wv[6], (bf16_t)wv[7]};
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(d.shadow_bf16) + r * d.shadow_ld + c) = b8;
+    }
+    if (d.shadow_fp8) {
+      const float lo[4] = {wv[0], wv[1], wv[2], wv[3]}, hi[4] = {wv[4], wv[5], wv[6], wv[7]};
+      store_fp8x4(d, r, c, lo, 4);
+      store_fp8x4(d, r, c + 4, hi, 4);
+    }
+  }
+}
+
 // One virtual block of 256 threads (`vblock` of tab.blk_start[tab.n], thread `tid` of it).  Each thread owns
 // 4 consecutive elements of one row (rows are processed in 4-element groups, so a group never straddles a
 // row).  The caller maps real blocks to virtual ones: 1:1 in k_adam, a strided loop in the GEMM launch.
@@ -141,6 +236,11 @@ __device__ __forceinline__ void adam_block(const DescTable& tab, const long vblo
   while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
   t = __builtin_amdgcn_readfirstlane(t);   // vblock is wave-uniform in every caller
   const rv_param_desc d = tab.d[t];
+  if (adam_wide(d) && !grad_in_bf16) {   // wave-uniform (the descriptor is); a bf16 flat gradient comes with fp32-slab descriptors
+    adam_block_wide<UPDATE>(d, vblock - tab.blk_start[t], tid, param, m_arena, v_arena, grad_out, lr, grad_scale,
+                            step_counter, grad_out_bf16);
+    return;
+  }
   const long gpr = (d.cols + 3) / 4;  // 4-element groups per row
   const bool coop = adam_coop(d);     // bias rows with many partials: one WAVE per group
   const long blk = vblock - tab.blk_start[t];
@@ -268,7 +368,7 @@ __device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long
   t = __builtin_amdgcn_readfirstlane(t);
   const rv_param_desc d = tab.d[t];
   it.t = t;
-  if (adam_coop(d)) { it.state = 2; return it; }
+  if (adam_coop(d) || adam_wide(d)) { it.state = 2; return it; }   // adam_block's own paths
   const long gpr = (d.cols + 3) / 4;
   const long grp = (vblock - tab.blk_start[t]) * 256 + tid;
   if (grp >= gpr * d.rows) return it;
@@ -460,13 +560,16 @@ __device__ __forceinline__ void refresh_block(const DescTable& tab, const long v
   while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
   t = __builtin_amdgcn_readfirstlane(t);
   const rv_param_desc d = tab.d[t];
-  const long gpr = (d.cols + 3) / 4;
+  const bool wide = adam_wide(d);   // the table gives such tensors 8 elements per thread: two 4-element halves here
+  const long gpr = wide ? d.cols / 8 : (d.cols + 3) / 4;
   const bool coop = adam_coop(d);   // the table's block layout gives such rows one WAVE per group
   const long blk = vblock - tab.blk_start[t];
   const long grp = coop ? blk * 4 + (tid >> 6) : blk * 256 + tid;
   if (grp >= gpr * d.rows || (coop && (tid & 63) != 0)) return;
   const unsigned r32 = (unsigned)grp / (unsigned)gpr;
-  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
+  const long r = r32, c0 = (long)((unsigned)grp - r32 * (unsigned)gpr) * (wide ? 8 : 4);
+  for (int half = 0; half < (wide ? 2 : 1); ++half) {
+  const long c = c0 + 4 * half;
   const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
   const long o = d.offset + r * d.cols + c;
   float wv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -493,6 +596,7 @@ __device__ __forceinline__ void refresh_block(const DescTable& tab, const long v
   if (d.shadow_f32)
     for (int j = 0; j < nvalid; ++j) d.shadow_f32[r * d.shadow_ld + c + j] = wv[j];
   if (d.shadow_fp8) store_fp8x4(d, r, c, wv, nvalid);
+  }
 }
 
 template <bool UPDATE>
@@ -517,7 +621,7 @@ inline int adam_build_table(const rv_param_desc* descs, int n, DescTable* tab) {
     RV_REQUIRE(descs[i].rows * ((descs[i].cols + 3) / 4) < 0x7fffffffL, RV_ERR_SHAPE, "param desc %d: tensor too large", i);
     tab->blk_start[i] = blk;
     {
-      const long groups = descs[i].rows * ((descs[i].cols + 3) / 4);
+      const long groups = adam_groups(descs[i]);
       blk += adam_coop(descs[i]) ? (groups + 3) / 4 : (groups + 255) / 256;
     }
   }
