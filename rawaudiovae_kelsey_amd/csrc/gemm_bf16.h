@@ -255,10 +255,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // LDS: 2 buffers x {A half 0, A half 1, B half 0, B half 1} x 16 KiB (128 rows x 64 k).  A half is
 // restaged two or more phases after its last fragment read (the partner wave group runs a barrier
 // behind), and read two barriers after the counted vmcnt that retires its LDS-DMA.
-template <bool A_KMAJ, bool B_KMAJ>
+// `tail_hook` runs once per wave in phase 0 of the LAST K tile, where the loop has nothing left to stage: a place to
+// put LDS-DMA of epilogue operands in flight (they are retired by the loop's final vmcnt(0)).
+template <bool A_KMAJ, bool B_KMAJ, typename Hook>
 __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                   const long lda, const long ldb, const int nk, lds_char* smem,
-                                                  const int wave, const int lane, f32x4 (&acc)[8][4]) {
+                                                  const int wave, const int lane, f32x4 (&acc)[8][4], Hook tail_hook) {
   constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k half tile
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
   const int wr = wave >> 2, wc = wave & 3;
@@ -323,6 +325,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
     if constexpr (!EARLY_B) rd_b(bq, cur, 0);
     rd_a(cur, 0);
     stage_b(1, kt + 1);
+    if (kt + 1 >= nk) tail_hook();
     mma(I0{}, I0{}, bq);
     // phase 1: B(n1);  stage A-half 0 of tile kt+1
     rd_b(b1, cur, 1);
@@ -482,8 +485,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // The 256 x 256 ping-pong kernels take the ReLU mask of their wave tile (128 rows x 128 B) through LDS: each wave
+  // issues its mask pieces as LDS-DMA (1 KiB = 8 rows each; 16-byte piece c of row r lands at position c ^ (r & 7),
+  // swizzled on the source address as in the main loop) and retires them chunk by chunk with a counted vmcnt -- one
+  // round trip to memory for the whole epilogue instead of one per chunk (loads into registers, stores, next chunk's
+  // loads ...: 4 dependent round trips per wave in a tail where all 256 blocks issue theirs together).  The first
+  // chunk's pieces are put in flight during the LAST K tile, into the 32 KiB of LDS behind the two ring buffers, and
+  // have landed when the loop ends; the other three follow into the ring once it is free (epilogue).
+  constexpr bool MASK_LDS = EPI == EPI_MASK_BF16 && PINGPONG;
+  static_assert(!MASK_LDS || (WTN == 64 && CH == 2 * CM), "mask through LDS: 128-byte mask rows, as many stores as DMA pieces per chunk");
+  constexpr int MK_C0 = 2 * CM * 1024;                       // bytes of one chunk's pieces per wave (4 KiB)
+  lds_char* mk_lds = smem + wave * (WTM * 128);              // chunks 1.. : the wave's 16 KiB of the ring (first 4 KiB unused)
+  lds_char* mk_lds0 = smem + 2 * (BM + BN) * 128 + wave * MK_C0;   // chunk 0: behind the ring
+  bool mask_lds = false;
+  const bf16_t* mk_g = nullptr;
+  if constexpr (MASK_LDS) {
+    if (p.mask) {
+      mask_lds = true;
+      const int mrow = lane >> 3, mpc = (lane & 7) ^ (lane >> 3);
+      mk_g = p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8;
+    }
+  }
+  auto mask_dma = [&](int i0, int i1, lds_char* base) {     // pieces [i0, i1) of the wave tile (8 rows each)
+#pragma unroll
+    for (int i = i0; i < i1; ++i)
+      __builtin_amdgcn_global_load_lds((glb_cptr)(mk_g + (long)(8 * i) * p.ld_mask),
+                                       (__attribute__((address_space(3))) void*)(base + (i - i0) * 1024), 16, 0, 0);
+  };
   if constexpr (PINGPONG) {
-    mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc);
+    mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc, [&]() {
+      if constexpr (MASK_LDS) {
+        if (mask_lds) mask_dma(0, 2 * CM, mk_lds0);
+      }
+    });
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
@@ -676,26 +710,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // register set, last four in the second), i.e. 16-byte bf16 / 2 x 16-byte fp32 accesses, and one store
   // instruction covers 16 rows x 64 B (bf16).  Within a chunk all global LOADS are issued before the first
   // store (loads and stores share the in-order vmcnt counter).
-  // The 256 x 256 ping-pong kernels take the ReLU mask of their wave tile (128 rows x 128 B) through LDS: the ring
-  // is free now, so each wave issues ALL its mask pieces as LDS-DMA at once (16 x 1 KiB, into its own 16 KiB of the
-  // ring; 16-byte piece c of row r lands at position c ^ (r & 7), swizzled on the source address as in the main
-  // loop) and retires them chunk by chunk with a counted vmcnt -- one round trip to memory for the whole epilogue
-  // instead of one per chunk (loads into registers, stores, next chunk's loads ...: 4 dependent round trips per
-  // wave in a tail where all 256 blocks issue theirs together).
-  constexpr bool MASK_LDS = EPI == EPI_MASK_BF16 && PINGPONG;
-  static_assert(!MASK_LDS || (WTN == 64 && CH == 2 * CM), "mask through LDS: 128-byte mask rows, as many stores as DMA pieces per chunk");
-  lds_char* mk_lds = smem + wave * (WTM * 128);
-  bool mask_lds = false;
   if constexpr (MASK_LDS) {
-    if (p.mask) {
-      mask_lds = true;
-      const int mrow = lane >> 3, mpc = (lane & 7) ^ (lane >> 3);
-      const bf16_t* mg = p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8;
-#pragma unroll
-      for (int i = 0; i < WTM / 8; ++i)
-        __builtin_amdgcn_global_load_lds((glb_cptr)(mg + (long)(8 * i) * p.ld_mask),
-                                         (__attribute__((address_space(3))) void*)(mk_lds + i * 1024), 16, 0, 0);
-    }
+    if (mask_lds) mask_dma(2 * CM, WTM / 8, mk_lds + MK_C0);   // chunks 1..: the ring is free now
   }
 
   float cs[NP][8];
@@ -924,11 +940,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         if (MASK_LDS && mask_lds) {
           // this chunk's 2 * CM pieces have landed once at most (pieces of later chunks) + (stores of earlier
           // chunks) = WTM / 8 - 2 * CM vector-memory operations of this wave are outstanding (in-order counter)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MASK_LDS ? WTM / 8 - 2 * CM : 0) : "memory");
+          // chunk 0 landed inside the main loop.  A later chunk's 2 * CM pieces have landed once at most (pieces of the
+          // chunks behind it) + (stores of the chunks before it, 2 * CM each) = WTM / 8 - 2 * CM vector-memory
+          // operations of this wave are outstanding (in-order counter)
+          if (c0 != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MASK_LDS ? WTM / 8 - 2 * CM : 0) : "memory");
+          const lds_char* mb = c0 == 0 ? mk_lds0 : mk_lds;
 #pragma unroll
           for (int it = 0; it < CH; ++it) {
             const int rl = (c0 + it / NP) * 16 + ej, pc = (it % NP) * 4 + (eq & 1) * 2 + (eq >> 1);
-            mk[it] = *(const __attribute__((address_space(3))) i32x4*)(mk_lds + rl * 128 + ((pc ^ (rl & 7)) * 16));
+            mk[it] = *(const __attribute__((address_space(3))) i32x4*)(mb + rl * 128 + ((pc ^ (rl & 7)) * 16));
           }
         } else if (PF_MASK && pf_on && c0 == 0) {
 #pragma unroll

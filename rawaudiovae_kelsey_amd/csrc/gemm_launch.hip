@@ -21,12 +21,14 @@ int g_force_tile = -1;   // test hook (include/rawvae_hip_diag.h): pin one tile 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   constexpr int RING = NSTAGE == 8 ? 2 : NSTAGE;  // NSTAGE 8 = the ping-pong main loop on 2 buffers
-  constexpr int smem_max = RING * (BM + BN) * 128;
+  // the ping-pong dgrad keeps its first ReLU-mask chunk behind the ring (gemm_bf16.h MASK_LDS): 4 KiB per wave
+  constexpr int mask_extra = (NSTAGE == 8 && EPI == EPI_MASK_BF16) ? 8 * 4096 : 0;
+  constexpr int smem_max = RING * (BM + BN) * 128 + mask_extra;
   // short K loops never refill the ring: allocate only the slots they stage (but at least the
   // epilogue's staging area) so several blocks fit on a CU
   constexpr int stage_bytes = (BM + BN) * 128;
   constexpr int epi_bytes = WGM * BN * 4 + 256;  // column-sum / block-sum reductions of the epilogue
-  const int used = (NSTAGE >= 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes;
+  const int used = (NSTAGE >= 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes + mask_extra;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE, FP8>;
   static bool attr_done = false;
@@ -160,7 +162,8 @@ int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
   GemmArgs d = d_in, g = g_in;
   const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
-  constexpr int smem = 2 * (BM + BN) * 128;  // the ring; the epilogue's reductions reuse its first bytes
+  constexpr int smem = 2 * (BM + BN) * 128 + 8 * 4096;  // the ring (the epilogue's reductions reuse its first bytes) + the
+                                                         // first ReLU-mask chunk of the dgrad blocks (gemm_bf16.h MASK_LDS)
   auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
