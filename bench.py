@@ -202,9 +202,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if os.environ.get("RV_HOOK"):
-        from rawaudiovae_kelsey_amd._lib import lib as _rvlib
-        _rvlib().rv_gemm_force_tile(int(os.environ["RV_HOOK"]))
     ekw = {"slab_dtype": args.slab_dtype} if args.slab_dtype else {}
     eng = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256, **ekw)
     eng.load_params(make_params(S, H, L, 0))
