@@ -466,19 +466,20 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (full_local && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && (Hp / 256) * (Sp / 256) * p->s_w1 <= 192) {
     // Default schedule, one stream.  dW1 is the last GEMM of the backward: 32 tiles x 4 K splits of 256x256 fill
     // half the chip, so its launch also carries the optimizer step of every tensor whose gradient is already
-    // complete on the other CUs (fc3 and fc4); fc1's and the heads' updates are the step's last launch.  An
-    // optimizer block streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take
-    // to finish; the heads' update on top made the launch wait for the optimizer (profiles/r02_adam_split_sweep.txt).
+    // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
+    // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
     RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 6,
-                                4, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+    // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
+    // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
+    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
+                                8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                 p->b.step_counter, 256 - n_gemm, stream));
-    RV_TRY(rv_adam_multi(p->d_slab, 6, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     return RV_OK;
   }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side bytes per launch of every kernel of the step from the two PMC passes of tools/prof_round2.sh
+"""HBM-side bytes per launch of every kernel of the step from the two PMC passes of tools/pmc_round.sh
 (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, CSV).  FETCH_SIZE (KiB) is doubled as MI355X_MICROARCH.md 'HBM'
 prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE (KiB) is taken as is.
     python tools/traffic_summary.py gpurun_out/r02_fetch gpurun_out/r02_write profiles/r02_traffic.json"""
@@ -35,9 +35,10 @@ if dom:
     d = rows[dom[0]]
     out.update({"kernel": dom[0], "traffic_bytes": d["traffic_bytes"], "read_bytes_corrected": d["read_bytes_corrected"],
                 "write_bytes": d["write_bytes"],
-                "algorithmic_bytes": {"read": 29360128, "write": 50331648,
+                "algorithmic_bytes": {"read": 29360128, "write": 33554432 + 4 * 32 * 64 * 4,
                                       "note": "dP4, W4, h3 read once (dP4 and h3 feed both GEMMs of the pair), the h3 mask "
-                                              "is the same h3; written: dP3 bf16 16.8 MB + dW4 as 4 split-K fp32 slabs 33.5 MB"}})
+                                              "is the same h3; written: dP3 bf16 16.8 MB + dW4 as 4 split-K fp16 slabs "
+                                              "16.8 MB + their per-granule exponents (fp32 slabs: 33.5 MB)"}})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["traffic_bytes"]):
     print("%8.1f MB  (read %7.1f  write %7.1f)  %s" % (v["traffic_bytes"] / 1e6, v["read_bytes_corrected"] / 1e6, v["write_bytes"] / 1e6, k[:110]))
