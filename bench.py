@@ -68,44 +68,42 @@ def parse():
     return ap.parse_args()
 
 
-def time_dominant_kernel(eng, reps=50):
+def time_dominant_kernel(eng, x, reps=50):
     """Average duration of the step's longest kernel -- the paired fc4 backward
     (`gemm_dgrad_wgrad_kernel`: dP3 = relu'(dP4 W4) and dW4 = dP4^T h3 in one launch, 256x256 tiles)
-    -- with HIP events on the launching stream, on the step's own operands.
-    Returns (ms_per_launch, algorithmic flops per launch, description)."""
+    -- with HIP events on the launching stream.  The launch is the training plan's own (`rv_plan_step` with the
+    fc4-backward phase alone: same operands, slab type and store policy as inside the step), repeated `reps` times,
+    EACH launch between its own pair of events; the figure is the median interval.  (Events around a back-to-back run
+    of the same launch add the ~1.5-2 us kernel boundary to every launch: that figure is reported beside it.)
+    Returns (ms_per_launch, ms_per_launch_back_to_back, algorithmic flops per launch, description)."""
     import torch
-    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick, lib, stream_ptr
-    Lb = lib()
+    from rawaudiovae_kelsey_amd import engine as E
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
     Bp, Sp, Hp, Lp = eng.padded()
-    dP4 = eng.buffer("dP4", torch.bfloat16, (Bp, Sp))
-    h3 = eng.buffer("h3", torch.bfloat16, (Bp, Hp))
-    W4b = eng.buffer("W4b", torch.bfloat16, (Sp, Hp))
     paired, bm, splits = dgrad_wgrad_pick(Bp, Hp, Sp)   # what the training step itself uses
-    dP3 = torch.empty((Bp, Hp), dtype=torch.bfloat16, device="cuda")
-    cs = torch.empty((Bp // bm) * Hp, dtype=torch.float32, device="cuda")
-    dW4 = torch.empty(splits * Sp * Hp, dtype=torch.float32, device="cuda")
-    half = eng.slab_dtype == "fp16"      # the slab element type the step itself uses
-    us = torch.empty(splits * (Sp // 32) * (Hp // 32), dtype=torch.float32, device="cuda")
-    st = stream_ptr()
-    ts = torch.cuda.current_stream()      # the stream the launches below go to (`st` is its handle)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
+    ts = torch.cuda.current_stream()
 
     def launch():
-        Lb.rv_linear_dgrad_wgrad_ex(dP4.data_ptr(), Sp, W4b.data_ptr(), Hp, h3.data_ptr(), Hp, Bp, Hp, Sp,
-                                    dP3.data_ptr(), Hp, cs.data_ptr(), dW4.data_ptr(), Hp, splits, int(half),
-                                    us.data_ptr() if half else None, st)
+        eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
     for _ in range(5):
         launch()
-    e0.record(ts)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]   # HIP events
+    for e0, e1 in ev:
+        e0.record(ts)
+        launch()
+        e1.record(ts)
+    ts.synchronize()
+    each = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record(ts)
     for _ in range(reps):
         launch()
-    e1.record(ts)
-    e1.synchronize()
-    ms = C.c_float(e0.elapsed_time(e1))
+    b1.record(ts)
+    b1.synchronize()
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
-    return ms.value / reps, 4.0 * S * H * B, desc
+    return each[len(each) // 2], b0.elapsed_time(b1) / reps, 4.0 * S * H * B, desc
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -575,7 +573,7 @@ def main():
                 alt = {"grad_allreduce": "bf16 payload, same schedule", "error": str(exc)[:200]}
             finally:
                 runner.set_payload("fp32")
-        kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng) if rank == 0 else (None, None, None)
+        kern_ms, kern_b2b_ms, kern_flops, kern_cfg = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None, None)
         # Side lines, never the headline: the same K steps on engines with opt-in reduced-precision storage
         alts = {}
         if world == 1 and not args.no_alts:
@@ -669,7 +667,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "us_per_launch": kern_ms * 1e3},
+                         "us_per_launch": kern_ms * 1e3, "us_per_launch_back_to_back": kern_b2b_ms * 1e3,
+                         "timing": "median of 50 launches of the plan's fc4-backward phase, each between its own pair of HIP "
+                                   "events on the launching stream; back_to_back = one event pair around 50 launches"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.torch_port import cpu_description, time_cpu_step

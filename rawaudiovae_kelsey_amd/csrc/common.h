@@ -38,6 +38,35 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return r;
 }
 
+// 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc0 sc1): the line goes to memory as the store retires instead
+// of staying dirty in the XCD's L2 until the end-of-kernel release writes everything back at once.  Every kernel of
+// the step ends with a burst of output stores (8-34 MB) that nothing in the same launch reads again, and the next
+// kernel runs on all XCDs, so keeping the lines in the writer's L2 buys nothing while the flush at the kernel
+// boundary costs bytes / ~6 TB/s with the chip idle (MI355X_MICROARCH.md price list, row "boundary"; "publish-large").
+// Measured on the whole step, same box: 190.8 -> 184.9 us (profiles/r03_ab_step.txt).  16-byte stores only: narrower
+// write-through stores cost 2.7-12x per byte (same guide, stores table).
+// Whether a launch uses them is the CALLER's choice (rv_store_wt, set by the training plan around its launches): a chain
+// of same-shaped GEMMs whose blocks land on the XCD that holds their input rows (the deep variant's H x H layers)
+// loses more from dropping the lines than it gains (deep C4 step 858 -> 951 us with write-through everywhere).
+extern thread_local int rv_store_wt;   // host side, gemm_launch.hip: non-zero = epilogue outputs written through
+
+template <typename V>
+__device__ __forceinline__ void store_wt16(V* dst, const V& v) {
+  static_assert(sizeof(V) == 16, "write-through stores are 16 bytes per lane");
+  const f32x4 r = __builtin_bit_cast(f32x4, v);
+  // the s_nop: a store of more than 64 bits reads its data registers a cycle after issue, and a VALU write to them in
+  // the very next slot would be seen by the store (a hazard the compiler pads for its own stores, but it cannot see
+  // inside an asm: without the pad 5 % of a 256 x 256 slab came out with elements of the NEXT store's values)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(r) : "memory");
+}
+
+// 16-byte output store: write-through when `wt` (wave-uniform), a plain store otherwise
+template <typename V>
+__device__ __forceinline__ void store_out16(V* dst, const V& v, const int wt) {
+  if (wt) store_wt16(dst, v);
+  else *dst = v;
+}
+
 // tanh(y) = 1 - 2/(1+exp(2y)); abs error ~2e-7 (v_exp_f32 and v_rcp_f32, 1 ulp each), saturates cleanly.
 // v_rcp_f32 directly: __frcp_rn is the correctly rounded reciprocal, a ten-instruction sequence per element.
 __device__ __forceinline__ float fast_tanh(float y) {

@@ -95,6 +95,7 @@ struct GemmArgs {
   bf16_t* a_copy;
   long ld_copy;
   long long* step_inc;   // EPI_BIAS_ACT_BF16: block 0 bumps the device step counter (the step's first kernel does)
+  int wt;                // non-zero: the epilogue's outputs are written through (common.h store_wt16; the launchers copy rv_store_wt)
 };
 
 template <int ROWS>
@@ -546,7 +547,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           const int t = wave + NW * i;
           const int r = 8 * t + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
           const bf16x8 v_ = *(const __attribute__((address_space(3))) bf16x8*)(slot_ + t * 1024 + lane * 16);
-          *(bf16x8*)(p.a_copy + (m0 + r) * p.ld_copy + (long)kt * 64 + c * 8) = v_;
+          store_out16((bf16x8*)(p.a_copy + (m0 + r) * p.ld_copy + (long)kt * 64 + c * 8), v_, p.wt);
         }
       }
     }
@@ -810,7 +811,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           tt[e] = __builtin_fmaxf(v[it][e] + bias[it % NP][e], floor_);
           o[e] = (bf16_t)tt[e];
         }
-        *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
+        store_out16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.wt);
         if (p.out_fp8 || p.amax_part) {   // fp8 forward only
           float q8[8];
 #pragma unroll
@@ -833,10 +834,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           f16x8 h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h[e] = (_Float16)(lo[e] * f16s); h[4 + e] = (_Float16)(hi[e] * f16s); }
-          *(f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]) = h;
+          store_out16((f16x8*)((_Float16*)p.out_f16 + split * p.split_stride_f32 + rowi[it] * p.ld_f32 + coli[it]), h, p.wt);
         } else {
-          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]) = lo;
-          *(f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4) = hi;
+          store_out16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it]), lo, p.wt);
+          store_out16((f32x4*)(out + rowi[it] * p.ld_f32 + coli[it] + 4), hi, p.wt);
         }
       }
     } else if constexpr (EPI == EPI_TANH_LOSS) {
@@ -919,11 +920,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             o[e] = (bf16_t)g;
           }
         }
-        if (p.x) *(bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col) = o;
+        if (p.x) store_out16((bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col), o, p.wt);
         if (p.recon && rv_) {
           if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
-            *(f32x4*)(p.recon + r * p.ld_recon + col) = f32x4{rec[0], rec[1], rec[2], rec[3]};
-            *(f32x4*)(p.recon + r * p.ld_recon + col + 4) = f32x4{rec[4], rec[5], rec[6], rec[7]};
+            store_out16((f32x4*)(p.recon + r * p.ld_recon + col), f32x4{rec[0], rec[1], rec[2], rec[3]}, p.wt);
+            store_out16((f32x4*)(p.recon + r * p.ld_recon + col + 4), f32x4{rec[4], rec[5], rec[6], rec[7]}, p.wt);
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -972,7 +973,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             o[2 * w] = (bf16_t)t0;
             o[2 * w + 1] = (bf16_t)t1;
           }
-          *(bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]) = o;
+          store_out16((bf16x8*)(p.out_bf16 + rowi[it] * p.ld_bf16 + coli[it]), o, p.wt);
         }
       }
     }

@@ -5,6 +5,10 @@
 
 using namespace rv;
 
+namespace rv {
+thread_local int rv_store_wt = 0;   // see common.h; set by plan.hip around the training step's launches
+}
+
 namespace {
 
 // Tile configurations (block tile, wave grid, LDS ring depth):
@@ -37,6 +41,7 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
     attr_done = true;
   }
   GemmArgs g = a;
+  g.wt = rv_store_wt;
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
   g.splits = splits;
@@ -161,6 +166,7 @@ template <int NSTAGE>
 int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
   GemmArgs d = d_in, g = g_in;
+  d.wt = g.wt = rv_store_wt;
   const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
   constexpr int smem = 2 * (BM + BN) * 128 + 8 * 4096;  // the ring (the epilogue's reductions reuse its first bytes) + the
                                                          // first ReLU-mask chunk of the dgrad blocks (gemm_bf16.h MASK_LDS)
@@ -192,6 +198,7 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
     attr_done = true;
   }
   GemmArgs g1 = a, g2 = b;
+  g1.wt = g2.wt = rv_store_wt;
   g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
   g2.tiles_m = (int)(Mp2 / BM); g2.tiles_n = (int)(Np2 / BN); g2.splits = splits2;
   const int n1 = g1.tiles_m * g1.tiles_n * splits1, n2 = g2.tiles_m * g2.tiles_n * splits2;
@@ -473,7 +480,7 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
   g.k_tiles = (int)(Kp / 64 / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np;
   rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
-  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits;
+  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.wt = rv_store_wt;
   const int n_gemm = g.tiles_m * g.tiles_n * splits;
   constexpr int smem = 2 * (256 + 256) * 128;
   static_assert(8 * 2 * AS_SLOT <= smem, "the optimizer waves' LDS rings live in the launch's dynamic LDS");

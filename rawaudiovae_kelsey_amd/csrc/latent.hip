@@ -69,7 +69,7 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
              const float* __restrict__ b3, const long Hp, const long B, const long L,
              const float* __restrict__ eps_in, float* __restrict__ eps_out, const uint64_t seed,
              const long long* __restrict__ step_counter, float* __restrict__ mulv, bf16_t* __restrict__ z,
-             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3) {
+             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3, const int wt) {
   constexpr long Lp = 64, L2p = 128;
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   lds_char* smem = (lds_char*)smem_dyn;
@@ -261,7 +261,7 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
         o[e] = (bf16_t)lo[e];
         o[4 + e] = (bf16_t)hi[e];
       }
-      *(bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8) = o;
+      store_out16((bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
     }
     asm volatile("" ::: "memory");
   }
@@ -296,7 +296,7 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
   hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

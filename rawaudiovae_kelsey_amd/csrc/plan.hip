@@ -362,10 +362,18 @@ int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
   return RV_OK;
 }
 
+// Launches issued inside a plan call write their epilogue outputs through (common.h store_wt16): scope guard
+struct WtScope {
+  int prev;
+  WtScope() : prev(rv::rv_store_wt) { rv::rv_store_wt = 1; }
+  ~WtScope() { rv::rv_store_wt = prev; }
+};
+
 int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float* recon_out,
                  float kl_beta, float lr, float grad_scale, int adam_from_flat,
                  unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step: plan not bound");
+  WtScope wt_scope;
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
   void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
@@ -735,6 +743,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
   RV_REQUIRE((p->allreduce || p->reduce_scatter) && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
+  WtScope wt_scope;
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (PHASE_ADAM, PHASE_ADAM_A, PHASE_ADAM_B, PHASE_ALL_LOCAL, PHASE_ANY_ADAM, PHASE_BWD_A,
-                   PHASE_BWD_B, PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr,
+                   PHASE_BWD_B, PHASE_BWD_CHAIN, PHASE_BWD_FC4, PHASE_BWD_REST, PHASE_FINALIZE_A, PHASE_FINALIZE_B, PHASE_FWD, PlanBuffers, lib, ptr,
                    stream_ptr)
 
 def _ops_invalidate():
