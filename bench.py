@@ -72,29 +72,25 @@ def time_dominant_kernel(eng, x, reps=50):
     """Average duration of the step's longest kernel -- the paired fc4 backward
     (`gemm_dgrad_wgrad_kernel`: dP3 = relu'(dP4 W4) and dW4 = dP4^T h3 in one launch, 256x256 tiles)
     -- with HIP events on the launching stream.  The launch is the training plan's own (`rv_plan_step` with the
-    fc4-backward phase alone: same operands, slab type and store policy as inside the step), repeated `reps` times,
-    EACH launch between its own pair of events; the figure is the median interval.  (Events around a back-to-back run
-    of the same launch add the ~1.5-2 us kernel boundary to every launch: that figure is reported beside it.)
-    Returns (ms_per_launch, ms_per_launch_back_to_back, algorithmic flops per launch, description)."""
+    fc4-backward phase alone: same operands, slab type and store policy as inside the step), `reps` launches back to
+    back between ONE pair of events: the figure contains the kernel boundary (each launch starts while the previous
+    one's 33 MB of output is still on its way to memory), so it is 2-3 us above rocprofv3's per-kernel duration of
+    the same launch inside the step (profiles/rNN_*_kernel_stats.csv).  Bracketing every launch with its own event
+    pair is worse, not better: an event record in a busy stream costs a ~6 us bubble (measured: 37-41 us).
+    Returns (ms_per_launch, algorithmic flops per launch, description)."""
     import torch
     from rawaudiovae_kelsey_amd import engine as E
     from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
     Bp, Sp, Hp, Lp = eng.padded()
     paired, bm, splits = dgrad_wgrad_pick(Bp, Hp, Sp)   # what the training step itself uses
     ts = torch.cuda.current_stream()
+    eng.step(x, phases=E.PHASE_FWD, stream=ts)          # operands as the step leaves them
 
     def launch():
         eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
     for _ in range(5):
         launch()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]   # HIP events
-    for e0, e1 in ev:
-        e0.record(ts)
-        launch()
-        e1.record(ts)
-    ts.synchronize()
-    each = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
     b0.record(ts)
     for _ in range(reps):
         launch()
@@ -103,7 +99,7 @@ def time_dominant_kernel(eng, x, reps=50):
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
-    return each[len(each) // 2], b0.elapsed_time(b1) / reps, 4.0 * S * H * B, desc
+    return b0.elapsed_time(b1) / reps, 4.0 * S * H * B, desc
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -573,7 +569,7 @@ def main():
                 alt = {"grad_allreduce": "bf16 payload, same schedule", "error": str(exc)[:200]}
             finally:
                 runner.set_payload("fp32")
-        kern_ms, kern_b2b_ms, kern_flops, kern_cfg = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None, None)
+        kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None)
         # Side lines, never the headline: the same K steps on engines with opt-in reduced-precision storage
         alts = {}
         if world == 1 and not args.no_alts:
@@ -667,9 +663,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kern_cfg,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "us_per_launch": kern_ms * 1e3, "us_per_launch_back_to_back": kern_b2b_ms * 1e3,
-                         "timing": "median of 50 launches of the plan's fc4-backward phase, each between its own pair of HIP "
-                                   "events on the launching stream; back_to_back = one event pair around 50 launches"},
+                         "us_per_launch": kern_ms * 1e3,
+                         "timing": "one pair of HIP events around 50 back-to-back launches of the plan's fc4-backward phase "
+                                   "(kernel boundary included; rocprofv3's per-kernel duration is 2-3 us shorter)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.torch_port import cpu_description, time_cpu_step
