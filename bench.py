@@ -139,7 +139,7 @@ def time_deep_c4(dev, comp, steps, warmup):
         def launch():
             Lb.rv_linear_dgrad_wgrad(ptr(eng.d_dec[depth - 1]), Hp, ptr(eng.shadow[wname]), Hp, ptr(eng.dec_act[depth - 2]), Hp,
                                      Bp, Hp, Hp, ptr(eng.d_dec[depth - 2]), Hp, ptr(eng.bias_part["dec.%d.bias" % (depth - 2)]),
-                                     ptr(eng.slabs[wname]), Hp, eng.splits[wname], st)
+                                     ptr(eng.slabs[wname]), Hp, eng.splits[wname], 0, None, st)
         for _ in range(5):
             launch()
         e0.record(comp)

@@ -49,13 +49,15 @@ const char* rv_last_error(void);
 /* Padded extents used by every bf16 operand: Bp, Sp, Hp multiples of 128, Lp of 64. */
 int rv_pad_dims(long B, long S, long H, long L, long* Bp, long* Sp, long* Hp, long* Lp);
 
-/* GEMM tiling decisions, exposed because callers size partial-sum buffers from them.
- * rv_gemm_pick: recommended split-K count (<= max_splits, power of two) and the block tile
- * (bm x bn) for a padded Mp x Np x Kp GEMM.  rv_gemm_tile: the tile the library uses when a
- * GEMM is launched with a given split count; per-row-tile outputs (column-sum partials,
- * MSE partials) then have Mp/bm row tiles and Np/bn column tiles. */
-int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
-int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
+/* GEMM tiling decisions, exposed because callers size partial-sum buffers from them (NULL outputs are skipped):
+ *   RV_PLAN_GEMM  recommended split-K count *splits (<= splits_in, a power of two) and block tile (*bm x *bn) of a
+ *                 padded Mp x Np x Kp GEMM;
+ *   RV_PLAN_TILE  the tile the library uses when that GEMM is launched with exactly splits_in splits; per-row-tile
+ *                 outputs (column-sum partials, MSE partials) then have Mp / bm row tiles and Np / bn column tiles;
+ *   RV_PLAN_PAIR  for rv_linear_dgrad_wgrad(Mp, Np, Kp): *paired (one 256 x 256 launch for both GEMMs), the row tile
+ *                 *bm of its column-sum partials and the weight gradient's split count *splits. */
+enum { RV_PLAN_GEMM = 0, RV_PLAN_TILE = 1, RV_PLAN_PAIR = 2 };
+int rv_gemm_plan(int what, long Mp, long Np, long Kp, int splits_in, int* bm, int* bn, int* splits, int* paired);
 
 /* fp32 [rows, cols] (leading dim ld_src) -> zero-padded bf16 [rows_p, cols_p] (leading dim ld_dst).
  * Replaces the implicit fp32 operand read of F.linear (model.py:20) for frames and
@@ -92,7 +94,7 @@ int rv_linear_fp32(const float* x, long ldx, const float* w, long ldw, const flo
  *   if x != NULL: mse_partial[block] = sum (recon-x)^2 over the block's valid elements
  *                 dP4 bf16 [Bp,Sp]   = (2/(B*S)) (recon-x)(1-recon^2)   (0 in padding)
  *                 db4_partial [Bp/bm][Sp] column sums of dP4 (optional)
- * with (bm, bn) = rv_gemm_tile(Bp, Sp, 1): n_mse_partials = (Bp/bm)*(Sp/bn). */
+ * with (bm, bn) = rv_gemm_plan(RV_PLAN_TILE, Bp, Sp, Hp, 1, ...): n_mse_partials = (Bp/bm)*(Sp/bn). */
 int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, long ldw,
                            const float* b4, long Bp, long Sp, long Hp, long B, long S,
                            const float* x, long ldx, float* recon, long ld_recon,
@@ -103,26 +105,33 @@ int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, l
  * ([out,in] layout, consumed as-is through transposing LDS reads).
  *   mask != NULL : dx_bf16 = (mask > 0) ? dX : 0   (ReLU', threshold_backward) and
  *                  colsum_partial [Mp/bm][Np] (optional) = column sums = bias grads,
- *                  bm from rv_gemm_tile(Mp, Np, 1)
+ *                  bm from rv_gemm_plan(RV_PLAN_TILE, Mp, Np, Kp, 1, ...)
  *   mask == NULL : dx_f32 written as `splits` fp32 partial slabs [Mp,Np]. */
 int rv_linear_dgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, long Mp,
                     long Np, long Kp, const void* mask_bf16, long ldmask, void* dx_bf16,
                     long lddx, float* colsum_partial, float* dx_f32, long lddx32, int splits,
                     void* stream);
 
+/* Split-K slab element type of a weight gradient: fp32, or block-floating-point fp16 -- fp16(partial * 2^e) with
+ * one exponent e per wave tile of one slab, taken from that tile's own largest magnitude, so gradients of ANY
+ * magnitude keep fp16's 11 significant bits relative to their tile (same element strides as fp32 slabs).  The GEMM
+ * writes the factors that undo the scales, 2^-e, to `slab_unscale`: [splits][Mp / 32][Np / 32] fp32, one per
+ * 32 x 32 granule of each slab (required with RV_SLAB_F16, ignored with RV_SLAB_F32).  The sum over slabs stays fp32
+ * in rv_adam_multi / rv_grad_finalize, which are told by rv_param_desc.grad_half / grad_unscale.  Halves the bytes
+ * the GEMM writes and the optimizer reads back. */
+enum { RV_SLAB_F32 = 0, RV_SLAB_F16 = 1 };
+
 /* Both halves of a Linear layer's backward in ONE launch when the extents allow 256x256 tiles
  * (neither GEMM alone has enough such tiles to fill 256 CUs; together they do):
  *   dx_bf16 [Mp,Np] = (x > 0) ? dY W : 0     with column-sum partials [Mp/bm][Np] (bias grads)
  *   dw_slabs [splits][Kp][Np] = dY^T x        (split over the batch)
  * dy [Mp(batch), Kp(out)], w [Kp, Np] ([out,in]), x [Mp, Np] = the layer's ReLU output (mask AND
- * wgrad operand).  `splits` and `bm` must come from rv_dgrad_wgrad_pick(Mp, Np, Kp); when the
+ * wgrad operand).  `splits` and `bm` must come from rv_gemm_plan(RV_PLAN_PAIR, Mp, Np, Kp, ...); when the
  * 256x256 pairing does not apply (e.g. the heads: Kp = 2 Lp) the two GEMMs still go out in one
  * launch if they share a small tile, otherwise as rv_linear_dgrad + rv_linear_wgrad. */
-int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits);
-int rv_linear_dgrad_wgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw,
-                          const void* x_bf16, long ldx, long Mp, long Np, long Kp, void* dx_bf16,
-                          long lddx, float* colsum_partial, float* dw_slabs, long lddw, int splits,
-                          void* stream);
+int rv_linear_dgrad_wgrad(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
+                          long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial, void* dw_slabs,
+                          long lddw, int splits, int slab_dtype, float* slab_unscale, void* stream);
 
 /* Backward of a Linear layer whose input had no activation (fc3, whose input is z): dX = dY W as
  * `dgrad_splits` fp32 slabs [Mp, Np] and dW = dY^T X as `wgrad_splits` slabs [Kp, Np], in ONE launch
@@ -133,25 +142,14 @@ int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16
                               long lddx, int dgrad_splits, float* dw_slabs, long lddw, int wgrad_splits,
                               void* stream);
 
-/* dW = dY^T X as `splits` fp32 partial slabs [Mp(out), Np(in)] (split over the batch).
+/* dW = dY^T X as `splits` partial slabs [Mp(out), Np(in)] (split over the batch) of element type slab_dtype.
  * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS
- * reads.  Autograd of F.linear w.r.t. weight, train.py:191. */
-int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp,
-                    long Np, long Kp, int splits, float* dw_f32_slabs, long lddw, void* stream);
-/* Split-K slab element type of a weight gradient: fp32, or block-floating-point fp16 -- fp16(partial * 2^e) with
- * one exponent e per wave tile of one slab, taken from that tile's own largest magnitude, so gradients of ANY
- * magnitude keep fp16's 11 significant bits relative to their tile (same element strides as fp32 slabs).  The GEMM
- * writes the factors that undo the scales, 2^-e, to `slab_unscale`: [splits][Mp / 32][Np / 32] fp32, one per
- * 32 x 32 granule of each slab (required with RV_SLAB_F16, ignored with RV_SLAB_F32).  The sum over slabs stays fp32
- * in rv_adam_multi / rv_grad_finalize, which are told by rv_param_desc.grad_half / grad_unscale.  Halves the bytes
- * the GEMM writes and the optimizer reads back. */
-enum { RV_SLAB_F32 = 0, RV_SLAB_F16 = 1 };
-/* rv_linear_wgrad with every option: a named block tile instead of the picker's choice (extents must be multiples of
- * it; `splits` must divide Kp/64; RV_TILE_256x256 runs the ping-pong main loop when Kp/64/splits is even) and the
- * slab element type. */
+ * reads.  Autograd of F.linear w.r.t. weight, train.py:191.  `tile`: RV_TILE_AUTO (the picker's choice) or a named
+ * block tile (extents must be multiples of it; `splits` must divide Kp/64; RV_TILE_256x256 runs the ping-pong main
+ * loop when Kp/64/splits is even). */
 enum { RV_TILE_AUTO = -1, RV_TILE_64x64 = 0, RV_TILE_128x128 = 4, RV_TILE_256x128 = 2, RV_TILE_256x256 = 7 };
-int rv_linear_wgrad_ex(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
-                       int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale, void* stream);
+int rv_linear_wgrad(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
+                    int splits, int tile, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale, void* stream);
 
 /* Reparameterisation forward, model.py:23-26, fused with the KL half of
  * loss_function (model.py:45):
@@ -189,7 +187,7 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
  * [Bp][Hp]); mu / logvar differ from the split-K route by fp32 summation order only; eps draws and the KL partial
  * layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a padded hidden width that is not a multiple
  * of 512 up to 2048.  18.8 us against 21-22 us for the three launches at C2 (profiles/r03_*): the training plan's
- * default where it applies (rv_plan_set_latent_fused). */
+ * default where it applies (rv_plan_set_option, RV_OPT_LATENT_FUSED). */
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
@@ -288,15 +286,18 @@ typedef struct rv_param_desc {
  * updates exp_avg / exp_avg_sq / param, rewrites the bf16 shadow, and (optional)
  * stores the summed gradient to grad_out (flat, exact) for inspection.
  * t = *step_counter (1-based).  grad_scale multiplies the summed gradient first
- * (1/world_size after an all-reduce SUM).  `descs` is HOST memory (copied per call). */
+ * (1/world_size after an all-reduce SUM).  `descs` is HOST memory (copied per call).
+ * grad_bf16 != NULL: the gradient is taken from that flat bf16 arena (same element offsets as the fp32 arenas; a bf16
+ * all-reduce's result) instead of the descriptors' slabs; grad_out must then be NULL. */
 int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
-                  float* exp_avg_sq, float* grad_out, float lr, float grad_scale,
+                  float* exp_avg_sq, float* grad_out, const void* grad_bf16, float lr, float grad_scale,
                   const long long* step_counter, void* stream);
 
 /* Sum gradient slabs into the flat exact-shape gradient arena only (no update):
- * what loss.backward() leaves in .grad; also the all-reduce payload builder. */
-int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream);
-/* dW = dY^T X on 256x256 tiles (as rv_linear_wgrad_tile with RV_TILE_256x256) in a launch that ALSO runs the
+ * what loss.backward() leaves in .grad; also the all-reduce payload builder.  out_bf16 != 0: grad_out is a flat
+ * bf16 arena (same element offsets) and receives the fp32 sum rounded to bf16 -- half the all-reduce bytes. */
+int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, void* stream);
+/* dW = dY^T X on 256x256 tiles (as rv_linear_wgrad with RV_TILE_256x256) in a launch that ALSO runs the
  * fused Adam update (rv_adam_multi) of the `n_desc` tensors in `descs` -- tensors whose gradients earlier
  * launches completed, never the one this GEMM produces -- on `n_adam_blocks` extra 512-thread blocks that take
  * the CUs the GEMM's tiles * splits blocks leave idle (extents must tile by 256 x 256 x 64). */
@@ -331,15 +332,6 @@ int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* g
 int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
                         void* stream);
 
-/* bf16 variants for the data-parallel exchange (halves the all-reduce bytes; the in-rank sums stay
- * fp32): rv_grad_finalize_bf16 rounds the summed gradient to a flat bf16 arena (same element offsets
- * as the fp32 arenas); rv_adam_multi_bf16grad takes the gradient from such an arena (after its
- * all-reduce) instead of the descriptors' slabs. */
-int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out_bf16, void* stream);
-int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
-                           float* exp_avg_sq, const void* grad_bf16, float lr, float grad_scale,
-                           const long long* step_counter, void* stream);
-
 /* ---- fp8 (e4m3, OCP) operand path for the two large forward GEMMs (BASELINE configs[4]; a build extension,
  * the reference has no reduced-precision path).  Operands are quantised per tensor:
  * q = fp8(value * scale), the GEMM accumulates in fp32 on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
@@ -348,26 +340,6 @@ int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param,
 /* fp32 [rows, cols] -> zero-padded fp8 [rows_p, cols_p]: fp8(src * *scale), saturating at +-448. */
 int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* dst_fp8, long rows_p, long cols_p,
                     long ld_dst, const float* scale, void* stream);
-/* rv_cast_pad_bf16 that also writes the fp8 operand (dst_fp8 may be NULL) and, when `fp8_state` is given, latches
- * the delayed activation scale for this step in its first wave from the previous step's per-block maxima
- * `amax_part[n_amax]` (see rv_plan_set_fp8 for the state block's layout). */
-int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long rows_p,
-                        long cols_p, long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state,
-                        const float* amax_part, int n_amax, long long* step_counter, void* stream);
-/* rv_linear_fwd / rv_decode_out_loss_fwd on fp8 operands. */
-/* rv_linear_fwd with every optional output of a bias/ReLU forward GEMM (NULL = not wanted): the output also as
- * fp8(y * *q_scale) (the next layer's fp8 operand) and max|y| of every block in amax_part[block] (rv_gemm_tile gives
- * the block count: (Mp/bm)*(Np/bn)), from which the next step derives its scale (delayed scaling). */
-int rv_linear_fwd_ex(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp, long Np,
-                     long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8, const float* q_scale,
-                     float* amax_part, void* stream);
-/* rv_linear_dgrad_wgrad with the slab element type of the weight gradient (RV_SLAB_*). */
-int rv_linear_dgrad_wgrad_ex(const void* dy_bf16, long lddy, const void* w_bf16, long ldw, const void* x_bf16, long ldx,
-                             long Mp, long Np, long Kp, void* dx_bf16, long lddx,
-                             float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype,
-                             float* slab_unscale, void* stream);
-int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias, const float* dq,
-                      long Mp, long Np, long Kp, int act, void* y_bf16, long ldy, void* stream);
 /* rv_linear_fwd whose operand rows are read where the audio lives (AudioDataset.__getitem__,
  * rawvae/dataset.py:108-118): row r < B is the frame audio_bf16[f*hop : f*hop + Kp], f = frame_index ? frame_index[r]
  * : first_frame + r, of the waveform kept in HBM as bf16 (cast once when it was uploaded; rounding to bf16 is what
@@ -381,11 +353,6 @@ int rv_linear_fwd_frames(const void* audio_bf16, const long long* frame_index, l
                          const void* w_bf16, long ldw, const float* bias, long Mp, long Np, long Kp, int act,
                          void* y_bf16, long ldy, void* frames_bf16, long ld_frames, long long* step_counter,
                          void* stream);
-int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
-                               const float* dq, long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx,
-                               float* recon, long ld_recon, void* dP4_bf16, long ld_dp4, float* mse_partial,
-                               float* db4_partial, void* stream);
-
 /* ---- whole-step plan: one call enqueues forward, loss, backward (and Adam) ---- */
 typedef struct rv_plan rv_plan;
 
@@ -422,10 +389,25 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L);
 void rv_plan_destroy(rv_plan*);
 long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
-/* 1 (default): heads GEMM, reparameterisation and fc3 of the forward are ONE launch (rv_latent_fwd) when the padded
- * latent width is 64, the padded hidden width a multiple of 512 up to 2048 and the fp8 path off; 0, or any other
- * shape: three launches (rv_heads_reparam_fwd + fc3). */
-int rv_plan_set_latent_fused(rv_plan*, int enable);
+/* Plan options (the plan must be bound):
+ *   RV_OPT_LATENT_FUSED  1 (default): heads GEMM, reparameterisation and fc3 of the forward are ONE launch
+ *     (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 up to 2048 and the
+ *     fp8 path off; 0, or any other shape: three launches (rv_heads_reparam_fwd + fc3).
+ *   RV_OPT_FP8  1: fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay
+ *     bf16).  The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
+ *       [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
+ *       [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
+ *           "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
+ *       [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
+ *       [7] non-zero: keep [3] fixed (parity runs).
+ *     Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them.
+ *   RV_OPT_SLAB_DTYPE  element type of the split-K slabs of the two large weight gradients (fc1.weight, fc4.weight;
+ *     2 x 33.5 MB of fp32 slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see above), which
+ *     halves what the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32
+ *     sum over a quarter of the batch; rounding it to fp16 adds ~3e-4 relative noise to those two gradients whatever
+ *     their magnitude (the sum over slabs stays fp32). */
+enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2 };
+int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and
  * dlogvar [B,L], all exact-shape fp32, each NULL = zero; the reparameterisation backward then takes kl_beta from
@@ -434,21 +416,6 @@ int rv_plan_set_latent_fused(rv_plan*, int enable);
  * phase.  Not honoured by the full-step schedules (phases == RV_PHASE_ALL_LOCAL). */
 int rv_plan_set_external_grads(rv_plan*, const float* d_recon, const float* recon, const float* dmu,
                                const float* dlogvar, float* grad_out);
-/* fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay bf16).
- * The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
- *   [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
- *   [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
- *       "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
- *   [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
- *   [7] non-zero: keep [3] fixed (parity runs).
- * Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them. */
-int rv_plan_set_fp8(rv_plan*, int enable);
-/* Element type of the split-K slabs of the two large weight gradients (fc1.weight, fc4.weight; 2 x 33.5 MB of fp32
- * slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see RV_SLAB_F16 above), which halves what
- * the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32 sum over a
- * quarter of the batch; rounding it to fp16 adds ~3e-4 relative noise to those two gradients whatever their
- * magnitude (the sum over slabs stays fp32). */
-int rv_plan_set_slab_dtype(rv_plan*, int slab_dtype);
 /* The plan's ten parameter descriptors (PARAM order): gradient slabs of its own workspace (from_flat = 0) or the
  * bound flat gradient arena (1), and the operand shadows Adam must refresh.  For callers that drive
  * rv_adam_multi / rv_params_from_flat themselves. */
@@ -473,15 +440,6 @@ int rv_plan_step_frames(rv_plan*, int phases, const float* audio, const void* au
                         const long long* frame_index, long first_frame, long hop, const float* eps, float* recon_out,
                         float kl_beta, float lr, float grad_scale, int adam_from_flat, unsigned long long seed,
                         void* stream);
-int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
-                          long n_frames, long S, long hop, void* dst_bf16, long rows_p, long cols_p, long ld_dst,
-                          void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part, int n_amax,
-                          long long* step_counter, void* stream);
-int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4, const float* dq,
-                                  long Bp, long Sp, long Hp, long B, long S, const float* audio, long n_samples,
-                                  const long long* frame_index, long first_frame, long hop, float* recon, long ld_recon,
-                                  void* dP4_bf16, long ld_dp4, float* mse_partial, float* db4_partial, void* stream);
-
 /* ---- data-parallel step with the collective driven from here (no reference code:
  * the reference is single-process).  `allreduce` is the collective library's in-place-capable
  * all-reduce with RCCL's ncclAllReduce signature -- (sendbuf, recvbuf, count, dtype, op, comm, stream),
@@ -493,42 +451,47 @@ int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long
  * no host synchronisation, capturable in a hipGraph.  Needs a grad arena and a non-default stream. */
 typedef int (*rv_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
                                void* comm, void* stream);
-int rv_plan_attach_comm(rv_plan*, rv_allreduce_fn allreduce, void* comm, int world);
 /* Sharded mode of rv_plan_step_ddp (optimizer state and update sharded over the ranks): per gradient bucket
  * (0: fc4 = arena elements [offset of fc4.weight, n_params); 1: everything before it) the flat fp32 gradients are
  * REDUCE-SCATTERED (each rank receives the sum of its `rv_plan_shard_count` elements), the rank runs Adam on its shard
- * only (rv_adam_flat), the updated fp32 parameters are ALL-GATHERED and every rank rebuilds its parameters and bf16
- * shadows from the gathered buffer (rv_params_from_flat).  Per rank: 1/world of Adam's 30 B/param instead of all of
- * it, the same bytes on the links as an all-reduce.  exp_avg / exp_avg_sq are valid on their owner rank only.
- * `reduce_scatter` / `all_gather` have RCCL's ncclReduceScatter / ncclAllGather signatures.  The caller owns
- * rs_buf (sum over the buckets of rv_plan_shard_count floats) and ag_buf (world times that), and its param / grad
- * arenas must extend 4 * world elements past n_params (a bucket is cut into `world` equal shards of a multiple of 4
- * elements, so the last shard can overhang its bucket). */
+ * only (rv_adam_flat), the updated parameters are ALL-GATHERED and every rank rebuilds its operand shadows from the
+ * gathered buffer.  Per rank: 1/world of Adam's 30 B/param instead of all of it, the same bytes on the links as an
+ * all-reduce.  exp_avg / exp_avg_sq are valid on their owner rank only.  `reduce_scatter` / `all_gather` have RCCL's
+ * ncclReduceScatter / ncclAllGather signatures. */
 typedef int (*rv_reduce_scatter_fn)(const void* sendbuf, void* recvbuf, size_t recvcount, int dtype, int op, void* comm,
                                     void* stream);
 typedef int (*rv_all_gather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, void* stream);
-long rv_plan_shard_count(const rv_plan*, int bucket, int world);
-/* Sharded mode with the 16-bit parameter message (rv_shard_encode / rv_shadows_from_msg below) instead of the fp32
- * all-gather: half the bytes of the exchange nothing hides.  msg_send holds the sum over the two buckets of
- * rv_plan_shard_msg_slots 16-bit slots, msg_recv `world` times that (caller-owned, 16-byte aligned); NULL, NULL
- * returns to the fp32 all-gather.  Weight shadows and biases are bit-identical to the fp32 route on every rank;
- * fp32 weight masters are current on their owner rank only.  Not available with the fp8 forward. */
-long rv_plan_shard_msg_slots(const rv_plan*, int bucket, int world);
-int rv_plan_set_shard_message(rv_plan*, void* msg_send, void* msg_recv);
-int rv_plan_attach_comm_sharded(rv_plan*, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
-                                int world, int rank, float* rs_buf, float* ag_buf);
-/* Payload of the gradient all-reduces: bf16_arena == NULL = fp32 (default, exact mean of the ranks' fp32
- * gradients); otherwise bf16 (each rank's summed gradient rounded to bf16 into the caller's `bf16_arena`, which holds
- * at least as many 2-byte elements as the fp32 arenas hold floats, and summed by the collective in bf16). */
-int rv_plan_set_ddp_payload(rv_plan*, void* bf16_arena);
-/* The stream rv_plan_step_ddp issues its collectives on.  Default: one high-priority stream per process, created by
- * the first attach.  Why a caller may want to choose: the HIP runtime multiplexes streams onto a few hardware queues
- * (GPU_MAX_HW_QUEUES, default 4), and when the collective stream shares a queue with the caller's compute stream the
- * runtime resolves their cross-stream waits on the host -- every kernel of the step then starts ~50 us late (880 us
- * instead of 255 us per step measured at one rank).  ddp.NativeDdpRunner times a short ping-pong against the compute
- * stream and hands over the first of several candidate streams that is not affected.  Call before or after attach;
- * the stream stays the caller's. */
-int rv_plan_set_comm_stream(rv_plan*, void* stream);
+/* Elements per rank of a bucket's shard (msg_slots == 0; host arithmetic only: a bucket is cut into `world` equal
+ * shards of a multiple of 4 elements, so the last shard can overhang its bucket), or the length in 16-bit slots of
+ * that shard's parameter message (msg_slots != 0, bound plan; see rv_shard_encode). */
+long rv_plan_shard_count(const rv_plan*, int bucket, int world, int msg_slots);
+/* Everything rv_plan_step_ddp needs from the caller, in one descriptor (copied; attach again to change a field,
+ * comm == NULL detaches and keeps only comm_stream).  All-reduce mode: `allreduce`; sharded mode: `reduce_scatter` AND
+ * `all_gather` with rs_buf / ag_buf. */
+typedef struct rv_comm_desc {
+  void* comm; int world; int rank;
+  rv_allreduce_fn allreduce;
+  rv_reduce_scatter_fn reduce_scatter;
+  rv_all_gather_fn all_gather;
+  float* rs_buf;   /* sharded: sum over the buckets of rv_plan_shard_count floats, 16-byte aligned                  */
+  float* ag_buf;   /*          `world` times that; the caller's param / grad arenas extend 4 * world past n_params   */
+  void* msg_send;  /* sharded, optional: the 16-bit parameter message (rv_shard_encode / rv_shadows_from_msg) instead */
+  void* msg_recv;  /*   of the fp32 all-gather -- half the bytes of the exchange nothing hides.  msg_send holds the    */
+                   /*   sum over the buckets of rv_plan_shard_count(.., 1) slots, msg_recv `world` times that; weight  */
+                   /*   shadows and biases are bit-identical to the fp32 route on every rank, fp32 weight masters are  */
+                   /*   current on their owner rank only.  NULL, NULL: fp32 all-gather.  Not with the fp8 forward.     */
+  void* grad_bf16; /* all-reduce, optional: bf16 payload -- each rank's summed gradient rounded to bf16 into this arena */
+                   /*   (as many 2-byte elements as the fp32 arenas hold floats) and summed by the collective in bf16;  */
+                   /*   NULL: fp32, the exact mean of the ranks' fp32 gradients                                         */
+  void* comm_stream; /* the stream the collectives are issued on, or NULL: one high-priority stream per process,     */
+                   /*   created by the library.  Why a caller may want to choose: the HIP runtime multiplexes streams   */
+                   /*   onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4), and when the collective stream shares */
+                   /*   a queue with the compute stream the runtime resolves their cross-stream waits on the host --    */
+                   /*   every kernel of the step then starts ~50 us late (880 us instead of 255 us per step at one      */
+                   /*   rank).  ddp.pick_comm_stream times a short ping-pong against the compute stream and hands over  */
+                   /*   the first candidate that is not affected.  The stream stays the caller's.                       */
+} rv_comm_desc;
+int rv_plan_attach_comm(rv_plan*, const rv_comm_desc*);
 int rv_plan_step_ddp(rv_plan*, const float* x, const float* eps, float* recon_out, float kl_beta,
                      float lr, unsigned long long seed, void* stream);
 /* Device pointers into the workspace for tests (name: "mulv","z","h1","h3","dP4",...). */

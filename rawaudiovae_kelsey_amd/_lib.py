@@ -32,6 +32,16 @@ class PlanBuffers(C.Structure):
                 ("loss_ring", c_void_p), ("ring", c_int)]
 
 
+class CommDesc(C.Structure):
+    """rv_comm_desc: everything rv_plan_step_ddp needs from the caller."""
+    _fields_ = [("comm", c_void_p), ("world", c_int), ("rank", c_int), ("allreduce", c_void_p),
+                ("reduce_scatter", c_void_p), ("all_gather", c_void_p), ("rs_buf", c_void_p), ("ag_buf", c_void_p),
+                ("msg_send", c_void_p), ("msg_recv", c_void_p), ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
+
+
+OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE = 0, 1, 2
+PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
+TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
 PHASE_FINALIZE_A, PHASE_ADAM, PHASE_FINALIZE_B = 8, 16, 32
 PHASE_ADAM_A, PHASE_ADAM_B = 64, 128
@@ -47,27 +57,12 @@ _SIGS = {
     "rv_version": (c_int, []),
     "rv_last_error": (C.c_char_p, []),
     "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
-    "rv_gemm_pick": (c_int, [c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 3),
-    "rv_gemm_tile": (c_int, [c_long, c_long, c_int] + [C.POINTER(c_int)] * 2),
     "rv_gemm_force_tile": (c_int, [c_int]),   # test hook (include/rawvae_hip_diag.h), not part of the product ABI
-    "rv_dgrad_wgrad_pick": (c_int, [c_long, c_long, c_long] + [C.POINTER(c_int)] * 3),
-    "rv_linear_dgrad_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
-                                      c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "rv_linear_dgrad_wgrad_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
                                           c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                  c_void_p, c_void_p]),
     "rv_cast_pad_fp8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
-    "rv_cast_pad_bf16_q8": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long,
-                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "rv_linear_fwd_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p,
-                                 c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
-    "rv_linear_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long, c_int,
-                                  c_void_p, c_long, c_void_p]),
-    "rv_decode_out_loss_fwd_fp8": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
-                                           c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
-                                           c_void_p, c_void_p, c_void_p]),
-    "rv_plan_set_fp8": (c_int, [c_void_p, c_int]),
     "rv_reparameterize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "rv_tanh_bwd_pack": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p]),
     "rv_colsum_partial": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
@@ -85,14 +80,11 @@ _SIGS = {
     "rv_linear_dgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
                                 c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
                                 c_int, c_void_p]),
-    "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int,
-                                c_void_p, c_long, c_void_p]),
-    "rv_linear_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
+    "rv_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
                                    c_int, c_void_p, c_void_p]),
-    "rv_linear_dgrad_wgrad_ex": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
+    "rv_linear_dgrad_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long,
                                          c_long, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int,
                                          c_void_p, c_void_p]),
-    "rv_plan_set_slab_dtype": (c_int, [c_void_p, c_int]),
     "rv_linear_fwd_frames": (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                                      c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_linear_wgrad_adam": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_int, c_void_p, c_long,
@@ -112,16 +104,12 @@ _SIGS = {
                                   c_void_p, c_void_p]),
     "rv_randn": (c_int, [c_void_p, c_long, c_u64, c_u64, c_void_p]),
     "rv_gather_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_void_p]),
-    "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_float, c_float, c_void_p, c_void_p]),
-    "rv_grad_finalize": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
     "rv_plan_create": (c_int, [C.POINTER(c_void_p), c_long, c_long, c_long, c_long]),
     "rv_plan_destroy": (None, [c_void_p]),
     "rv_plan_workspace_bytes": (c_long, [c_void_p]),
     "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
-    "rv_plan_set_latent_fused": (c_int, [c_void_p, c_int]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -130,32 +118,24 @@ _SIGS = {
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_int, c_u64, c_void_p]),
-    "rv_gather_cast_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_long, c_long,
-                                      c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "rv_decode_out_loss_fwd_frames": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_long, c_long,
-                                              c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long,
-                                              c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
-    "rv_plan_attach_comm": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
-    "rv_plan_shard_count": (c_long, [c_void_p, c_int, c_int]),
-    "rv_plan_attach_comm_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rv_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_float, c_float, c_void_p, c_void_p]),
     "rv_params_from_flat": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_void_p, c_void_p]),
-    "rv_plan_set_ddp_payload": (c_int, [c_void_p, c_void_p]),
-    "rv_plan_set_comm_stream": (c_int, [c_void_p, c_void_p]),
-    "rv_plan_shard_msg_slots": (c_long, [c_void_p, c_int, c_int]),
-    "rv_plan_set_shard_message": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rv_shard_msg_slots": (c_long, [C.POINTER(ParamDesc), c_int, c_long]),
     "rv_shard_encode": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_shadows_from_msg": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
-    "rv_grad_finalize_bf16": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p]),
-    "rv_adam_multi_bf16grad": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_float, c_float, c_void_p, c_void_p]),
     "rv_plan_step_ddp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
     "rv_graph_begin": (c_int, [c_void_p]),
     "rv_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "rv_graph_launch": (c_int, [c_void_p, c_void_p]),
     "rv_graph_destroy": (None, [c_void_p]),
+    "rv_gemm_plan": (c_int, [c_int, c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 4),
+    "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_float, c_float, c_void_p, c_void_p]),
+    "rv_grad_finalize": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_int, c_void_p]),
+    "rv_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "rv_plan_attach_comm": (c_int, [c_void_p, C.POINTER(CommDesc)]),
+    "rv_plan_shard_count": (c_long, [c_void_p, c_int, c_int, c_int]),
 }
 
 EXPORTED = tuple(_SIGS)
@@ -211,25 +191,26 @@ def stream_ptr(stream=None):
     return s.cuda_stream or None
 
 
+def _gemm_plan(what, Mp, Np, Kp, splits_in):
+    o = [c_int() for _ in range(4)]   # bm, bn, splits, paired
+    lib().rv_gemm_plan(what, Mp, Np, Kp, splits_in, *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)
+
+
 def gemm_pick(Mp, Np, Kp, max_splits=16):
     """(bm, bn, splits) the library recommends for a padded Mp x Np x Kp GEMM."""
-    o = [c_int() for _ in range(3)]
-    lib().rv_gemm_pick(Mp, Np, Kp, max_splits, *[C.byref(v) for v in o])
-    return tuple(v.value for v in o)
+    return _gemm_plan(PLAN_GEMM, Mp, Np, Kp, max_splits)[:3]
 
 
 def gemm_tile(Mp, Np, splits=1):
     """(bm, bn) block tile used for a GEMM launched with `splits` K splits."""
-    o = [c_int() for _ in range(2)]
-    lib().rv_gemm_tile(Mp, Np, splits, *[C.byref(v) for v in o])
-    return tuple(v.value for v in o)
+    return _gemm_plan(PLAN_TILE, Mp, Np, 64, splits)[:2]
 
 
 def dgrad_wgrad_pick(Mp, Np, Kp):
     """(paired, bm_dgrad, splits) for the fused backward of one Linear layer."""
-    o = [c_int() for _ in range(3)]
-    lib().rv_dgrad_wgrad_pick(Mp, Np, Kp, *[C.byref(v) for v in o])
-    return tuple(v.value for v in o)
+    bm, _, splits, paired = _gemm_plan(PLAN_PAIR, Mp, Np, Kp, 0)
+    return paired, bm, splits
 
 
 def pad_dims(B, S, H, L):

@@ -6,6 +6,7 @@
 #include "adam.h"
 #include "philox.h"
 #include "../../include/rawvae_hip.h"
+#include "internal.h"
 
 #include <stdarg.h>
 #include <string.h>
@@ -51,7 +52,7 @@ __device__ __forceinline__ unsigned long long q8x8(const float (&v)[8], float sc
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// fp8 state block (rv_plan_set_fp8): thread 0 of the step's first kernel latches the delayed h3 scale
+// fp8 state block (RV_OPT_FP8): thread 0 of the step's first kernel latches the delayed h3 scale
 __device__ __forceinline__ void fp8_latch(float* st, const float* amax_part, int n_amax, int lane) {
   float m = 0.f;
   for (int i = lane; i < n_amax; i += 64) m = fmaxf(m, amax_part[i]);
@@ -829,28 +830,15 @@ int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* s
 }
 
 int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
-                  float* exp_avg_sq, float* grad_out, float lr, float grad_scale,
+                  float* exp_avg_sq, float* grad_out, const void* grad_bf16, float lr, float grad_scale,
                   const long long* step_counter, void* stream) {
   RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_adam_multi: null pointer");
+  RV_REQUIRE(!(grad_bf16 && grad_out), RV_ERR_UNSUPPORTED, "rv_adam_multi: grad_out is the sum of the slabs; not with grad_bf16");
   DescTable tab;
   int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
-                     step_counter, (bf16_t*)nullptr, (const bf16_t*)nullptr);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-int rv_adam_multi_bf16grad(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
-                           float* exp_avg_sq, const void* grad_bf16, float lr, float grad_scale,
-                           const long long* step_counter, void* stream) {
-  RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter && grad_bf16, RV_ERR_NULL, "rv_adam_multi_bf16grad: null pointer");
-  DescTable tab;
-  int rc = adam_build_table(descs, n_desc, &tab);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
-                     (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, (float*)nullptr, lr, grad_scale,
                      step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16);
   RV_CHECK_LAUNCH();
   return RV_OK;
@@ -942,26 +930,15 @@ int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg,
   return RV_OK;
 }
 
-int rv_grad_finalize(const rv_param_desc* descs, int n_desc, float* grad_out, void* stream) {
+int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, void* stream) {
   RV_REQUIRE(grad_out, RV_ERR_NULL, "rv_grad_finalize: null pointer");
   DescTable tab;
   int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
-                     (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, grad_out,
-                     0.f, 1.f, (const long long*)nullptr, (bf16_t*)nullptr, (const bf16_t*)nullptr);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-int rv_grad_finalize_bf16(const rv_param_desc* descs, int n_desc, void* grad_out_bf16, void* stream) {
-  RV_REQUIRE(grad_out_bf16, RV_ERR_NULL, "rv_grad_finalize_bf16: null pointer");
-  DescTable tab;
-  int rc = adam_build_table(descs, n_desc, &tab);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
-                     (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     0.f, 1.f, (const long long*)nullptr, (bf16_t*)grad_out_bf16, (const bf16_t*)nullptr);
+                     (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     out_bf16 ? (float*)nullptr : (float*)grad_out, 0.f, 1.f, (const long long*)nullptr,
+                     out_bf16 ? (bf16_t*)grad_out : (bf16_t*)nullptr, (const bf16_t*)nullptr);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

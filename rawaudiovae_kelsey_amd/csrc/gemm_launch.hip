@@ -2,6 +2,7 @@
 #include "gemm_bf16.h"
 #include "adam.h"
 #include "../../include/rawvae_hip.h"
+#include "internal.h"
 
 using namespace rv;
 
@@ -434,18 +435,13 @@ int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp,
   return launch_auto<true, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
 }
 
-int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp,
-                    int splits, float* dw, long lddw, void* stream) {
-  return rv_linear_wgrad_ex(dy, lddy, x, ldx, Mp, Np, Kp, splits, RV_TILE_AUTO, dw, lddw, RV_SLAB_F32, nullptr, stream);
-}
-
 // Weight gradient with every option: a named block tile (RV_TILE_AUTO = the picker's choice) and the slab element type.
-int rv_linear_wgrad_ex(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
                        int tile, void* dw, long lddw, int slab_dtype, float* slab_unscale, void* stream) {
   RV_REQUIRE(dy && x && dw, RV_ERR_NULL, "rv_linear_wgrad: null operand");
   RV_REQUIRE(tile == RV_TILE_AUTO || tile == RV_TILE_256x256 || tile == RV_TILE_256x128 || tile == RV_TILE_128x128 ||
-                 tile == RV_TILE_64x64, RV_ERR_UNSUPPORTED, "rv_linear_wgrad_ex: unknown tile %d", tile);
-  RV_REQUIRE(splits >= 1, RV_ERR_SHAPE, "rv_linear_wgrad_ex: splits %d", splits);
+                 tile == RV_TILE_64x64, RV_ERR_UNSUPPORTED, "rv_linear_wgrad: unknown tile %d", tile);
+  RV_REQUIRE(splits >= 1, RV_ERR_SHAPE, "rv_linear_wgrad: splits %d", splits);
   GemmArgs a{};
   a.A = (const bf16_t*)dy; a.lda = lddy; a.B = (const bf16_t*)x; a.ldb = ldx;
   a.k_tiles = (int)(Kp / 64 / splits); a.M_valid = (int)Mp; a.N_valid = (int)Np;
@@ -536,13 +532,6 @@ int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, i
 }
 
 int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
-                          long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
-                          float* dw_slabs, long lddw, int splits, void* stream) {
-  return rv_linear_dgrad_wgrad_ex(dy, lddy, w, ldw, x, ldx, Mp, Np, Kp, dx_bf16, lddx, colsum_partial, dw_slabs,
-                                  lddw, splits, RV_SLAB_F32, nullptr, stream);
-}
-
-int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw, const void* x, long ldx,
                              long Mp, long Np, long Kp, void* dx_bf16, long lddx,
                              float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype, float* slab_unscale,
                              void* stream) {
@@ -567,7 +556,7 @@ int rv_linear_dgrad_wgrad_ex(const void* dy, long lddy, const void* w, long ldw,
       return rc;
     rc = launch_tile<true, false, EPI_MASK_BF16>(td, d, Mp, Np, Kp, 1, (hipStream_t)stream);
     if (rc) return rc;
-    return rv_linear_wgrad_ex(dy, lddy, x, ldx, Kp, Np, Mp, splits, RV_TILE_AUTO, dw_slabs, lddw, slab_dtype, slab_unscale, stream);
+    return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, splits, RV_TILE_AUTO, dw_slabs, lddw, slab_dtype, slab_unscale, stream);
   }
   RV_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: leading dims must be multiples of 8");
   RV_REQUIRE((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE, "rv_linear_dgrad_wgrad: operands must be 16-byte aligned");
@@ -613,7 +602,20 @@ int rv_linear_dgrad_wgrad_f32(const void* dy, long lddy, const void* w, long ldw
   }
   rc = rv_linear_dgrad(dy, lddy, w, ldw, Mp, Np, Kp, nullptr, 0, nullptr, 0, nullptr, dx_slabs, lddx, dgrad_splits, stream);
   if (rc) return rc;
-  return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, wgrad_splits, dw_slabs, lddw, stream);
+  return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, wgrad_splits, RV_TILE_AUTO, dw_slabs, lddw, RV_SLAB_F32, nullptr, stream);
+}
+
+int rv_gemm_plan(int what, long Mp, long Np, long Kp, int splits_in, int* bm, int* bn, int* splits, int* paired) {
+  switch (what) {
+    case RV_PLAN_GEMM: return rv_gemm_pick(Mp, Np, Kp, splits_in, bm, bn, splits);
+    case RV_PLAN_TILE: {
+      if (splits) *splits = splits_in;
+      return rv_gemm_tile(Mp, Np, splits_in, bm, bn);
+    }
+    case RV_PLAN_PAIR: return rv_dgrad_wgrad_pick(Mp, Np, Kp, paired, bm, splits);
+  }
+  RV_REQUIRE(false, RV_ERR_UNSUPPORTED, "rv_gemm_plan: unknown query %d", what);
+  return RV_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,44 @@
+// Launchers that only the step plan (plan.hip) calls: forms of public entry points with extra operands (fp8 copies,
+// per-block maxima, frames read in place).  Not part of the C ABI (include/rawvae_hip.h) and not exported.
+#pragma once
+#include "../../include/rawvae_hip.h"
+
+#define RV_INTERNAL extern "C" __attribute__((visibility("hidden")))
+
+// The pickers behind rv_gemm_plan (gemm_launch.hip).
+RV_INTERNAL int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, int* bn, int* splits);
+RV_INTERNAL int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
+RV_INTERNAL int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits);
+RV_INTERNAL int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);
+
+// rv_cast_pad_bf16 that also writes the fp8 operand (dst_fp8 may be NULL) and, when `fp8_state` is given, latches the
+// delayed activation scale for this step in its first wave from the previous step's per-block maxima
+// `amax_part[n_amax]` (state block layout: RV_OPT_FP8 in the public header).
+RV_INTERNAL int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long rows_p,
+                                    long cols_p, long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state,
+                                    const float* amax_part, int n_amax, long long* step_counter, void* stream);
+// The same from hop-strided frames of a resident fp32 waveform (rv_gather_frames + the cast in one kernel).
+RV_INTERNAL int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
+                                      long n_frames, long S, long hop, void* dst_bf16, long rows_p, long cols_p,
+                                      long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part,
+                                      int n_amax, long long* step_counter, void* stream);
+// rv_linear_fwd with every optional output of a bias/ReLU forward GEMM (NULL = not wanted): the output also as
+// fp8(y * *q_scale) (the next layer's fp8 operand) and max|y| of every block in amax_part[block], from which the next
+// step derives its scale (delayed scaling).
+RV_INTERNAL int rv_linear_fwd_ex(const void* x_bf16, long ldx, const void* w_bf16, long ldw, const float* bias, long Mp,
+                                 long Np, long Kp, int act, void* y_bf16, long ldy, void* y_fp8, long ldy_fp8,
+                                 const float* q_scale, float* amax_part, void* stream);
+// rv_linear_fwd / rv_decode_out_loss_fwd on fp8 operands (K extents and leading dims in fp8 elements).
+RV_INTERNAL int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias,
+                                  const float* dq, long Mp, long Np, long Kp, int act, void* y_bf16, long ldy,
+                                  void* stream);
+RV_INTERNAL int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
+                                           const float* dq, long Bp, long Sp, long Hp, long B, long S, const float* x,
+                                           long ldx, float* recon, long ld_recon, void* dP4_bf16, long ld_dp4,
+                                           float* mse_partial, float* db4_partial, void* stream);
+// rv_decode_out_loss_fwd whose fp32 target rows are read in place from the waveform (dq != NULL: fp8 operands).
+RV_INTERNAL int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4,
+                                              const float* dq, long Bp, long Sp, long Hp, long B, long S,
+                                              const float* audio, long n_samples, const long long* frame_index,
+                                              long first_frame, long hop, float* recon, long ld_recon, void* dP4_bf16,
+                                              long ld_dp4, float* mse_partial, float* db4_partial, void* stream);

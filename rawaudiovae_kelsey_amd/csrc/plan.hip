@@ -3,6 +3,7 @@
 // helpers.  C ABI: include/rawvae_hip.h.
 #include "common.h"
 #include "../../include/rawvae_hip.h"
+#include "internal.h"
 
 #include <string.h>
 
@@ -10,7 +11,6 @@
 #include <string>
 #include <vector>
 
-extern "C" int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);   // gemm_launch.hip (internal)
 
 namespace {
 
@@ -58,7 +58,7 @@ struct rv_plan {
   const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
   const float* ext_dmu = nullptr; const float* ext_dlv = nullptr;
   float* ext_grad_out = nullptr;
-  int latent_fused = 1;          // rv_plan_set_latent_fused: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
+  int latent_fused = 1;          // RV_OPT_LATENT_FUSED: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
   // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
@@ -67,18 +67,18 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
-  // sharded optimizer (rv_plan_attach_comm_sharded)
+  // sharded optimizer (rv_plan_attach_comm with reduce_scatter + all_gather)
   rv_reduce_scatter_fn reduce_scatter = nullptr;
   rv_all_gather_fn all_gather = nullptr;
   int rank = 0;
   float* rs_buf = nullptr;
   float* ag_buf = nullptr;
-  // 16-bit parameter message instead of the fp32 all-gather (rv_plan_set_shard_message): send / receive buffers
+  // 16-bit parameter message instead of the fp32 all-gather (rv_comm_desc.msg_send / msg_recv): send / receive buffers
   unsigned short* msg_send = nullptr;
   unsigned short* msg_recv = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
-  int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (rv_plan_set_fp8)
-  int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (rv_plan_set_slab_dtype)
+  int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (RV_OPT_FP8)
+  int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (RV_OPT_SLAB_DTYPE)
   float* us_w1 = nullptr;         // per-granule scale tables of the fp16 slabs (workspace "dW1_us" / "dW4_us")
   float* us_w4 = nullptr;
   // frame source of the step in flight (rv_plan_step_frames): `x` is then the resident waveform
@@ -86,7 +86,7 @@ struct rv_plan {
   long fr_first = 0, fr_hop = 0, fr_nsamples = 0;
   const void* fr_bf16 = nullptr;   // the waveform as bf16 (fc1's operand is gathered from it), or null
   int payload_bf16 = 0;
-  void* grad_bf16 = nullptr;   // caller's flat bf16 payload arena (rv_plan_set_ddp_payload)
+  void* grad_bf16 = nullptr;   // caller's flat bf16 payload arena (rv_comm_desc.grad_bf16)
 
   char* ws(const char* name, long* nbytes = nullptr) const {
     for (const Buf& x : bufs)
@@ -181,7 +181,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
   p->add("db4p", (long)p->n_mt4 * Sp * 4);
-  p->add("xq", Bp * Sp);          // fp8 operands of the fp8 forward path (rv_plan_set_fp8)
+  p->add("xq", Bp * Sp);          // fp8 operands of the fp8 forward path (RV_OPT_FP8)
   p->add("W1q", Hp * Sp);
   p->add("W4q", Sp * Hp);
   p->add("h3q", Bp * Hp);
@@ -242,14 +242,7 @@ int rv_plan_set_external_grads(rv_plan* p, const float* d_recon, const float* re
   return RV_OK;
 }
 
-int rv_plan_set_latent_fused(rv_plan* p, int enable) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_latent_fused: null plan");
-  p->latent_fused = enable ? 1 : 0;
-  return RV_OK;
-}
-
-int rv_plan_set_fp8(rv_plan* p, int enable) {
-  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_fp8: plan not bound");
+static int plan_set_fp8(rv_plan* p, int enable) {
   p->fp8 = enable ? 1 : 0;
   float* st = (float*)p->ws("fp8_state");
   // Adam keeps the fp8 shadows of fc1.weight / fc4.weight current (descriptor 0 and 8)
@@ -260,9 +253,8 @@ int rv_plan_set_fp8(rv_plan* p, int enable) {
   return RV_OK;
 }
 
-int rv_plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
-  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_slab_dtype: plan not bound");
-  RV_REQUIRE(slab_dtype == RV_SLAB_F32 || slab_dtype == RV_SLAB_F16, RV_ERR_UNSUPPORTED, "rv_plan_set_slab_dtype: %d", slab_dtype);
+static int plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
+  RV_REQUIRE(slab_dtype == RV_SLAB_F32 || slab_dtype == RV_SLAB_F16, RV_ERR_UNSUPPORTED, "rv_plan_set_option: slab element type %d", slab_dtype);
   p->slab_dtype = slab_dtype;
   const long Hp = p->Hp, Sp = p->Sp;
   const bool half = slab_dtype == RV_SLAB_F16;
@@ -270,6 +262,17 @@ int rv_plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
   d1->grad_half = half; d1->grad_unscale = half ? p->us_w1 : nullptr; d1->us_ld = Sp / 32; d1->us_split_stride = (Hp / 32) * (Sp / 32);
   rv_param_desc* d4 = p->d_slab + 8;
   d4->grad_half = half; d4->grad_unscale = half ? p->us_w4 : nullptr; d4->us_ld = Hp / 32; d4->us_split_stride = (Sp / 32) * (Hp / 32);
+  return RV_OK;
+}
+
+int rv_plan_set_option(rv_plan* p, int option, int value) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_option: plan not bound");
+  switch (option) {
+    case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; return RV_OK;
+    case RV_OPT_FP8: return plan_set_fp8(p, value);
+    case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
+  }
+  RV_REQUIRE(false, RV_ERR_UNSUPPORTED, "rv_plan_set_option: unknown option %d", option);
   return RV_OK;
 }
 
@@ -322,7 +325,7 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
       p->d_flat[i].grad_splits = 1;
     }
   }
-  return rv_plan_set_slab_dtype(p, p->slab_dtype);
+  return plan_set_slab_dtype(p, p->slab_dtype);
 }
 
 int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
@@ -462,7 +465,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   };
   auto heads_bwd = [&](void* st) {
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                                 (float*)p->ws("dWh"), Hp, p->s_wh, st);
+                                 (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, st);
   };
   RV_REQUIRE(!(full_local && (p->ext_d_recon || p->ext_dmu || p->ext_dlv)), RV_ERR_STATE,
              "rv_plan_step: external gradients are set (rv_plan_set_external_grads); run the backward phases without ADAM");
@@ -477,7 +480,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
     // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
     RV_TRY(latent_bwd(stream));
     RV_TRY(reparam_bwd(stream));
@@ -487,7 +490,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
                                 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                 p->b.step_counter, 256 - n_gemm, stream));
-    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     return RV_OK;
   }
@@ -505,7 +508,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_colsum_partial(dP4, 1, Bp, Sp, Sp, (float*)p->ws("db4p"), Sp, stream));
   }
   if (do_pair)
-    RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   if (do_chain_a && do_w3) {
     RV_TRY(latent_bwd(stream));
@@ -516,9 +519,9 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
     RV_TRY(heads_bwd(stream));
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   }
-  if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, (float*)p->ws("dW3"), Lp, stream));
+  if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, RV_TILE_AUTO, p->ws("dW3"), Lp, RV_SLAB_F32, nullptr, stream));
 
   // tensor masks (bit i = parameter i in state_dict order)
   unsigned fin = 0, adam = 0;
@@ -541,14 +544,14 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     if (!((fin >> i) & 1)) { ++i; continue; }
     int j = i;
     while (j < 10 && ((fin >> j) & 1)) ++j;
-    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, fin_out, stream));
+    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, fin_out, 0, stream));
     i = j;
   }
   for (int i = 0; i < 10;) {
     if (!((adam >> i) & 1)) { ++i; continue; }
     int j = i;
     while (j < 10 && ((adam >> j) & 1)) ++j;
-    RV_TRY(rv_adam_multi(ad + i, j - i, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, grad_scale,
+    RV_TRY(rv_adam_multi(ad + i, j - i, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
     i = j;
   }
@@ -568,41 +571,40 @@ int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, const void* 
 }
 
 // ------------------------------------------------------------ data-parallel step
-int rv_plan_set_comm_stream(rv_plan* p, void* stream) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_comm_stream: null plan");
-  p->comm_stream = (hipStream_t)stream;   // NULL: back to the library's own (created on the next attach)
-  return RV_OK;
-}
-
-int rv_plan_attach_comm(rv_plan* p, rv_allreduce_fn allreduce, void* comm, int world) {
-  RV_REQUIRE(p && allreduce && comm, RV_ERR_NULL, "rv_plan_attach_comm: null argument");
-  RV_REQUIRE(world >= 1, RV_ERR_SHAPE, "rv_plan_attach_comm: world %d", world);
-  if (!p->comm_stream) {
-    const int src = helper_stream(true, &p->comm_stream);
-    if (src) return src;
-  }
-  if (!p->ev_ready[0]) {
-    for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  p->allreduce = allreduce;
-  p->comm = comm;
-  p->world = world;
-  return RV_OK;
-}
-
 static long shard_count(long lo, long hi, int world) { return ((hi - lo + world - 1) / world + 3) / 4 * 4; }
 
-long rv_plan_shard_count(const rv_plan* p, int bucket, int world) {
-  if (!p || world < 1 || bucket < 0 || bucket > 1) return 0;
-  return bucket == 0 ? shard_count(p->off[8], p->n_params, world) : shard_count(0, p->off[8], world);
+long rv_plan_shard_count(const rv_plan* p, int bucket, int world, int msg_slots) {
+  if (!p || world < 1 || bucket < 0 || bucket > 1) return msg_slots ? -1 : 0;
+  const long cnt = bucket == 0 ? shard_count(p->off[8], p->n_params, world) : shard_count(0, p->off[8], world);
+  if (!msg_slots) return cnt;
+  if (!p->bound) return -1;
+  return bucket == 0 ? rv_shard_msg_slots(p->d_slab + 8, 2, cnt) : rv_shard_msg_slots(p->d_slab, 8, cnt);
 }
 
-int rv_plan_attach_comm_sharded(rv_plan* p, rv_reduce_scatter_fn reduce_scatter, rv_all_gather_fn all_gather, void* comm,
-                                int world, int rank, float* rs_buf, float* ag_buf) {
-  RV_REQUIRE(p && reduce_scatter && all_gather && comm && rs_buf && ag_buf, RV_ERR_NULL, "rv_plan_attach_comm_sharded: null argument");
-  RV_REQUIRE(world >= 1 && rank >= 0 && rank < world, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: rank %d of %d", rank, world);
-  RV_REQUIRE((((uintptr_t)rs_buf | (uintptr_t)ag_buf) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm_sharded: buffers must be 16-byte aligned");
+int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
+  RV_REQUIRE(p && c, RV_ERR_NULL, "rv_plan_attach_comm: null argument");
+  if (!c->comm) {   // detach: the stream choice is the one field that may be set ahead of a communicator
+    p->allreduce = nullptr; p->reduce_scatter = nullptr; p->all_gather = nullptr; p->comm = nullptr;
+    p->comm_stream = (hipStream_t)c->comm_stream;
+    return RV_OK;
+  }
+  const bool sharded = c->reduce_scatter || c->all_gather;
+  RV_REQUIRE(c->world >= 1 && c->rank >= 0 && c->rank < c->world, RV_ERR_SHAPE, "rv_plan_attach_comm: rank %d of %d", c->rank, c->world);
+  if (sharded) {
+    RV_REQUIRE(c->reduce_scatter && c->all_gather && !c->allreduce, RV_ERR_NULL,
+               "rv_plan_attach_comm: sharded mode takes reduce_scatter AND all_gather (and no allreduce)");
+    RV_REQUIRE(c->rs_buf && c->ag_buf, RV_ERR_NULL, "rv_plan_attach_comm: sharded mode needs rs_buf and ag_buf");
+    RV_REQUIRE((((uintptr_t)c->rs_buf | (uintptr_t)c->ag_buf) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm: buffers must be 16-byte aligned");
+    RV_REQUIRE((c->msg_send == nullptr) == (c->msg_recv == nullptr), RV_ERR_NULL, "rv_plan_attach_comm: both message buffers or neither");
+    RV_REQUIRE((((uintptr_t)c->msg_send | (uintptr_t)c->msg_recv) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm: message buffers must be 16-byte aligned");
+    RV_REQUIRE(!(c->msg_send && p->fp8), RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the fp8 shadows are derived from fp32 parameters; "
+               "use the fp32 all-gather with the fp8 forward");
+    RV_REQUIRE(!c->grad_bf16, RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the bf16 gradient payload belongs to the all-reduce mode");
+  } else {
+    RV_REQUIRE(c->allreduce, RV_ERR_NULL, "rv_plan_attach_comm: no collective given");
+    RV_REQUIRE(!c->msg_send && !c->msg_recv, RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the parameter message belongs to the sharded mode");
+  }
+  p->comm_stream = (hipStream_t)c->comm_stream;   // NULL: the library's own
   if (!p->comm_stream) {
     const int src = helper_stream(true, &p->comm_stream);
     if (src) return src;
@@ -611,29 +613,17 @@ int rv_plan_attach_comm_sharded(rv_plan* p, rv_reduce_scatter_fn reduce_scatter,
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  if (!p->ev_upd[0]) {
+  if (sharded && !p->ev_upd[0]) {
     for (hipEvent_t& e : p->ev_upd) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_gath) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  p->reduce_scatter = reduce_scatter; p->all_gather = all_gather; p->comm = comm;
-  p->world = world; p->rank = rank; p->rs_buf = rs_buf; p->ag_buf = ag_buf;
-  return RV_OK;
-}
-
-long rv_plan_shard_msg_slots(const rv_plan* p, int bucket, int world) {
-  if (!p || !p->bound || world < 1 || bucket < 0 || bucket > 1) return -1;
-  return bucket == 0 ? rv_shard_msg_slots(p->d_slab + 8, 2, shard_count(p->off[8], p->n_params, world))
-                     : rv_shard_msg_slots(p->d_slab, 8, shard_count(0, p->off[8], world));
-}
-
-int rv_plan_set_shard_message(rv_plan* p, void* msg_send, void* msg_recv) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_shard_message: null plan");
-  RV_REQUIRE((msg_send == nullptr) == (msg_recv == nullptr), RV_ERR_NULL, "rv_plan_set_shard_message: both buffers or neither");
-  RV_REQUIRE((((uintptr_t)msg_send | (uintptr_t)msg_recv) & 15) == 0, RV_ERR_SHAPE, "rv_plan_set_shard_message: buffers must be 16-byte aligned");
-  RV_REQUIRE(!(msg_send && p->fp8), RV_ERR_UNSUPPORTED, "rv_plan_set_shard_message: the fp8 shadows are derived from fp32 parameters; "
-             "use the fp32 all-gather with the fp8 forward");
-  p->msg_send = (unsigned short*)msg_send;
-  p->msg_recv = (unsigned short*)msg_recv;
+  p->allreduce = sharded ? nullptr : c->allreduce;
+  p->reduce_scatter = sharded ? c->reduce_scatter : nullptr;
+  p->all_gather = sharded ? c->all_gather : nullptr;
+  p->comm = c->comm; p->world = c->world; p->rank = c->rank;
+  p->rs_buf = c->rs_buf; p->ag_buf = c->ag_buf;
+  p->msg_send = (unsigned short*)c->msg_send; p->msg_recv = (unsigned short*)c->msg_recv;
+  p->grad_bf16 = c->grad_bf16; p->payload_bf16 = c->grad_bf16 ? 1 : 0;
   return RV_OK;
 }
 
@@ -655,7 +645,7 @@ static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) 
   if (*n < 0) *n = 0;
 }
 
-// One sharded data-parallel step (see rv_plan_attach_comm_sharded in the header): RS(fc4) on the collective stream
+// One sharded data-parallel step (see rv_comm_desc in the header): RS(fc4) on the collective stream
 // behind the rest of backward, RS(rest), Adam on the own shards, AG(fc4), AG(rest) on the caller's stream.
 static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                             unsigned long long seed, void* stream) {
@@ -680,9 +670,9 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     return RV_OK;
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, stream));
+  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, 0, stream));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
   RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
   RV_TRY(scatter_bucket(0, sc));                              // fc4's 8.4 MB travel behind the rest of backward
@@ -692,9 +682,9 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
-  RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, stream));
+                               (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream));
+  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, 0, stream));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: fc4's reduce-scatter is done
   RV_TRY(scatter_bucket(1, s0));
   for (int b = 0; b < 2; ++b) {
@@ -731,13 +721,6 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   return RV_OK;
 }
 
-int rv_plan_set_ddp_payload(rv_plan* p, void* bf16_arena) {
-  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_ddp_payload: null plan");
-  p->grad_bf16 = bf16_arena;
-  p->payload_bf16 = bf16_arena ? 1 : 0;
-  return RV_OK;
-}
-
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                      unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
@@ -759,8 +742,8 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   // Bucket = tensors [t0, t1) of the flat arena: slabs -> flat payload (caller's stream), then the SUM over ranks
   // on stream `on`
   auto payload = [&](int t0, int t1) -> int {
-    if (p->payload_bf16) return rv_grad_finalize_bf16(p->d_slab + t0, t1 - t0, p->grad_bf16, stream);
-    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, stream);
+    if (p->payload_bf16) return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->grad_bf16, 1, stream);
+    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, 0, stream);
   };
   auto reduce = [&](int b, int t0, int t1, hipStream_t on) -> int {
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
@@ -777,14 +760,14 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   };
   auto adam_bucket = [&](int t0, int n) -> int {
     if (p->payload_bf16)
-      return rv_adam_multi_bf16grad(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, p->grad_bf16, lr,
+      return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, p->grad_bf16, lr,
                                     scale, p->b.step_counter, stream);
-    return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, lr, scale,
+    return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, scale,
                          p->b.step_counter, stream);
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad_ex(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   RV_TRY(payload(8, 10));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) travels behind the rest of backward
@@ -796,7 +779,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
                         mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                               (float*)p->ws("dWh"), Hp, p->s_wh, stream));
+                               (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));        // the join: fc4's sum has arrived
   const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
   if (!p->payload_bf16 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && n_gemm <= 192) {
@@ -804,7 +787,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_flat + 8,
                                 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, scale, p->b.step_counter, 256 - n_gemm, stream));
   } else {
-    RV_TRY(rv_linear_wgrad_ex(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
     RV_TRY(adam_bucket(8, 2));
   }
   RV_TRY(payload(0, 8));                                   // fc1, fc21, fc22, fc3: contiguous in the arena
@@ -854,31 +837,6 @@ void rv_graph_destroy(rv_graph* g) {
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
   delete g;
-}
-
-// --------------------------------------------------------------------- events
-int rv_event_create(void** ev) {
-  RV_REQUIRE(ev, RV_ERR_NULL, "rv_event_create: null");
-  hipEvent_t e;
-  RV_HIP(hipEventCreate(&e));
-  *ev = (void*)e;
-  return RV_OK;
-}
-
-int rv_event_record(void* ev, void* stream) {
-  RV_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
-  return RV_OK;
-}
-
-int rv_event_elapsed_ms_sync(void* a, void* b, float* ms) {
-  RV_REQUIRE(ms, RV_ERR_NULL, "rv_event_elapsed_ms_sync: null");
-  RV_HIP(hipEventSynchronize((hipEvent_t)b));
-  RV_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
-  return RV_OK;
-}
-
-void rv_event_destroy(void* ev) {
-  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }
 
 }  // extern "C"

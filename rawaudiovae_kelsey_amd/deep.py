@@ -270,7 +270,7 @@ class DeepTrainEngine:
             # dy [Bp,kd] is the gradient at the output of layer `wname`, whose input is dec_act[i]
             L_.rv_linear_dgrad_wgrad(ptr(dy), kd, W(wname), Hp, ptr(self.dec_act[i]), Hp, Bp, Hp, kd,
                                      ptr(self.d_dec[i]), Hp, ptr(self.bias_part["dec.%d.bias" % i]),
-                                     ptr(self.slabs[wname]), Hp, self.splits[wname], st)
+                                     ptr(self.slabs[wname]), Hp, self.splits[wname], 0, None, st)
             dy, kd, wname = self.d_dec[i], Hp, "dec.%d.weight" % i
         # dec.0: input is z (no ReLU): dz as fp32 slabs, weight gradient separately
         L_.rv_linear_dgrad_wgrad_f32(ptr(dy), Hp, W("dec.0.weight"), Lp, ptr(self.z), Lp, Bp, Lp, Hp,
@@ -285,14 +285,14 @@ class DeepTrainEngine:
         for i in range(d - 1, -1, -1):
             L_.rv_linear_dgrad_wgrad(ptr(dy), kd, wptr, Hp, ptr(self.enc_act[i]), Hp, Bp, Hp, kd,
                                      ptr(self.d_enc[i]), Hp, ptr(self.bias_part["enc.%d.bias" % i]),
-                                     ptr(self.slabs[wname]), Hp, self.splits[wname], st)
+                                     ptr(self.slabs[wname]), Hp, self.splits[wname], 0, None, st)
             dy, kd, wname = self.d_enc[i], Hp, "enc.%d.weight" % i
             wptr = W(wname)
-        L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"],
-                           ptr(self.slabs["enc.0.weight"]), Sp, st)
+        L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"], -1,
+                           ptr(self.slabs["enc.0.weight"]), Sp, 0, None, st)
         if adam:
             for chunk in self._chunks:
-                L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None,
+                L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, None,
                                  self.lr, 1.0, ctr, st)
         self.host_steps += 1
 
@@ -300,7 +300,7 @@ class DeepTrainEngine:
         """Exact-shape fp32 gradients of the last backward (sums the slabs); for tests."""
         out = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         for chunk in self._chunks:
-            lib().rv_grad_finalize(chunk, len(chunk), ptr(out), stream_ptr())
+            lib().rv_grad_finalize(chunk, len(chunk), ptr(out), 0, stream_ptr())
         return {k: self.view(out, k) for k in self.names}
 
     def outputs(self):

@@ -92,13 +92,13 @@ class TrainEngine:
         self.fp8_x_scale = 256.0        # frames are in [-1, 1]
         self.fp8_h3_scale = 16.0        # first step only; afterwards 224 / max|h3| of the previous step
         if self.fp8:
-            L_.rv_plan_set_fp8(self._plan, 1)
+            L_.rv_plan_set_option(self._plan, _lib.OPT_FP8, 1)
         # element type of the fc1 / fc4 weight-gradient split-K slabs: "fp16" (default) = block-floating-point fp16, one
         # power-of-two scale per wave tile and slab (half the bytes written and re-read, any gradient magnitude); "fp32"
         if slab_dtype not in ("fp32", "fp16"):
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
-        L_.rv_plan_set_slab_dtype(self._plan, int(slab_dtype == "fp16"))
+        L_.rv_plan_set_option(self._plan, _lib.OPT_SLAB_DTYPE, _lib.SLAB_F16 if slab_dtype == "fp16" else _lib.SLAB_F32)
 
     def __del__(self):
         try:
@@ -136,11 +136,11 @@ class TrainEngine:
     def set_latent_fused(self, enable):
         """True (default): heads GEMM + reparameterisation + fc3 of the forward as one launch where the library has the
         fused kernel (padded latent width 64, hidden width a multiple of 512 up to 2048, bf16); False: always three
-        launches (`rv_plan_set_latent_fused`)."""
-        lib().rv_plan_set_latent_fused(self._plan, int(bool(enable)))
+        launches (`rv_plan_set_option`, RV_OPT_LATENT_FUSED)."""
+        lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_FUSED, int(bool(enable)))
 
     def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
-        """Write entries of the fp8 state block (include/rawvae_hip.h, rv_plan_set_fp8).  Weight scales are
+        """Write entries of the fp8 state block (include/rawvae_hip.h, RV_OPT_FP8).  Weight scales are
         normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""
         st = self.buffer("fp8_state", torch.float32, (8,))
         for i, v in ((0, x), (1, w1), (2, w4), (3, h3)):
@@ -252,32 +252,47 @@ class TrainEngine:
             from .ddp import ShardPlan
             self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
             for b in (0, 1):
-                if lib().rv_plan_shard_count(self._plan, b, comm.world) != self.shard_plan.counts[b]:
+                if lib().rv_plan_shard_count(self._plan, b, comm.world, 0) != self.shard_plan.counts[b]:
                     raise _lib.RvError("shard bookkeeping of ddp.ShardPlan and the library disagree")
             f32 = dict(dtype=torch.float32, device=self.device)
             self._rs_buf = torch.zeros(self.shard_plan.rs_elems, **f32)
             self._ag_buf = torch.zeros(self.shard_plan.ag_elems, **f32)
-            lib().rv_plan_attach_comm_sharded(self._plan, comm.reduce_scatter_addr, comm.all_gather_addr, comm.handle,
-                                              comm.world, comm.rank, ptr(self._rs_buf), ptr(self._ag_buf))
+            d = self._comm_desc = _lib.CommDesc(comm=comm.handle, world=comm.world, rank=comm.rank,
+                                                reduce_scatter=comm.reduce_scatter_addr, all_gather=comm.all_gather_addr,
+                                                rs_buf=ptr(self._rs_buf), ag_buf=ptr(self._ag_buf),
+                                                comm_stream=self._comm_stream_ptr())
             gather = gather or ("fp32" if self.fp8 else "bf16")
             if gather not in ("bf16", "fp32") or (gather == "bf16" and self.fp8):
                 raise _lib.RvError("attach_comm: gather=%r (expected 'bf16' or 'fp32'; 'bf16' not with the fp8 forward)" % (gather,))
             self.shard_gather = gather
             if gather == "bf16":
-                slots = [lib().rv_plan_shard_msg_slots(self._plan, b, comm.world) for b in (0, 1)]
+                slots = [lib().rv_plan_shard_count(self._plan, b, comm.world, 1) for b in (0, 1)]
                 if min(slots) <= 0:
-                    raise _lib.RvError("rv_plan_shard_msg_slots failed")
+                    raise _lib.RvError("rv_plan_shard_count(msg_slots) failed")
                 i16 = dict(dtype=torch.int16, device=self.device)
                 self._msg_send = torch.zeros(sum(slots), **i16)
                 self._msg_recv = torch.zeros(comm.world * sum(slots), **i16)
                 self.msg_slots = slots
-                lib().rv_plan_set_shard_message(self._plan, ptr(self._msg_send), ptr(self._msg_recv))
+                d.msg_send, d.msg_recv = ptr(self._msg_send), ptr(self._msg_recv)
                 self._shared["bf16_gather_engine"] = self   # refresh_shadows of every engine on this arena gathers first
-            else:
-                lib().rv_plan_set_shard_message(self._plan, None, None)
         else:
-            lib().rv_plan_attach_comm(self._plan, comm.allreduce_addr, comm.handle, comm.world)
+            d = self._comm_desc = _lib.CommDesc(comm=comm.handle, world=comm.world, rank=getattr(comm, "rank", 0),
+                                                allreduce=comm.allreduce_addr, comm_stream=self._comm_stream_ptr())
+        lib().rv_plan_attach_comm(self._plan, C.byref(d))
         self._comm = comm   # keep the communicator alive as long as the plan can use it
+
+    def _comm_stream_ptr(self):
+        st = getattr(self, "_comm_stream", None)
+        return st.cuda_stream if st is not None else None
+
+    def _reattach(self, **fields):
+        """Change fields of the attached communicator descriptor (rv_comm_desc is copied by the library)."""
+        d = getattr(self, "_comm_desc", None)
+        if d is None:
+            raise _lib.RvError("no communicator attached (attach_comm)")
+        for k, v in fields.items():
+            setattr(d, k, v)
+        lib().rv_plan_attach_comm(self._plan, C.byref(d))
 
     def set_ddp_payload(self, payload):
         """Gradient all-reduce payload of `step_ddp`: "fp32" (default; exact mean of the ranks' fp32
@@ -288,9 +303,9 @@ class TrainEngine:
         if payload == "bf16":
             if getattr(self, "_grad_bf16", None) is None:
                 self._grad_bf16 = torch.empty(self.param.numel(), dtype=torch.bfloat16, device=self.param.device)
-            lib().rv_plan_set_ddp_payload(self._plan, self._grad_bf16.data_ptr())
+            self._reattach(grad_bf16=self._grad_bf16.data_ptr())
         else:
-            lib().rv_plan_set_ddp_payload(self._plan, None)
+            self._reattach(grad_bf16=None)
 
     def step_ddp(self, x, eps=None, recon_out=None, stream=None):
         """One whole data-parallel training step in one host call (`rv_plan_step_ddp`): every rank
@@ -321,7 +336,8 @@ class TrainEngine:
             return
         from . import ddp
         self._comm_stream = ddp.pick_comm_stream(st, self.device)
-        lib().rv_plan_set_comm_stream(self._plan, self._comm_stream.cuda_stream)
+        if getattr(self, "_comm_desc", None) is not None:   # else attach_comm hands it over
+            self._reattach(comm_stream=self._comm_stream.cuda_stream)
         self._comm_pick_for = st.cuda_stream
 
     def plan_descs(self, from_flat=False):

@@ -118,7 +118,7 @@ def _slab_sum(slabs, splits, rows_p, ld, rows, cols, row0=0, col0=0):
     d = (ParamDesc * 1)()
     base = slabs.data_ptr() + 4 * (row0 * ld + col0)
     d[0] = ParamDesc(0, rows, cols, base, ld, rows_p * ld, splits, None, None, 0)
-    lib().rv_grad_finalize(d, 1, ptr(out), stream_ptr())
+    lib().rv_grad_finalize(d, 1, ptr(out), 0, stream_ptr())
     return out
 
 
@@ -126,7 +126,7 @@ def _wgrad(dy, x, Mp, Np, Kp):
     """dW slabs for dy [Kp, Mp], x [Kp, Np] (both bf16 padded). Returns (slabs, splits)."""
     splits = gemm_pick(Mp, Np, Kp)[2]
     slabs = torch.empty((splits, Mp, Np), dtype=torch.float32, device=dy.device)
-    lib().rv_linear_wgrad(ptr(dy), Mp, ptr(x), Np, Mp, Np, Kp, splits, ptr(slabs), Np, stream_ptr())
+    lib().rv_linear_wgrad(ptr(dy), Mp, ptr(x), Np, Mp, Np, Kp, splits, -1, ptr(slabs), Np, 0, None, stream_ptr())
     return slabs, splits
 
 

@@ -116,7 +116,7 @@ class StrictFp32Engine:
             shp = self.shapes[k]
             rows, cols = (shp[0], shp[1]) if len(shp) == 2 else (1, shp[0])
             d[i] = ParamDesc(self.offsets[k], rows, cols, self.grad.data_ptr() + 4 * self.offsets[k], cols, 0, 1, None, None, 0)
-        lib().rv_adam_multi(d, 10, ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, self.lr, 1.0,
+        lib().rv_adam_multi(d, 10, ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, None, self.lr, 1.0,
                             ptr(self.step_counter), stream_ptr())
 
     def step(self, x, eps):

@@ -181,7 +181,7 @@ def test_shard_plan_matches_library():
         sizes = [H * S, H, Ld * H, Ld, Ld * H, Ld, H * Ld, H, S * H, S]
         for world in (1, 2, 3, 8):
             sp = ShardPlan(sum(sizes[:8]), sum(sizes), world)
-            assert [L.rv_plan_shard_count(plan, b, world) for b in (0, 1)] == sp.counts
+            assert [L.rv_plan_shard_count(plan, b, world, 0) for b in (0, 1)] == sp.counts
             for b in (0, 1):   # the shards tile the bucket exactly
                 lo, hi = sp.buckets[b]
                 spans = [sp.own(b, r) for r in range(world)]

@@ -162,7 +162,7 @@ def test_sharded_16bit_message_rebuilds_shadows_and_biases(world):
             lo, hi = sp.buckets[b]
             cnt = sp.counts[b]
             slots = L_.rv_shard_msg_slots(arr, nt, cnt)
-            assert slots == L_.rv_plan_shard_msg_slots(sh._plan, b, world) and slots % 8 == 0 and slots >= cnt
+            assert slots == L_.rv_plan_shard_count(sh._plan, b, world, 1) and slots % 8 == 0 and slots >= cnt
             gathered = torch.zeros(world * slots, dtype=torch.int16, device="cuda")
             for r in range(world):
                 a, e = sp.own(b, r)

@@ -104,7 +104,7 @@ def test_all_tiles_all_layouts(L, tile, M, N, K, splits):
     L.rv_linear_dgrad(A.data_ptr(), K, Bm.data_ptr(), N, M, N, K, None, 0, None, 0, None, out.data_ptr(), N, splits, sp())
     ref = a_km.astype(np.float64) @ b_mn.astype(np.float64)
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
-    L.rv_linear_wgrad(Am.data_ptr(), M, Bm.data_ptr(), N, M, N, K, splits, out.data_ptr(), N, sp())
+    L.rv_linear_wgrad(Am.data_ptr(), M, Bm.data_ptr(), N, M, N, K, splits, -1, out.data_ptr(), N, 0, None, sp())
     ref = a_mn.astype(np.float64).T @ b_mn.astype(np.float64)
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
@@ -175,7 +175,7 @@ def test_linear_wgrad(L, M, N, K, splits):
     dy, x = rand_bf16(rng, (K, M)), rand_bf16(rng, (K, N))
     dyd, xd = dev(dy, torch.bfloat16), dev(x, torch.bfloat16)
     out = torch.full((splits, M, N), 7.0, dtype=torch.float32, device="cuda")
-    L.rv_linear_wgrad(dyd.data_ptr(), M, xd.data_ptr(), N, M, N, K, splits, out.data_ptr(), N, sp())
+    L.rv_linear_wgrad(dyd.data_ptr(), M, xd.data_ptr(), N, M, N, K, splits, -1, out.data_ptr(), N, 0, None, sp())
     ref = dy.astype(np.float64).T @ x.astype(np.float64)
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
@@ -189,7 +189,7 @@ def test_gemm_identity_asymmetric(L):
     out = torch.zeros((1, M, N), dtype=torch.float32, device="cuda")
     L.rv_linear_dgrad(ad.data_ptr(), K, bd.data_ptr(), N, M, N, K, None, 0, None, 0, None, out.data_ptr(), N, 1, sp())
     np.testing.assert_array_equal(out[0].cpu().numpy(), b)
-    L.rv_linear_wgrad(ad.data_ptr(), M, bd.data_ptr(), N, M, N, K, 1, out.data_ptr(), N, sp())
+    L.rv_linear_wgrad(ad.data_ptr(), M, bd.data_ptr(), N, M, N, K, 1, -1, out.data_ptr(), N, 0, None, sp())
     np.testing.assert_array_equal(out[0].cpu().numpy(), b)
     bt = np.ascontiguousarray(b.T)
     btd = dev(bt, torch.bfloat16)
@@ -405,10 +405,10 @@ def test_adam_multi_and_finalize(L):
         descs[i] = ParamDesc(off, r, c, sd.data_ptr(), ld, (r + 2) * ld, splits, sh.data_ptr(), None, c + 3)
         off += r * c
     ctr = torch.full((1,), 3, dtype=torch.int64, device="cuda")
-    L.rv_grad_finalize(descs, len(shapes), gout.data_ptr(), sp())
+    L.rv_grad_finalize(descs, len(shapes), gout.data_ptr(), 0, sp())
     gflat = np.concatenate([g.reshape(-1) for g in grads])
     np.testing.assert_allclose(gout.cpu().numpy(), gflat, rtol=1e-6, atol=1e-6)
-    L.rv_adam_multi(descs, len(shapes), pd.data_ptr(), md.data_ptr(), vd.data_ptr(), None, 1e-3, 0.5,
+    L.rv_adam_multi(descs, len(shapes), pd.data_ptr(), md.data_ptr(), vd.data_ptr(), None, None, 1e-3, 0.5,
                     ctr.data_ptr(), sp())
     g = 0.5 * gflat.astype(np.float64)
     m = 0.9 * m0 + 0.1 * g
@@ -428,7 +428,7 @@ def test_adam_multi_and_finalize(L):
 
 @pytest.mark.parametrize("loader", ["lds_dma_ring", "plain_loads"])
 def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
-    """rv_linear_wgrad_adam: the weight-gradient GEMM must equal rv_linear_wgrad_ex bit for bit, and the optimizer
+    """rv_linear_wgrad_adam: the weight-gradient GEMM must equal rv_linear_wgrad bit for bit, and the optimizer
     blocks riding in its launch must equal rv_adam_multi bit for bit on a mixed bag of tensors -- aligned matrices
     with 4, 2 and 1 split-K slabs (the streamed path), a ragged matrix, short rows, a bias row summed by a wave
     (>= 16 partials), a bias row with few partials -- for both loaders of the optimizer blocks: a bag of fp32 slabs
@@ -490,8 +490,8 @@ def test_wgrad_launch_carrying_optimizer_blocks(L, loader):
                     t.zero_()
         pb, mb, vb = state()
         dwb = torch.zeros(splits, M, N, device="cuda")
-        L.rv_linear_wgrad_ex(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, 7, dwb.data_ptr(), N, 0, None, sp())
-        L.rv_adam_multi(descs, len(spec), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, 1e-3, 0.25, ctr.data_ptr(), sp())
+        L.rv_linear_wgrad(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, 7, dwb.data_ptr(), N, 0, None, sp())
+        L.rv_adam_multi(descs, len(spec), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, None, 1e-3, 0.25, ctr.data_ptr(), sp())
         torch.cuda.synchronize()
     finally:
         pass
@@ -526,8 +526,8 @@ def test_fp16_slabs_keep_their_precision_at_any_gradient_magnitude(L, tile, mag)
     w32 = torch.zeros(splits, M, N, device="cuda")
     w16 = torch.zeros(splits, M, N, dtype=torch.float16, device="cuda")
     us = torch.zeros(splits, M // 32, N // 32, device="cuda")
-    L.rv_linear_wgrad_ex(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w32.data_ptr(), N, 0, None, sp())
-    L.rv_linear_wgrad_ex(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w16.data_ptr(), N, 1, us.data_ptr(), sp())
+    L.rv_linear_wgrad(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w32.data_ptr(), N, 0, None, sp())
+    L.rv_linear_wgrad(dy.data_ptr(), M, x.data_ptr(), N, M, N, K, splits, tile, w16.data_ptr(), N, 1, us.data_ptr(), sp())
     torch.cuda.synchronize()
     ush = us.cpu().numpy()
     assert np.all(ush > 0) and np.all(np.log2(ush) == np.round(np.log2(ush)))   # exact powers of two
@@ -544,8 +544,8 @@ def test_fp16_slabs_keep_their_precision_at_any_gradient_magnitude(L, tile, mag)
     d16 = (ParamDesc * 1)(ParamDesc(0, M, N, w16.data_ptr(), N, M * N, splits, None, None, 0, None, None, 1,
                                     us.data_ptr(), N // 32, (M // 32) * (N // 32)))
     d32 = (ParamDesc * 1)(ParamDesc(0, M, N, w32.data_ptr(), N, M * N, splits, None, None, 0))
-    L.rv_grad_finalize(d16, 1, out16.data_ptr(), sp())
-    L.rv_grad_finalize(d32, 1, out32.data_ptr(), sp())
+    L.rv_grad_finalize(d16, 1, out16.data_ptr(), 0, sp())
+    L.rv_grad_finalize(d32, 1, out32.data_ptr(), 0, sp())
     torch.cuda.synchronize()
     a, b = out16.view(M, N).cpu().numpy(), out32.view(M, N).cpu().numpy()
     np.testing.assert_array_equal(a, deq.sum(0, dtype=np.float32))
@@ -599,7 +599,7 @@ def test_paired_dgrad_wgrad(L, force, loop, M, N, K):
         cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
         dw = torch.full((splits, K, N), 7.0, dtype=torch.float32, device="cuda")
         L.rv_linear_dgrad_wgrad(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N,
-                                cs.data_ptr(), dw.data_ptr(), N, splits, sp())
+                                cs.data_ptr(), dw.data_ptr(), N, splits, 0, None, sp())
         ref_dx = (dy.astype(np.float64) @ w.astype(np.float64)) * (x > 0)
         ref_dw = dy.astype(np.float64).T @ x.astype(np.float64)
         assert np.abs(dx.float().cpu().numpy() - ref_dx).max() <= 2 ** -7 * np.abs(ref_dx).max()
@@ -642,7 +642,7 @@ def test_heads_backward_dual_launch(L):
     cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
     dw = torch.full((splits, K, N), 7.0, dtype=torch.float32, device="cuda")
     L.rv_linear_dgrad_wgrad(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N,
-                            cs.data_ptr(), dw.data_ptr(), N, splits, sp())
+                            cs.data_ptr(), dw.data_ptr(), N, splits, 0, None, sp())
     ref_dx = (dy.astype(np.float64) @ w.astype(np.float64)) * (x > 0)
     ref_dw = dy.astype(np.float64).T @ x.astype(np.float64)
     assert np.abs(dx.float().cpu().numpy() - ref_dx).max() <= 2 ** -7 * np.abs(ref_dx).max()
@@ -651,7 +651,7 @@ def test_heads_backward_dual_launch(L):
 
 
 def test_bf16_gradient_payload_kernels(L):
-    """rv_grad_finalize_bf16 == bf16(rv_grad_finalize), and rv_adam_multi_bf16grad == rv_adam_multi fed the
+    """rv_grad_finalize(out_bf16) == bf16(rv_grad_finalize), and rv_adam_multi(grad_bf16) == rv_adam_multi fed the
     same (already bf16-valued) gradient."""
     from rawaudiovae_kelsey_amd._lib import ParamDesc
     rng = np.random.default_rng(45)
@@ -661,8 +661,8 @@ def test_bf16_gradient_payload_kernels(L):
     n = 8 + rows * cols + 5
     g32 = torch.zeros(n, device="cuda")
     g16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
-    L.rv_grad_finalize(d, 1, g32.data_ptr(), sp())
-    L.rv_grad_finalize_bf16(d, 1, g16.data_ptr(), sp())
+    L.rv_grad_finalize(d, 1, g32.data_ptr(), 0, sp())
+    L.rv_grad_finalize(d, 1, g16.data_ptr(), 1, sp())
     assert torch.equal(g16, g32.to(torch.bfloat16))
     step = torch.tensor([3], dtype=torch.int64, device="cuda")
     outs = []
@@ -670,12 +670,12 @@ def test_bf16_gradient_payload_kernels(L):
         p = dev(rng.standard_normal(n).astype(np.float32) * 0 + 0.5)
         m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
         if use_bf16:
-            L.rv_adam_multi_bf16grad(d, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(), 1e-3, 0.5,
+            L.rv_adam_multi(d, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), None, g16.data_ptr(), 1e-3, 0.5,
                                      step.data_ptr(), sp())
         else:
             flat = g16.float()
             df = (ParamDesc * 1)(ParamDesc(8, rows, cols, flat.data_ptr() + 4 * 8, cols, 0, 1, None, None, 0))
-            L.rv_adam_multi(df, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), None, 1e-3, 0.5, step.data_ptr(), sp())
+            L.rv_adam_multi(df, 1, p.data_ptr(), m.data_ptr(), v.data_ptr(), None, None, 1e-3, 0.5, step.data_ptr(), sp())
         torch.cuda.synchronize()
         outs.append((p.clone(), m.clone(), v.clone()))
     for a, b in zip(outs[0], outs[1]):

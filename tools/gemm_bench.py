@@ -50,16 +50,16 @@ cases = {
     "fc3 fwd   4096x2048x64   NT": (2 * B * H * L, lambda: Lb.rv_linear_fwd(P(z), L, P(W3), L, P(bH), B, H, L, 1, P(outH), H, st)),
     "fc4 fwd+loss 4096x1024x2048": (2 * B * S * H, lambda: Lb.rv_decode_out_loss_fwd(P(h), H, P(W4), H, P(bS), B, S, H, B, S, P(xf), S, None, S, P(outS), S, P(msep), P(cs), st)),
     "dgrad fc4 4096x2048x1024 NN": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), S, P(W4), H, B, H, S, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
-    "wgrad fc4 1024x2048x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(dp4), LD(S), P(h), LD(H), S, H, B, SPL["w4"], P(f32buf), H, st)),
-    "PAIR dgrad+wgrad fc4 (34.4GF)": (4 * B * H * S, lambda: Lb.rv_linear_dgrad_wgrad(P(dp4), LD(S), P(W4), LD(H), P(h), LD(H), B, H, S, P(outH), H, P(cs), P(f32buf), H, PAIR_S, st)),
+    "wgrad fc4 1024x2048x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(dp4), LD(S), P(h), LD(H), S, H, B, SPL["w4"], -1, P(f32buf), H, 0, None, st)),
+    "PAIR dgrad+wgrad fc4 (34.4GF)": (4 * B * H * S, lambda: Lb.rv_linear_dgrad_wgrad(P(dp4), LD(S), P(W4), LD(H), P(h), LD(H), B, H, S, P(outH), H, P(cs), P(f32buf), H, PAIR_S, 0, None, st)),
     "dz        4096x64x2048   NN": (2 * B * L * H, lambda: Lb.rv_linear_dgrad(P(h), H, P(W3), L, B, L, H, None, 0, None, 0, None, P(f32buf), L, SPL["dz"], st)),
-    "wgrad fc3 2048x64x4096   TN": (2 * B * L * H, lambda: Lb.rv_linear_wgrad(P(h), H, P(z), L, H, L, B, SPL["w3"], P(f32buf), L, st)),
+    "wgrad fc3 2048x64x4096   TN": (2 * B * L * H, lambda: Lb.rv_linear_wgrad(P(h), H, P(z), L, H, L, B, SPL["w3"], -1, P(f32buf), L, 0, None, st)),
     "dgrad hd  4096x2048x128  NN": (2 * B * H * L2, lambda: Lb.rv_linear_dgrad(P(dmulv), L2, P(Wh), H, B, H, L2, P(h), H, P(outH), H, P(cs), None, 0, 1, st)),
-    "wgrad hd  128x2048x4096  TN": (2 * B * H * L2, lambda: Lb.rv_linear_wgrad(P(dmulv), L2, P(h), H, L2, H, B, SPL["wh"], P(f32buf), H, st)),
+    "wgrad hd  128x2048x4096  TN": (2 * B * H * L2, lambda: Lb.rv_linear_wgrad(P(dmulv), L2, P(h), H, L2, H, B, SPL["wh"], -1, P(f32buf), H, 0, None, st)),
     "pure NT f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(x), LD(S), P(W1), LD(S), None, B, H, S, 1, P(f32buf), H, st)),
     "pure NN f32 4096x2048x1024": (2 * B * H * S, lambda: Lb.rv_linear_dgrad(P(dp4), LD(S), P(W4), LD(H), B, H, S, None, 0, None, 0, None, P(f32buf), H, 1, st)),
     "pure NT f32 4096x1024x2048": (2 * B * H * S, lambda: Lb.rv_linear_fwd_f32(P(h), LD(H), P(W4), LD(H), None, B, S, H, 1, P(f32buf), S, st)),
-    "wgrad fc1 2048x1024x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(h), LD(H), P(x), LD(S), H, S, B, SPL["w1"], P(f32buf), S, st)),
+    "wgrad fc1 2048x1024x4096 TN": (2 * B * H * S, lambda: Lb.rv_linear_wgrad(P(h), LD(H), P(x), LD(S), H, S, B, SPL["w1"], -1, P(f32buf), S, 0, None, st)),
 }
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events on the current stream
