@@ -193,6 +193,19 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                   float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream);
 
+/* The backward mirror of rv_latent_fwd's first two steps in ONE launch (same shape limits): dz = dP3 W3 (autograd of
+ * fc3's input, model.py:29) for 16 batch rows per workgroup over the full contraction, then rv_reparam_bwd's
+ * arithmetic on that block's dz while it is still in LDS -- no dz slabs, no second launch.  Arguments as
+ * rv_reparam_bwd with dP3 [Bp, Hp] bf16 and W3 [Hp, Lp] bf16 ([out, in]) in place of the dz slabs; dz differs from the
+ * split-K route by fp32 summation order only.  With z_bf16 != NULL the launch also computes fc3's weight gradient
+ * dW3 [Hp, Lp] = dP3^T z as `dw3_splits` fp32 slabs (rv_linear_wgrad's result, bit for bit) on extra workgroups that
+ * share the CUs with the dz workgroups (80 KiB of LDS each): the second read of dP3 fills the bubbles of the first. */
+int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw3, long Bp, long Hp, long Lp, long B,
+                  long L, long S, const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
+                  const float* dlv_ext, void* dmulv_bf16, float* dbh_partial, const float* mse_partial, int n_mse,
+                  const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,
+                  const void* z_bf16, long ldz, float* dw3_slabs, long lddw3, int dw3_splits, void* stream);
+
 /* Backward of reparameterize + KL:
  *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
  * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums
@@ -392,7 +405,8 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
 /* Plan options (the plan must be bound):
  *   RV_OPT_LATENT_FUSED  1 (default): heads GEMM, reparameterisation and fc3 of the forward are ONE launch
  *     (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 up to 2048 and the
- *     fp8 path off; 0, or any other shape: three launches (rv_heads_reparam_fwd + fc3).
+ *     fp8 path off, and dz + the reparameterisation backward likewise (rv_latent_bwd; not tied to fp8); 0, or any
+ *     other shape: three launches (rv_heads_reparam_fwd + fc3) and dz as split-K slabs + rv_reparam_bwd.
  *   RV_OPT_FP8  1: fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay
  *     bf16).  The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
  *       [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)

@@ -129,6 +129,9 @@ _SIGS = {
     "rv_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "rv_graph_launch": (c_int, [c_void_p, c_void_p]),
     "rv_graph_destroy": (None, [c_void_p]),
+    "rv_latent_bwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p,
+                              c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                              c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p]),
     "rv_gemm_plan": (c_int, [c_int, c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 4),
     "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_float, c_float, c_void_p, c_void_p]),

@@ -268,6 +268,176 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave's is in flight towards LDS when it ends
 }
 
+
+// `64` k-rows of 64 bf16 (row stride ld) -> MN-major LDS image at sl (gemm_bf16.h: [k][64 n], 32-byte chunks swizzled
+// by swz_mn<64>(k); fragments by load_frag<64, false>, i.e. transposing LDS reads): the operand whose contraction
+// index is the ROW of the matrix in memory
+__device__ __forceinline__ void stage_rows_mn64(const bf16_t* g, long ld, lds_char* sl, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kr = 8 * i + (lane >> 3), p16 = lane & 7;
+    const int c32 = (p16 >> 1) ^ swz_mn<64>(kr);
+    dma16(g + kr * ld + (c32 * 2 + (p16 & 1)) * 8, sl + i * 1024);
+  }
+}
+
+// The backward mirror of k_latent_fwd's first two steps: dz = dP3 W3 (autograd of fc3, model.py:29) for 16 batch rows
+// per workgroup over the FULL contraction (K = Hp cut over the 4 waves, private LDS-DMA rings, no barrier in the
+// streaming loop), then the backward of reparameterize + KL (k_reparam_bwd's arithmetic, elementwise.hip) on the
+// block's 16 x 64 dz while it is still in LDS: no dz slabs in HBM, no second launch.  Streams W3 (Hp x 64) + 16 rows
+// of dP3 through every CU: 320 KB at C2, and the CU's L2 -> LDS port is the bound again.
+// The launch has two more roles.  Blocks [n_rows, n_rows + n_w3): fc3's weight gradient dW3 = dP3^T z as an ordinary
+// split-K GEMM on 64 x 64 tiles (gemm_bf16.h's body, same 256 threads): it needs nothing this launch produces, and with
+// 80 KiB of LDS per workgroup a dz block and a dW3 block share every CU, so the second read of dP3 fills the bubbles of
+// the first instead of lengthening another launch.  The last block finishes the loss scalar.
+constexpr int LB_WAVES = 4;
+constexpr int LB_LDS = LB_WAVES * L_RING;   // 80 KiB: two workgroups per CU
+
+__global__ void __launch_bounds__(256)
+k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __restrict__ W3, const long ldw3,
+             const long Hp, const long B, const long L, const long S, const float* __restrict__ mulv,
+             const float* __restrict__ eps, const float kl_beta, const float* __restrict__ dmu_ext,
+             const float* __restrict__ dlv_ext, bf16_t* __restrict__ dmulv, float* __restrict__ dbh_partial,
+             const float* __restrict__ mse_partial, const int n_mse, const float* __restrict__ kl_partial,
+             const int n_kl, float* __restrict__ loss_out, const long long* __restrict__ step_counter, const int ring_n,
+             const int n_rows, const GemmArgs w3grad) {
+  constexpr long Lp = 64, L2p = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  lds_char* smem = (lds_char*)smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float inv_nk = 1.0f / ((float)B * (float)L);
+  if ((int)blockIdx.x >= n_rows) {
+    if (blockIdx.x != gridDim.x - 1) {   // fc3's weight gradient, one 64 x 64 tile of one K split
+      gemm_body<64, 64, 2, 2, false, false, EPI_F32, 2>(w3grad, (int)blockIdx.x - n_rows, smem_dyn);
+      return;
+    }
+    if (loss_out && mse_partial && kl_partial) {   // the loss scalar (k_reparam_bwd's extra block, same summation order)
+      float* red = (float*)smem_dyn;
+      float m = 0.f, k = 0.f;
+      for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+      for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+      m = block_sum_256(m, red);
+      k = block_sum_256(k, red);
+      if (tid == 0) {
+        const float mse = m / ((float)B * (float)S);
+        const float kld = -0.5f * k * inv_nk;
+        if (step_counter && ring_n > 0) loss_out += 4 * ((*step_counter - 1) % ring_n);
+        loss_out[0] = mse + kl_beta * kld;
+        loss_out[1] = mse;
+        loss_out[2] = kld;
+      }
+    }
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const long r0 = (long)blockIdx.x * LAT_ROWS;
+  lds_char* ring = smem + wave * L_RING;
+  lds_char* const W0 = ring, * const W1 = ring + LW_SLOT;
+  const long kw = Hp / LB_WAVES;
+  const int NU = (int)(kw / 64);
+  const int bi = (int)(blockIdx.x >> 3);   // the forward's stagger (see k_latent_fwd), over 4 slices
+  const int ks = (wave + bi) & (LB_WAVES - 1);
+  const int rot = (bi >> 2) % NU;
+  auto walk = [&](int s) { const int t = s + rot; return t >= NU ? t - NU : t; };
+  const bf16_t* xg = dP3 + r0 * lddp + ks * kw;
+  const bf16_t* wg = W3 + ks * kw * ldw3;
+  auto issue = [&](int s) {   // 2 + 8 LDS-DMA instructions
+    stage_rows<16>(xg + 64 * walk(s), lddp, ring + LX_OFF + (s & 1) * LX_SLOT, lane);
+    stage_rows_mn64(wg + (long)(64 * walk(s)) * ldw3, ldw3, (s & 1) ? W1 : W0, lane);
+  };
+  // the epilogue's operands (thread: row rr, columns l..l+3) are requested before the stream starts
+  const int rr = tid >> 4;
+  const long b = r0 + rr, l = (long)(tid & 15) * 4;
+  const bool live = b < B && l < L;
+  float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), lv4 = mu4;
+  float ev[4] = {0.f, 0.f, 0.f, 0.f}, xm[4] = {0.f, 0.f, 0.f, 0.f}, xv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    mu4 = *reinterpret_cast<const float4*>(mulv + b * L2p + l);
+    lv4 = *reinterpret_cast<const float4*>(mulv + b * L2p + Lp + l);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (l + e < L) {
+        ev[e] = eps[b * L + l + e];
+        if (dmu_ext) xm[e] = dmu_ext[b * L + l + e];
+        if (dlv_ext) xv[e] = dlv_ext[b * L + l + e];
+      }
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0);
+  if (NU > 1) issue(1);
+  for (int s = 0; s < NU; ++s) {
+    // step s needs X(s), W(s); the only younger pieces are step s + 1's ten
+    if (s + 1 < NU) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const lds_char* ws = (s & 1) ? W1 : W0;
+    bf16x8 x[2], w[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) x[kk] = load_frag<16, true>(ring + LX_OFF + (s & 1) * LX_SLOT, 0, kk, lane);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, false>(ws, cb * 16, kk, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: both slots may be refilled
+    if (s + 2 < NU) issue(s + 2);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[cb], 0, 0, 0);
+  }
+  // lane (q, j) holds partial dz[j][16 cb + 4 q + e]: park the wave's 16 x 64 partial sums in its weight slot 0
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+    *(__attribute__((address_space(3))) f32x4*)(W0 + (j * 64 + cb * 16 + q * 4) * 4) = acc[cb];
+  __syncthreads();
+
+  float dmu[4] = {0.f, 0.f, 0.f, 0.f}, dlv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    f32x4 pz[LB_WAVES];
+#pragma unroll
+    for (int w = 0; w < LB_WAVES; ++w)
+      pz[w] = *(const __attribute__((address_space(3))) f32x4*)(smem + w * L_RING + (rr * 64 + l) * 4);
+    const float mua[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, lva[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (l + e < L) {
+        const float dz = (pz[0][e] + pz[1][e]) + (pz[2][e] + pz[3][e]);
+        const float sd = __expf(0.5f * lva[e]);
+        dmu[e] = dz + kl_beta * mua[e] * inv_nk;
+        dlv[e] = dz * ev[e] * 0.5f * sd + kl_beta * 0.5f * (sd * sd - 1.f) * inv_nk;
+        if (dmu_ext) dmu[e] += xm[e];   // gradients arriving from outside (autograd)
+        if (dlv_ext) dlv[e] += xv[e];
+      }
+    }
+  }
+  const bf16x4 m4 = {(bf16_t)dmu[0], (bf16_t)dmu[1], (bf16_t)dmu[2], (bf16_t)dmu[3]};
+  const bf16x4 v4 = {(bf16_t)dlv[0], (bf16_t)dlv[1], (bf16_t)dlv[2], (bf16_t)dlv[3]};
+  *reinterpret_cast<bf16x4*>(dmulv + b * L2p + l) = m4;
+  *reinterpret_cast<bf16x4*>(dmulv + b * L2p + Lp + l) = v4;
+  // column sums (bias gradients of fc21 | fc22) through the activation slots of waves 0 and 1 (idle by now)
+  *(__attribute__((address_space(3))) f32x4*)(smem + 0 * L_RING + LX_OFF + tid * 16) = f32x4{dmu[0], dmu[1], dmu[2], dmu[3]};
+  *(__attribute__((address_space(3))) f32x4*)(smem + 1 * L_RING + LX_OFF + tid * 16) = f32x4{dlv[0], dlv[1], dlv[2], dlv[3]};
+  __syncthreads();
+  if (dbh_partial && tid < 64) {
+    // column tid = group (tid / 4), element (tid % 4); rows in ascending order (k_reparam_bwd's order)
+    const int g = tid >> 2, e = tid & 3;
+    const __attribute__((address_space(3))) float* sm = (const __attribute__((address_space(3))) float*)(smem + 0 * L_RING + LX_OFF);
+    const __attribute__((address_space(3))) float* sv = (const __attribute__((address_space(3))) float*)(smem + 1 * L_RING + LX_OFF);
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a += sm[(r * 16 + g) * 4 + e];
+      c += sv[(r * 16 + g) * 4 + e];
+    }
+    dbh_partial[(long)blockIdx.x * L2p + tid] = a;
+    dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -297,6 +467,46 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
                      (bf16_t*)h3_bf16, ldh3, rv_store_wt);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw3, long Bp, long Hp, long Lp, long B,
+                  long L, long S, const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
+                  const float* dlv_ext, void* dmulv_bf16, float* dbh_partial, const float* mse_partial, int n_mse,
+                  const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,
+                  const void* z_bf16, long ldz, float* dw3_slabs, long lddw3, int dw3_splits, void* stream) {
+  RV_REQUIRE(dp3_bf16 && w3_bf16 && mulv && eps && dmulv_bf16, RV_ERR_NULL, "rv_latent_bwd: null pointer");
+  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_bwd: built for a padded latent width of 64 (got %ld)", Lp);
+  RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
+             "rv_latent_bwd: the hidden width must be a multiple of 512 up to 2048 (got %ld)", Hp);
+  RV_REQUIRE(Bp > 0 && Bp % 64 == 0 && B <= Bp && L <= Lp && lddp >= Hp && ldw3 >= Lp && lddp % 8 == 0 &&
+                 ldw3 % 8 == 0, RV_ERR_SHAPE, "rv_latent_bwd: bad extents Bp %ld Hp %ld", Bp, Hp);
+  RV_REQUIRE((((uintptr_t)dp3_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)mulv | (uintptr_t)dmulv_bf16) & 15) == 0, RV_ERR_SHAPE,
+             "rv_latent_bwd: operands must be 16-byte aligned");
+  GemmArgs g{};
+  int n_w3 = 0;
+  if (z_bf16) {   // fc3's weight gradient rides along: dW3 [Hp, Lp] = dP3^T z, `dw3_splits` fp32 slabs over the batch
+    RV_REQUIRE(dw3_slabs && dw3_splits >= 1 && (Bp / 64) % dw3_splits == 0 && ldz >= Lp && ldz % 8 == 0 && lddw3 >= Lp &&
+                   ((uintptr_t)z_bf16 & 15) == 0 && ((uintptr_t)dw3_slabs & 15) == 0 && lddw3 % 4 == 0,
+               RV_ERR_SHAPE, "rv_latent_bwd: bad weight-gradient arguments (splits %d)", dw3_splits);
+    g.A = (const bf16_t*)dp3_bf16; g.lda = lddp; g.B = (const bf16_t*)z_bf16; g.ldb = ldz;
+    g.k_tiles = (int)(Bp / 64 / dw3_splits); g.M_valid = (int)Hp; g.N_valid = (int)Lp;
+    g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
+    g.tiles_m = (int)(Hp / 64); g.tiles_n = 1; g.splits = dw3_splits;
+    g.wt = rv_store_wt;
+    n_w3 = g.tiles_m * g.tiles_n * g.splits;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_latent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
+    attr_done = true;
+  }
+  const int n_rows = (int)(Bp / LAT_ROWS);
+  hipLaunchKernelGGL(k_latent_bwd, dim3((unsigned)(n_rows + n_w3 + 1)), dim3(256), LB_LDS, (hipStream_t)stream,
+                     (const bf16_t*)dp3_bf16, lddp, (const bf16_t*)w3_bf16, ldw3, Hp, B, L, S, mulv, eps, kl_beta, dmu_ext,
+                     dlv_ext, (bf16_t*)dmulv_bf16, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
+                     step_counter, ring, n_rows, g);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

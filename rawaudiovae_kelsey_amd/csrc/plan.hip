@@ -372,6 +372,37 @@ struct WtScope {
   ~WtScope() { rv::rv_store_wt = prev; }
 };
 
+// The latent-sized backward between the fc4 pair and fc1's weight gradient: dz, the reparameterisation backward (which
+// also finishes the loss), fc3's weight gradient, and the heads' dgrad + wgrad.  Row-local form (RV_OPT_LATENT_FUSED,
+// padded latent width 64): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of the same launch) and the
+// heads' backward -- two launches.  Otherwise three: dz + dW3 as split-K slabs, rv_reparam_bwd, the heads' backward.
+static bool latent_bwd_fused(const rv_plan* p) { return p->latent_fused && p->Lp == 64 && p->Hp % 512 == 0 && p->Hp <= 2048; }
+
+static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, const float* dmu_ext, const float* dlv_ext,
+                            void* stream) {
+  const long Bp = p->Bp, Hp = p->Hp, Lp = p->Lp, L2p = 2 * p->Lp, B = p->B, L = p->L, S = p->S;
+  void* dP3 = p->ws("dP3"); void* z = p->ws("z"); void* h1 = p->ws("h1"); void* dP1 = p->ws("dP1"); void* dmulv = p->ws("dmulv");
+  float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
+  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  int rc;
+  if (latent_bwd_fused(p)) {
+    rc = rv_latent_bwd(dP3, Hp, p->ws("W3b"), Lp, Bp, Hp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv,
+                       (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter,
+                       p->b.ring, z, Lp, (float*)p->ws("dW3"), Lp, p->s_w3, stream);
+    if (rc) return rc;
+    return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
+                                 p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream);
+  }
+  rc = rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz, (float*)p->ws("dW3"), Lp,
+                                 p->s_w3, stream);
+  if (rc) return rc;
+  rc = rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv, (float*)p->ws("dbhp"),
+                      mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream);
+  if (rc) return rc;
+  return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"), p->ws("dWh"), Hp,
+                               p->s_wh, RV_SLAB_F32, nullptr, stream);
+}
+
 int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float* recon_out,
                  float kl_beta, float lr, float grad_scale, int adam_from_flat,
                  unsigned long long seed, void* stream) {
@@ -482,9 +513,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
     RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-    RV_TRY(latent_bwd(stream));
-    RV_TRY(reparam_bwd(stream));
-    RV_TRY(heads_bwd(stream));
+    RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
     // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
     // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
     RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
@@ -510,18 +539,32 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   if (do_pair)
     RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  if (do_chain_a && do_w3) {
-    RV_TRY(latent_bwd(stream));
-  } else if (do_chain_a) {
-    RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
-                           p->s_dz, stream));
+  bool w3_done = false;
+  if (do_chain_a && do_chain_b && do_w3) {
+    RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, stream));
+    w3_done = true;
+  } else {
+    if (do_chain_a && latent_bwd_fused(p)) {
+      RV_TRY(rv_latent_bwd(dP3, Hp, p->ws("W3b"), Lp, Bp, Hp, Lp, B, L, S, mulv, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, dmulv,
+                           (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter,
+                           p->b.ring, do_w3 ? z : nullptr, Lp, (float*)p->ws("dW3"), Lp, p->s_w3, stream));
+      w3_done = do_w3;
+    } else if (do_chain_a) {
+      if (do_w3) {
+        RV_TRY(latent_bwd(stream));
+        w3_done = true;
+      } else {
+        RV_TRY(rv_linear_dgrad(dP3, Hp, p->ws("W3b"), Lp, Bp, Lp, Hp, nullptr, 0, nullptr, 0, nullptr, dz_slabs, Lp,
+                               p->s_dz, stream));
+      }
+      RV_TRY(reparam_bwd(stream));
+    }
+    if (do_chain_b) RV_TRY(heads_bwd(stream));
   }
-  if (do_chain_a) RV_TRY(reparam_bwd(stream));
   if (do_chain_b) {
-    RV_TRY(heads_bwd(stream));
     RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   }
-  if (do_w3 && !do_chain_a) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, RV_TILE_AUTO, p->ws("dW3"), Lp, RV_SLAB_F32, nullptr, stream));
+  if (do_w3 && !w3_done) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, RV_TILE_AUTO, p->ws("dW3"), Lp, RV_SLAB_F32, nullptr, stream));
 
   // tensor masks (bit i = parameter i in state_dict order)
   unsigned fin = 0, adam = 0;
@@ -649,11 +692,9 @@ static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) 
 // behind the rest of backward, RS(rest), Adam on the own shards, AG(fc4), AG(rest) on the caller's stream.
 static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                             unsigned long long seed, void* stream) {
-  const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
-  void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
-  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
-  float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
-  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
+  void* xb = p->ws("xb"); void* h3 = p->ws("h3");
+  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dP1 = p->ws("dP1");
   const float* eps_used = eps ? eps : (float*)p->ws("eps");
   hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
   const float scale = 1.0f / (float)p->world;
@@ -677,12 +718,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
   RV_TRY(scatter_bucket(0, sc));                              // fc4's 8.4 MB travel behind the rest of backward
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
-  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
-                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
-  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
-                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                               (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream));
+  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
   RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, 0, stream));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: fc4's reduce-scatter is done
@@ -729,11 +765,9 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   WtScope wt_scope;
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
-  const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
-  void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
-  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
-  float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
-  float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
+  void* xb = p->ws("xb"); void* h3 = p->ws("h3");
+  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dP1 = p->ws("dP1");
   const float* eps_used = eps ? eps : (float*)p->ws("eps");
   hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
   const float scale = 1.0f / (float)p->world;
@@ -774,12 +808,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
   RV_TRY(reduce(0, 8, 10, sc));
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
-  RV_TRY(rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz,
-                                   (float*)p->ws("dW3"), Lp, p->s_w3, stream));
-  RV_TRY(rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, nullptr, nullptr, dmulv, (float*)p->ws("dbhp"),
-                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                               (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream));
+  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));        // the join: fc4's sum has arrived
   const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
   if (!p->payload_bf16 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && n_gemm <= 192) {

@@ -300,9 +300,34 @@ def test_full_step_equals_its_phases(shape):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 512, 16, 384)])
+def test_backward_in_one_go_equals_the_finer_phases(shape):
+    """The latent-sized backward as the full step issues it (rv_latent_bwd with fc3's weight gradient on extra
+    workgroups of its launch, then the heads' backward) against the same backward issued phase by phase (BWD_FC4,
+    BWD_CHAIN, BWD_REST: fc3's weight gradient then is a launch of its own): every gradient bit for bit."""
+    from rawaudiovae_kelsey_amd import engine as E
+    S, H, L, B = shape
+    x, eps = torch.from_numpy(make_frames(B, S, 31)).cuda(), torch.from_numpy(make_eps(B, L, 32)).cuda()
+    fin = E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B
+    out = []
+    for fine in (False, True):
+        e = _engine(S, H, L, B)
+        if fine:
+            for ph in (E.PHASE_FWD, E.PHASE_BWD_FC4, E.PHASE_BWD_CHAIN, E.PHASE_BWD_REST, fin):
+                e.step(x, eps, phases=ph)
+        else:
+            e.step(x, eps, phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | fin)
+        torch.cuda.synchronize()
+        out.append(({k: v.clone() for k, v in e.grad_views().items()}, e.last_loss()))
+    assert out[0][1] == out[1][1]
+    for k in PARAM_NAMES:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
+        assert float(out[0][0][k].abs().max()) > 0, k
+
+
 def test_latent_forward_one_launch_vs_three_in_the_step():
-    """The step with heads + reparam + fc3 as one launch (`set_latent_fused(True)`, the default where it applies) against
-    the default step with the three launches: same eps, losses equal to fp32 summation order, parameters after 5 steps
+    """The step with heads + reparam + fc3 as one launch and dz + reparam backward as one launch
+    (`set_latent_fused(True)`, the default where it applies) against the step with the three + three launches: same eps, losses equal to fp32 summation order, parameters after 5 steps
     agree like two summation orders do."""
     from oracle.inputs import make_frames, make_params
     from rawaudiovae_kelsey_amd.engine import TrainEngine

@@ -381,6 +381,81 @@ def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
                         h31.data_ptr(), Hp, sp())
 
 
+@pytest.mark.parametrize("B,Lt,H,ext", [(100, 3, 512, False), (4096, 64, 2048, False), (300, 40, 900, True)])
+def test_latent_bwd_one_launch_equals_two(L, B, Lt, H, ext):
+    """rv_latent_bwd (dz = dP3 W3 over the full contraction + the reparameterisation / KL backward + the loss scalar
+    + fc3's weight gradient on extra workgroups, one launch) against the route it replaces (rv_linear_dgrad into fp32 split-K slabs + rv_reparam_bwd) and against
+    float64 numpy, on the same bf16 operands.  Stated bound: dz is a 512..2048-term bf16-product sum accumulated in
+    fp32 in another order -> 1e-5 relative to the row's term scale; dmulv is rounded to bf16 once (<= 1 ulp apart)."""
+    rng = np.random.default_rng(19)
+    Bp, Lp, Hp, S = -(-B // 128) * 128, 64, -(-H // 512) * 512, 512
+    dp3 = np.zeros((Bp, Hp), np.float32); dp3[:B, :H] = rand_bf16(rng, (B, H), 1e-3)
+    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.2)
+    mulv = np.zeros((Bp, 2 * Lp), np.float32)
+    mulv[:B, :Lt] = rng.standard_normal((B, Lt)) * 0.5; mulv[:B, Lp:Lp + Lt] = rng.standard_normal((B, Lt)) * 0.3
+    eps = rng.standard_normal((B, Lt)).astype(np.float32)
+    xm = (rng.standard_normal((B, Lt)) * 1e-3).astype(np.float32) if ext else None
+    xv = (rng.standard_normal((B, Lt)) * 1e-3).astype(np.float32) if ext else None
+    n_mse, n_kl, kl_beta = 37, Bp // 16, 1e-2
+    msep = rng.random(n_mse).astype(np.float32); klp = -rng.random(n_kl).astype(np.float32)
+    dpd, w3d, mvd, ed = dev(dp3, torch.bfloat16), dev(w3, torch.bfloat16), dev(mulv), dev(eps)
+    xmd, xvd = (dev(xm), dev(xv)) if ext else (None, None)
+    msed, kld = dev(msep), dev(klp)
+    ctr = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    P = lambda t: None if t is None else t.data_ptr()
+    zz = np.zeros((Bp, Lp), np.float32); zz[:B, :Lt] = rand_bf16(rng, (B, Lt), 1.0)
+    zd = dev(zz, torch.bfloat16)
+    w3s = 2 if Bp % 128 == 0 else 1
+    dw3a, dw3b = torch.full((w3s, Hp, Lp), 7.0, device="cuda"), torch.empty(w3s, Hp, Lp, device="cuda")
+
+    def outs():
+        return (torch.full((Bp, 2 * Lp), 7.0, device="cuda", dtype=torch.bfloat16), torch.zeros(Bp // 16, 2 * Lp, device="cuda"),
+                torch.zeros(4, 4, device="cuda"))
+    dm1, db1, loss1 = outs()
+    L.rv_latent_bwd(dpd.data_ptr(), Hp, w3d.data_ptr(), Lp, Bp, Hp, Lp, B, Lt, S, mvd.data_ptr(), ed.data_ptr(), kl_beta,
+                    P(xmd), P(xvd), dm1.data_ptr(), db1.data_ptr(), msed.data_ptr(), n_mse, kld.data_ptr(), n_kl,
+                    loss1.data_ptr(), ctr.data_ptr(), 4, zd.data_ptr(), Lp, dw3a.data_ptr(), Lp, w3s, sp())
+    dm2, db2, loss2 = outs()
+    splits = 4
+    slabs = torch.empty(splits, Bp, Lp, device="cuda")
+    L.rv_linear_dgrad(dpd.data_ptr(), Hp, w3d.data_ptr(), Lp, Bp, Lp, Hp, None, 0, None, 0, None, slabs.data_ptr(), Lp, splits, sp())
+    L.rv_reparam_bwd(slabs.data_ptr(), splits, Bp, Lp, B, Lt, S, mvd.data_ptr(), ed.data_ptr(), kl_beta, P(xmd), P(xvd),
+                     dm2.data_ptr(), db2.data_ptr(), msed.data_ptr(), n_mse, kld.data_ptr(), n_kl, loss2.data_ptr(),
+                     ctr.data_ptr(), 4, sp())
+    # float64 reference
+    dz = dp3[:B].astype(np.float64) @ w3[:, :Lt].astype(np.float64)
+    mu, lv = mulv[:B, :Lt].astype(np.float64), mulv[:B, Lp:Lp + Lt].astype(np.float64)
+    sd = np.exp(0.5 * lv); ink = 1.0 / (B * Lt)
+    dmu = dz + kl_beta * mu * ink + (xm if ext else 0)
+    dlv = dz * eps * 0.5 * sd + kl_beta * 0.5 * (sd * sd - 1) * ink + (xv if ext else 0)
+    g1, g2 = dm1.float().cpu().numpy(), dm2.float().cpu().numpy()
+    scale = np.abs(dp3[:B]).astype(np.float64) @ np.abs(w3[:, :Lt]).astype(np.float64)
+    tol = 2.0 ** -8 * np.abs(dmu) + 1e-5 * scale + 1e-12   # one bf16 rounding + the fp32 accumulation
+    assert (np.abs(g1[:B, :Lt] - dmu) <= tol).all()
+    tol_v = 2.0 ** -8 * np.abs(dlv) + 1e-5 * scale * np.abs(eps) * sd + 1e-12
+    assert (np.abs(g1[:B, Lp:Lp + Lt] - dlv) <= tol_v).all()
+    assert not g1[B:].any() and not g1[:, Lt:Lp].any() and not g1[:, Lp + Lt:].any()
+    # against the two-launch route: equal up to one bf16 ulp where the fp32 sums differ in the last bits
+    assert np.mean(g1 != g2) < 0.05
+    np.testing.assert_allclose(g1, g2, rtol=2.0 ** -7, atol=1e-5 * float(scale.max()))   # (sums that nearly cancel)
+    # bias-gradient partials: column sums of the UNROUNDED dmu / dlv over each 16-row block
+    ref_db = np.zeros((Bp, 2 * Lp)); ref_db[:B, :Lt] = dmu; ref_db[:B, Lp:Lp + Lt] = dlv
+    ref_db = ref_db.reshape(Bp // 16, 16, 2 * Lp).sum(1)
+    np.testing.assert_allclose(db1.cpu().numpy(), ref_db, rtol=1e-4, atol=1e-4 * np.abs(ref_db).max())
+    np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.abs(ref_db).max())
+    # fc3's weight gradient on the launch's extra workgroups == rv_linear_wgrad, bit for bit, and right
+    L.rv_linear_wgrad(dpd.data_ptr(), Hp, zd.data_ptr(), Lp, Hp, Lp, Bp, w3s, -1, dw3b.data_ptr(), Lp, 0, None, sp())
+    assert torch.equal(dw3a, dw3b)
+    ref_w3 = dp3.astype(np.float64).T @ zz.astype(np.float64)
+    np.testing.assert_allclose(dw3a.double().sum(0).cpu().numpy(), ref_w3, rtol=1e-4, atol=1e-5 * np.abs(ref_w3).max())
+    # the loss scalar: same summation order as rv_reparam_bwd's -> bit-equal; slot (3 - 1) % 4 of the ring
+    assert torch.equal(loss1, loss2) and float(loss1[2, 0]) != 0.0 and not loss1[[0, 1, 3]].any()
+    from rawaudiovae_kelsey_amd import _lib
+    with pytest.raises(_lib.RvError):
+        L.rv_latent_bwd(dpd.data_ptr(), Hp, w3d.data_ptr(), Lp, Bp, Hp, 128, B, Lt, S, mvd.data_ptr(), ed.data_ptr(), kl_beta,
+                        None, None, dm1.data_ptr(), db1.data_ptr(), None, 0, None, 0, None, None, 0, None, 0, None, 0, 0, sp())
+
+
 def test_adam_multi_and_finalize(L):
     from rawaudiovae_kelsey_amd._lib import ParamDesc
     rng = np.random.default_rng(8)
