@@ -493,10 +493,23 @@ k_gather_frames(const float* __restrict__ audio, long n_samples, const long long
 // ---- sharded data-parallel optimizer (rv_plan_step_ddp, sharded mode) ----
 // Adam on one rank's contiguous shard [lo, lo + n) of the flat arenas; the gradient comes from the reduce-scatter's
 // output buffer (element i of the shard at grad_shard[i]).  Same arithmetic, in the same order, as adam_block.
+struct MsgBias { long offset, n, side; };            // arena offset, elements, first index in the side region
+struct MsgBiasTable { MsgBias b[4]; int n; };
+
 __global__ void __launch_bounds__(256)
 k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __restrict__ v_arena,
             const float* __restrict__ grad_shard, const long lo, const long n, const float lr, const float grad_scale,
-            const long long* __restrict__ step_counter) {
+            const long long* __restrict__ step_counter, unsigned short* __restrict__ msg, const long cnt,
+            const MsgBiasTable bt) {
+  // msg != null: the updated shard also goes out as this rank's 16-bit parameter message (k_shard_encode's layout and
+  // rounding: bf16 of element i at slot i, then the bucket's bias rows as fp32 -- only the owned ones are written,
+  // the rest of the caller's zero-initialised message is never read)
+  auto emit_bias = [&](long o, float w) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < bt.n && o >= bt.b[t].offset && o < bt.b[t].offset + bt.b[t].n)
+        reinterpret_cast<float*>(msg + cnt)[bt.b[t].side + (o - bt.b[t].offset)] = w;
+  };
   float step_size, bc2s;   // bc2s: 1 / sqrt(1 - beta2^t)
   adam_step_consts(step_counter, lr, &step_size, &bc2s);
   const bool vec = (lo & 3) == 0 && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m_arena) |
@@ -513,6 +526,13 @@ k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __res
     reinterpret_cast<float4*>(m_arena + lo)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
     reinterpret_cast<float4*>(v_arena + lo)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     reinterpret_cast<float4*>(param + lo)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    if (msg) {
+      const bf16x4 o = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
+      *reinterpret_cast<bf16x4*>(msg + 4 * i) = o;
+      if (bt.n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) emit_bias(lo + 4 * i + j, wv[j]);
+    }
   }
   for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float g = grad_shard[i] * grad_scale;
@@ -521,6 +541,11 @@ k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __res
     m_arena[lo + i] = m_;
     v_arena[lo + i] = v_;
     param[lo + i] = w_;
+    if (msg) {
+      const bf16_t o = (bf16_t)w_;
+      msg[i] = *reinterpret_cast<const unsigned short*>(&o);
+      emit_bias(lo + i, w_);
+    }
   }
 }
 
@@ -544,8 +569,7 @@ inline unsigned grid_for(long n_threads, long cap = 2048) {
 //                               bias tensors); a rank fills the ones it owns and zeroes the others
 // so that an all-gather of cnt + 2 nbias 16-bit slots per rank (half the bytes of the fp32 parameters) lets every rank
 // rebuild every bf16 weight shadow and -- exactly -- every bias.  fp32 weight masters stay current on their owner.
-struct MsgBias { long offset, n, side; };            // arena offset, elements, first index in the side region
-struct MsgBiasTable { MsgBias b[4]; int n; };
+
 
 __global__ void __launch_bounds__(256)
 k_shard_encode(const float* __restrict__ param, const long own, const long n, const long cnt, const MsgBiasTable bt,
@@ -610,6 +634,8 @@ k_shadows_from_msg(const MsgTable tab, const unsigned short* __restrict__ msg, c
 }
 
 }  // namespace
+
+static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* bt, long* nbias);
 
 extern "C" {
 
@@ -850,7 +876,26 @@ int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* g
   RV_REQUIRE(lo >= 0 && n >= 0, RV_ERR_SHAPE, "rv_adam_flat: bad range %ld + %ld", lo, n);
   if (n == 0) return RV_OK;
   hipLaunchKernelGGL(k_adam_flat, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, param, exp_avg,
-                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter);
+                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter, (unsigned short*)nullptr, 0L, MsgBiasTable{});
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+// rv_adam_flat that also emits the rank's 16-bit parameter message for the bucket made of `descs` (what rv_shard_encode
+// would produce from the updated parameters, bit for bit; `msg` zero-initialised by the caller once): one pass less.
+int rv_adam_flat_msg(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
+                     const float* grad_shard, long lo, long n, long cnt, float lr, float grad_scale,
+                     const long long* step_counter, void* msg, void* stream) {
+  RV_REQUIRE(descs && param && exp_avg && exp_avg_sq && grad_shard && step_counter && msg, RV_ERR_NULL, "rv_adam_flat_msg: null pointer");
+  RV_REQUIRE(lo >= 0 && n >= 0 && n <= cnt && cnt % 4 == 0 && ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE,
+             "rv_adam_flat_msg: shard of %ld in slots of %ld", n, cnt);
+  if (n == 0) return RV_OK;
+  MsgBiasTable bt;
+  long nbias = 0;
+  int rc = msg_bias_table(descs, n_desc, &bt, &nbias);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam_flat, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, param, exp_avg,
+                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter, (unsigned short*)msg, cnt, bt);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -870,6 +915,7 @@ int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* fla
 }
 
 // ---- sharded optimizer, 16-bit parameter message (see k_shard_encode)
+}  // extern "C"
 static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* bt, long* nbias) {
   bt->n = 0;
   *nbias = 0;
@@ -881,6 +927,7 @@ static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* 
   }
   return RV_OK;
 }
+extern "C" {
 
 long rv_shard_msg_slots(const rv_param_desc* descs, int n_desc, long cnt) {
   MsgBiasTable bt;

@@ -42,3 +42,9 @@ RV_INTERNAL int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const vo
                                               const float* audio, long n_samples, const long long* frame_index,
                                               long first_frame, long hop, float* recon, long ld_recon, void* dP4_bf16,
                                               long ld_dp4, float* mse_partial, float* db4_partial, void* stream);
+// rv_adam_flat that also emits the rank's 16-bit parameter message for the bucket `descs` (rv_shard_encode's output from
+// the updated parameters, bit for bit; the caller zero-initialises `msg` once): the sharded step's update and encode in
+// one pass.
+RV_INTERNAL int rv_adam_flat_msg(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
+                                 const float* grad_shard, long lo, long n, long cnt, float lr, float grad_scale,
+                                 const long long* step_counter, void* msg, void* stream);

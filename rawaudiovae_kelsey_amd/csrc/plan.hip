@@ -713,46 +713,43 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+  // What follows a bucket's reduce-scatter -- Adam on the own shard, the parameter exchange, the shadow rebuild -- on
+  // stream `on` (bucket 0: the collective stream, behind the rest of backward; nothing there reads fc4's parameters).
+  const bool use_msg = p->msg_send && !p->fp8;
+  const long slots[2] = {use_msg ? rv_shard_msg_slots(p->d_slab + t0_b[0], nt_b[0], cnt[0]) : 0,
+                         use_msg ? rv_shard_msg_slots(p->d_slab + t0_b[1], nt_b[1], cnt[1]) : 0};
+  unsigned short* snd[2] = {p->msg_send, p->msg_send + slots[0]};
+  unsigned short* rcv[2] = {p->msg_recv, p->msg_recv + (long)p->world * slots[0]};
+  auto update_bucket = [&](int b, hipStream_t on) -> int {
+    long own, n;
+    own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
+    if (use_msg) {
+      // 16-bit parameter message: bf16 of the shard + the bucket's biases in fp32 (half the all-gather bytes), written
+      // by the update itself
+      RV_REQUIRE(own == lo_b[b] + (long)p->rank * cnt[b], RV_ERR_STATE, "sharded step: shard origin");
+      RV_TRY(rv_adam_flat_msg(p->d_slab + t0_b[b], nt_b[b], p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, cnt[b], lr,
+                              scale, p->b.step_counter, snd[b], (void*)on));
+      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, (void*)on);
+      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter message %d failed (collective library code %d)", b, nrc);
+      return rv_shadows_from_msg(p->d_slab + t0_b[b], nt_b[b], rcv[b], lo_b[b], cnt[b], slots[b], p->b.param, (void*)on);
+    }
+    RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, (void*)on));
+    const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)on);
+    if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
+    return rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, (void*)on);
+  };
   RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, 0, stream));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
   RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
-  RV_TRY(scatter_bucket(0, sc));                              // fc4's 8.4 MB travel behind the rest of backward
+  RV_TRY(scatter_bucket(0, sc));                              // fc4's whole exchange and update travel behind the
+  RV_TRY(update_bucket(0, sc));                               // rest of backward
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
   RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, 0, stream));
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: fc4's reduce-scatter is done
+  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: a communicator's collectives never fly on two streams
   RV_TRY(scatter_bucket(1, s0));
-  for (int b = 0; b < 2; ++b) {
-    long own, n;
-    own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
-    RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, stream));
-  }
-  if (p->msg_send && !p->fp8) {
-    // 16-bit parameter message: bf16 of the shard + the bucket's biases in fp32 (half the all-gather bytes)
-    const long slots[2] = {rv_shard_msg_slots(p->d_slab + t0_b[0], nt_b[0], cnt[0]),
-                           rv_shard_msg_slots(p->d_slab + t0_b[1], nt_b[1], cnt[1])};
-    unsigned short* snd[2] = {p->msg_send, p->msg_send + slots[0]};
-    unsigned short* rcv[2] = {p->msg_recv, p->msg_recv + (long)p->world * slots[0]};
-    for (int b = 0; b < 2; ++b) {
-      long own, n;
-      own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
-      RV_TRY(rv_shard_encode(p->d_slab + t0_b[b], nt_b[b], p->b.param, lo_b[b] + (long)p->rank * cnt[b], n, cnt[b], snd[b], stream));
-    }
-    for (int b = 0; b < 2; ++b) {
-      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, stream);
-      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter message %d failed (collective library code %d)", b, nrc);
-    }
-    for (int b = 0; b < 2; ++b)
-      RV_TRY(rv_shadows_from_msg(p->d_slab + t0_b[b], nt_b[b], rcv[b], lo_b[b], cnt[b], slots[b], p->b.param, stream));
-  } else {
-    for (int b = 0; b < 2; ++b) {
-      const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, stream);
-      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
-    }
-    for (int b = 0; b < 2; ++b)
-      RV_TRY(rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, stream));
-  }
+  RV_TRY(update_bucket(1, s0));
 #undef RV_TRY
   return RV_OK;
 }

@@ -13,11 +13,11 @@ PY
 }
 B="python bench.py --steps 200 --warmup 20 --repeats 7 --no-cpu-baseline --no-alts"
 {
-echo "== same box, interleaved twice; default = fp16 block-floating-point slabs, fused latent forward, eager launches"
+echo "== same box, interleaved twice; default = fp16 block-floating-point slabs, row-local latent forward and backward, eager launches"
 for i in 1 2; do
   $B > $O/tmp_b.json 2>/dev/null; line "default" $O/tmp_b.json
   $B --slab-dtype fp32 > $O/tmp_b.json 2>/dev/null; line "fp32 split-K slabs (round 2 default)" $O/tmp_b.json
-  $B --latent-fused 0 > $O/tmp_b.json 2>/dev/null; line "latent forward as three launches" $O/tmp_b.json
+  $B --latent-fused 0 > $O/tmp_b.json 2>/dev/null; line "latent fwd / bwd as 3 + 3 launches" $O/tmp_b.json
   $B --slab-dtype fp32 --latent-fused 0 > $O/tmp_b.json 2>/dev/null; line "both (round 2's step + epilogue prefetch)" $O/tmp_b.json
   $B --graph-pool > $O/tmp_b.json 2>/dev/null; line "one hipGraph of 8 steps (--graph-pool)" $O/tmp_b.json
   $B --graph > $O/tmp_b.json 2>/dev/null; line "one hipGraph per step (--graph)" $O/tmp_b.json
