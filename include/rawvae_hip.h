@@ -413,8 +413,16 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *       [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
  *           "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
  *       [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
- *       [7] non-zero: keep [3] fixed (parity runs).
- *     Weight scales are the caller's (224 / max|W| at refresh); Adam rewrites the fp8 shadows with them.
+ *       [7] non-zero: keep [3] and the weight scales fixed (parity runs)
+ *       [8] max|W1|, [9] max|W4| as the last optimizer update left them in the fp8 shadows (0 = none yet; reduced by
+ *           the step's first kernel from [32 ..]: 2 x 1024 slots that a small kernel behind the optimizer fills with
+ *           max|q| / scale over slices of the two shadows, and that the first kernel resets); [10..31] reserved.  The
+ *           caller zero-initialises the whole buffer.
+ *     Weight scales start as the caller's (224 / max|W| at refresh).  Adam rewrites the fp8 shadows with the current
+ *     scale; the first kernel of the next step, AFTER latching [5] / [6] from the scales the shadows were written
+ *     with, moves [1] / [2] to 224 / the measured maximum for the coming update (delayed scaling: a weight that grows
+ *     never meets a scale older than one step; one that has saturated reads as 448 / scale, so the scale halves until
+ *     it fits).
  *   RV_OPT_SLAB_DTYPE  element type of the split-K slabs of the two large weight gradients (fc1.weight, fc4.weight;
  *     2 x 33.5 MB of fp32 slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see above), which
  *     halves what the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32

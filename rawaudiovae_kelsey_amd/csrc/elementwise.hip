@@ -52,17 +52,89 @@ __device__ __forceinline__ unsigned long long q8x8(const float (&v)[8], float sc
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// fp8 state block (RV_OPT_FP8): thread 0 of the step's first kernel latches the delayed h3 scale
-__device__ __forceinline__ void fp8_latch(float* st, const float* amax_part, int n_amax, int lane) {
-  float m = 0.f;
-  for (int i = lane; i < n_amax; i += 64) m = fmaxf(m, amax_part[i]);
+// fp8 state block (RV_OPT_FP8): block 0 (256 threads) of the step's first kernel latches the delayed h3 scale and moves
+// the weight scales after the weights.  max|W1|, max|W4| of the last optimizer update sit in 2 x 1024 slots behind the
+// 32 floats of the state block proper (k_fp8_wmax below fills them behind the optimizer); they are reduced with every
+// load of a thread in flight at once and reset here.
+constexpr int FP8_WSLOTS = 1024;
+__device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_part, int n_amax) {
+  __shared__ float red[3][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* w_amax = st + 32;
+  float a[FP8_WSLOTS / 256], b[FP8_WSLOTS / 256];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (lane == 0) {
+  for (int k = 0; k < FP8_WSLOTS / 256; ++k) {
+    a[k] = w_amax[tid + 256 * k];
+    b[k] = w_amax[FP8_WSLOTS + tid + 256 * k];
+  }
+  float m = 0.f, w1 = 0.f, w4 = 0.f;
+  for (int i = tid; i < n_amax; i += 256) m = fmaxf(m, amax_part[i]);
+#pragma unroll
+  for (int k = 0; k < FP8_WSLOTS / 256; ++k) {
+    w1 = fmaxf(w1, a[k]);
+    w4 = fmaxf(w4, b[k]);
+    w_amax[tid + 256 * k] = 0.f;
+    w_amax[FP8_WSLOTS + tid + 256 * k] = 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    w1 = fmaxf(w1, __shfl_xor(w1, o, 64));
+    w4 = fmaxf(w4, __shfl_xor(w4, o, 64));
+  }
+  if (lane == 0) { red[0][wave] = m; red[1][wave] = w1; red[2][wave] = w4; }
+  __syncthreads();
+  if (tid == 0) {
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    w1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    w4 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
     st[4] = m;
     if (st[7] == 0.f && m > 0.f) st[3] = 224.f / m;
     st[5] = 1.f / (st[0] * st[1]);
     st[6] = 1.f / (st[3] * st[2]);
+    // the weight shadows read by this step were written with st[1] / st[2] (now inside st[5] / st[6]); the coming
+    // optimizer update quantises with scales that follow the weights it last saw
+    st[8] = w1;
+    st[9] = w4;
+    if (st[7] == 0.f) {
+      if (w1 > 0.f) st[1] = 224.f / w1;
+      if (w4 > 0.f) st[2] = 224.f / w4;
+    }
+  }
+}
+
+// max|W| of the two fp8 weight shadows as the optimizer left them, for next step's scales: 1024 blocks, each a slice of
+// one shadow (first half of the grid: W1q, second half: W4q), max|q| / scale of the slice into the block's slot.  An
+// extra pass over 4 MB (~2 us with its launch) instead of a reduction inside the optimizer kernels, where one atomic per
+// wave on 64 cache lines cost 6 us and the loads to avoid them more.
+__global__ void __launch_bounds__(256) k_fp8_wmax(const unsigned char* __restrict__ w1q, const long n1,
+                                                  const unsigned char* __restrict__ w4q, const long n4, float* __restrict__ st) {
+  __shared__ float red[4];
+  const int half = FP8_WSLOTS / 2;
+  const bool second = (int)blockIdx.x >= half;
+  const unsigned char* q = second ? w4q : w1q;
+  const long n = second ? n4 : n1;
+  const int b = (int)blockIdx.x - (second ? half : 0);
+  float m = 0.f;
+  for (long i = ((long)b * 256 + threadIdx.x) * 16; i + 16 <= n; i += (long)half * 256 * 16) {
+    const uint4 v = *reinterpret_cast<const uint4*>(q + i);
+    const unsigned w[4] = {v.x & 0x7F7F7F7Fu, v.y & 0x7F7F7F7Fu, v.z & 0x7F7F7F7Fu, v.w & 0x7F7F7F7Fu};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 0));
+      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 1));
+      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 2));
+      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 3));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // two slot halves per tensor: block b of a tensor owns slot b of that tensor's 1024 (the upper 512 stay zero)
+    st[32 + (second ? FP8_WSLOTS : 0) + b] = m / st[second ? 2 : 1];
   }
 }
 
@@ -76,9 +148,9 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
                                                        const float* __restrict__ amax_part, int n_amax,
                                                        const long long* __restrict__ frame_idx, long first_frame,
                                                        long hop, long n_samples) {
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (blockIdx.x == 0) {
     if (step_counter && threadIdx.x == 0) *step_counter += 1;
-    if (fp8_state) fp8_latch(fp8_state, amax_part, n_amax, threadIdx.x);
+    if (fp8_state) fp8_latch_block(fp8_state, amax_part, n_amax);
   }
   const float qs = dst_fp8 ? *fp8_scale : 0.f;   // the x / weight scale is constant across the latch
   const long cpr = cols_p / 8;
@@ -706,6 +778,16 @@ int rv_gather_cast_frames(const float* audio, long n_samples, const long long* f
                      audio, n_frames, S, 0L, (bf16_t*)dst_bf16, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state, amax_part,
                      amax_part ? n_amax : 0, frame_index, first_frame, hop, n_samples);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_fp8_wmax(const void* w1q, long n1, const void* w4q, long n4, float* fp8_state, void* stream) {
+  RV_REQUIRE(w1q && w4q && fp8_state, RV_ERR_NULL, "rv_fp8_wmax: null pointer");
+  RV_REQUIRE(n1 > 0 && n4 > 0 && n1 % 16 == 0 && n4 % 16 == 0 && (((uintptr_t)w1q | (uintptr_t)w4q) & 15) == 0, RV_ERR_SHAPE,
+             "rv_fp8_wmax: shadows must be 16-byte aligned multiples of 16 bytes");
+  hipLaunchKernelGGL(k_fp8_wmax, dim3(FP8_WSLOTS), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)w1q, n1,
+                     (const unsigned char*)w4q, n4, fp8_state);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

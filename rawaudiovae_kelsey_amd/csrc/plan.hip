@@ -185,7 +185,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("W1q", Hp * Sp);
   p->add("W4q", Sp * Hp);
   p->add("h3q", Bp * Hp);
-  p->add("fp8_state", 8 * 4);
+  p->add("fp8_state", (32 + 2 * 1024) * 4);   // 16 state floats (+16 pad), then 2 x 1024 max|W| slots
   p->add("h3_amax", 4096 * 4);    // per-block max|h3| of the fc3 forward (zero until it has run)
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
@@ -372,6 +372,13 @@ struct WtScope {
   ~WtScope() { rv::rv_store_wt = prev; }
 };
 
+// fp8 forward: behind every optimizer update the maxima of the two fp8 weight shadows are measured for the next step's
+// weight scales (RV_OPT_FP8, state block [8] / [9]).
+static int fp8_after_update(rv_plan* p, void* stream) {
+  if (!p->fp8) return RV_OK;
+  return rv_fp8_wmax(p->ws("W1q"), p->Hp * p->Sp, p->ws("W4q"), p->Sp * p->Hp, (float*)p->ws("fp8_state"), stream);
+}
+
 // The latent-sized backward between the fc4 pair and fc1's weight gradient: dz, the reparameterisation backward (which
 // also finishes the loss), fc3's weight gradient, and the heads' dgrad + wgrad.  Row-local form (RV_OPT_LATENT_FUSED,
 // padded latent width 64): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of the same launch) and the
@@ -521,7 +528,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                 p->b.step_counter, 256 - n_gemm, stream));
     RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                          p->b.step_counter, stream));
-    return RV_OK;
+    return fp8_after_update(p, stream);
   }
   // ---- backward / finalize / Adam as an ordered list of steps, each enabled by the phase mask ----
   const bool old_a = phases & RV_PHASE_BWD_A, old_b = phases & RV_PHASE_BWD_B;
@@ -598,6 +605,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                          p->b.step_counter, stream));
     i = j;
   }
+  if (adam & 0x101) RV_TRY(fp8_after_update(p, stream));   // fc1.weight or fc4.weight were updated
 #undef RV_TRY
   return RV_OK;
 }
@@ -750,6 +758,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: a communicator's collectives never fly on two streams
   RV_TRY(scatter_bucket(1, s0));
   RV_TRY(update_bucket(1, s0));
+  RV_TRY(fp8_after_update(p, stream));
 #undef RV_TRY
   return RV_OK;
 }
@@ -819,6 +828,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(payload(0, 8));                                   // fc1, fc21, fc22, fc3: contiguous in the arena
   RV_TRY(reduce(1, 0, 8, s0));                             // nothing left to hide it behind: on the caller's stream
   RV_TRY(adam_bucket(0, 8));
+  RV_TRY(fp8_after_update(p, stream));
 #undef RV_TRY
   return RV_OK;
 }

@@ -142,7 +142,7 @@ class TrainEngine:
     def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
         """Write entries of the fp8 state block (include/rawvae_hip.h, RV_OPT_FP8).  Weight scales are
         normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""
-        st = self.buffer("fp8_state", torch.float32, (8,))
+        st = self.buffer("fp8_state", torch.float32, (-1,))[:16]
         for i, v in ((0, x), (1, w1), (2, w4), (3, h3)):
             if v is not None:
                 st[i] = float(v)
@@ -150,7 +150,7 @@ class TrainEngine:
             st[7] = 1.0 if freeze_h3 else 0.0
 
     def fp8_state(self):
-        return self.buffer("fp8_state", torch.float32, (8,)).tolist()
+        return self.buffer("fp8_state", torch.float32, (-1,))[:16].tolist()
 
     def refresh_shadows(self, stream=None):
         """Rebuild this engine's bf16/padded weight shadows from the fp32 arena.  If an engine sharing the arena
@@ -164,7 +164,7 @@ class TrainEngine:
             ddp.gather_sharded_params(owner)
         if self.fp8:
             with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
-                st = self.buffer("fp8_state", torch.float32, (8,))
+                st = self.buffer("fp8_state", torch.float32, (-1,))[:16]
                 cur = st.tolist()
                 amax1 = float(self.view(self.param, "fc1.weight").abs().max())
                 amax4 = float(self.view(self.param, "fc4.weight").abs().max())
@@ -173,6 +173,8 @@ class TrainEngine:
                 st[2] = 224.0 / max(amax4, 1e-12)
                 if cur[3] == 0.0:
                     st[3] = self.fp8_h3_scale
+                st[8:10] = 0.0   # max|W| of the last update: none yet for these weights
+                self.buffer("fp8_state", torch.float32, (-1,))[32:] = 0.0
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
         self._shadow_version = self._shared["version"]
 

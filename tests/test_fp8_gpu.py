@@ -107,3 +107,21 @@ def test_fp8_trajectory_vs_reference_golden(case):
     w4q = e.buffer("W4q", torch.uint8, (Sp, Hp)).view(torch.float8_e4m3fn).float().cpu().numpy()
     w4 = e.view(e.param, "fc4.weight").cpu().numpy()
     np.testing.assert_array_equal(w4q[:S, :H], O.fp8_e4m3_round(w4 * np.float32(st[2])))
+    # ... with a scale that follows the weights: behind the optimizer a small kernel measures max|q| / scale of the two
+    # fp8 shadows into slots; the next step's first kernel reduces them ([8], [9]) and moves the weight scales to
+    # 224 / that maximum AFTER latching this step's dequantisation factors
+    w1 = e.view(e.param, "fc1.weight").cpu().numpy()
+    slots = e.buffer("fp8_state", torch.float32, (-1,))[32:].view(2, 1024).max(dim=1).values.tolist()
+    assert abs(slots[1] * st[2] / float(np.abs(w4q).max()) - 1.0) < 1e-6                   # of the LAST update's shadow
+    assert abs(slots[1] / float(np.abs(w4).max()) - 1.0) < 0.07 and abs(slots[0] / float(np.abs(w1).max()) - 1.0) < 0.07
+    assert 0.9 < st[9] / slots[1] < 1.1 and 0.9 < st[8] / slots[0] < 1.1                  # of the one before it
+    assert abs(st[2] * np.abs(w4).max() / 224.0 - 1.0) < 0.1 and np.abs(w4q).max() <= 448.0
+    # a stale scale (weights that "grew" 8x since it was set) is gone after one step
+    e.set_fp8_scales(w4=st[2] * 8.0)
+    e.step(torch.from_numpy(make_frames(B, S, 99)).cuda(), torch.from_numpy(make_eps(B, L, 98)).cuda())
+    st2 = e.fp8_state()
+    assert abs(st2[2] * slots[1] / 224.0 - 1.0) < 1e-6
+    w4q = e.buffer("W4q", torch.uint8, (Sp, Hp)).view(torch.float8_e4m3fn).float().cpu().numpy()
+    w4 = e.view(e.param, "fc4.weight").cpu().numpy()
+    np.testing.assert_array_equal(w4q[:S, :H], O.fp8_e4m3_round(w4 * np.float32(st2[2])))
+    assert 200.0 < np.abs(w4q).max() <= 448.0
