@@ -110,7 +110,11 @@ def test_c2_gradients_vs_reference_golden(c2_step, name):
 
 def test_adam_state_vs_reference_golden():
     """param / exp_avg / exp_avg_sq after 1 and 3 steps against the reference's optimizer state
-    (small_f32.npz) and against the bf16-quantised oracle."""
+    (small_f32.npz) and against the bf16-quantised oracle.  The bound on the PARAMETERS against the fp32 reference is
+    wide on purpose (2 * lr * n and rel-L2 0.15 on the update): Adam's first steps are ~sign(g) * lr, so an element
+    whose bf16-path gradient has the other sign moves the other way by a full lr.  The tight evidence for the optimizer
+    arithmetic is elsewhere: tests/test_strict_fp32_gpu.py (fp32 operands: update within 1e-5 of the reference's) and
+    tests/test_kernels_gpu.py::test_adam_multi_and_finalize (the kernel against numpy on identical gradients)."""
     g = np.load(os.path.join(GOLDEN, "small_f32.npz"))
     S, H, L, B = (int(v) for v in g["shape"])
     e = _engine(S, H, L, B)
