@@ -90,16 +90,22 @@ def time_dominant_kernel(eng, x, reps=50):
         eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
     for _ in range(5):
         launch()
-    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
-    b0.record(ts)
-    for _ in range(reps):
-        launch()
-    b1.record(ts)
-    b1.synchronize()
+    # five batches of `reps` launches, each between one pair of HIP events; the figure is the MEDIAN batch average (a
+    # single batch moves by +-5 % from run to run on one box: profiles/r03_ab_step.txt, column "pair")
+    batches = []
+    for _ in range(5):
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
+        b0.record(ts)
+        for _ in range(reps):
+            launch()
+        b1.record(ts)
+        b1.synchronize()
+        batches.append(b0.elapsed_time(b1) / reps)
+    batches.sort()
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
-    return b0.elapsed_time(b1) / reps, 4.0 * S * H * B, desc
+    return batches[len(batches) // 2], 4.0 * S * H * B, desc, batches
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -569,7 +575,7 @@ def main():
                 alt = {"grad_allreduce": "bf16 payload, same schedule", "error": str(exc)[:200]}
             finally:
                 runner.set_payload("fp32")
-        kern_ms, kern_flops, kern_cfg = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None)
+        kern_ms, kern_flops, kern_cfg, kern_batches = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None, None)
         # Side lines, never the headline: the same K steps on engines with opt-in reduced-precision storage
         alts = {}
         if world == 1 and not args.no_alts:
@@ -664,8 +670,10 @@ def main():
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": kern_ms * 1e3,
-                         "timing": "one pair of HIP events around 50 back-to-back launches of the plan's fc4-backward phase "
-                                   "(kernel boundary included; rocprofv3's per-kernel duration is 2-3 us shorter)"},
+                         "us_per_launch_batches": [b * 1e3 for b in kern_batches],
+                         "timing": "median of five batches, each one pair of HIP events around 50 back-to-back launches of the "
+                                   "plan's fc4-backward phase (kernel boundary included; rocprofv3's per-kernel duration is "
+                                   "2-3 us shorter)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.torch_port import cpu_description, time_cpu_step
