@@ -68,44 +68,58 @@ def parse():
     return ap.parse_args()
 
 
-def time_dominant_kernel(eng, x, reps=50):
+def time_dominant_kernel(eng, x, steps=10, reps=7):
     """Average duration of the step's longest kernel -- the paired fc4 backward
     (`gemm_dgrad_wgrad_kernel`: dP3 = relu'(dP4 W4) and dW4 = dP4^T h3 in one launch, 256x256 tiles)
-    -- with HIP events on the launching stream.  The launch is the training plan's own (`rv_plan_step` with the
-    fc4-backward phase alone: same operands, slab type and store policy as inside the step), `reps` launches back to
-    back between ONE pair of events: the figure contains the kernel boundary (each launch starts while the previous
-    one's 33 MB of output is still on its way to memory), so it is 2-3 us above rocprofv3's per-kernel duration of
-    the same launch inside the step (profiles/rNN_*_kernel_stats.csv).  Bracketing every launch with its own event
-    pair is worse, not better: an event record in a busy stream costs a ~6 us bubble (measured: 37-41 us).
-    Returns (ms_per_launch, algorithmic flops per launch, description)."""
+    -- IN the step, with HIP events on the launching stream.  Two hipGraphs of `steps` training steps issued phase by
+    phase through the training plan (`rv_plan_step`: forward | fc4 backward | rest of backward | Adam), one with and
+    one without the fc4-backward phase (the plan's own launch: same operands, slab type and store policy as in the
+    full step), are replayed alternately `reps` times with an event after every replay and no host synchronisation;
+    the figure is the MEDIAN over the replays of (time with - time without) / steps.  It contains the kernel's
+    boundaries (the launch gap and the drain of its 33 MB of output), so it sits 1-3 us above rocprofv3's per-kernel
+    duration of the same launch (profiles/rNN_*_kernel_stats.csv).
+    Why not `n` launches of the kernel back to back: under a sustained run of this one kernel (~1 PFLOP/s) the chip
+    slows down -- 50-launch batches replayed from a graph went from 33-35 us (first) to 41-44 us (fifth), and issued
+    from Python they are host-bound on top (a single-phase call costs ~38 us of host time) -- which is neither the
+    kernel's duration in the step nor a property of the kernel.  Bracketing the launch inside the step with its own
+    event pair is worse still: an event record in a busy stream costs a ~6 us bubble (measured: 37-41 us).
+    Returns (ms_per_launch, algorithmic flops per launch, description, all replay differences in ms)."""
     import torch
     from rawaudiovae_kelsey_amd import engine as E
     from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
     Bp, Sp, Hp, Lp = eng.padded()
     paired, bm, splits = dgrad_wgrad_pick(Bp, Hp, Sp)   # what the training step itself uses
     ts = torch.cuda.current_stream()
-    eng.step(x, phases=E.PHASE_FWD, stream=ts)          # operands as the step leaves them
+    rest = E.PHASE_BWD_CHAIN | E.PHASE_BWD_REST
+    seq_with = (E.PHASE_FWD, E.PHASE_BWD_FC4, rest, E.PHASE_ADAM)
+    seq_without = (E.PHASE_FWD, rest, E.PHASE_ADAM)
 
-    def launch():
-        eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
-    for _ in range(5):
-        launch()
-    # five batches of `reps` launches, each between one pair of HIP events; the figure is the MEDIAN batch average (a
-    # single batch moves by +-5 % from run to run on one box: profiles/r03_ab_step.txt, column "pair")
-    batches = []
-    for _ in range(5):
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events
-        b0.record(ts)
-        for _ in range(reps):
-            launch()
-        b1.record(ts)
-        b1.synchronize()
-        batches.append(b0.elapsed_time(b1) / reps)
-    batches.sort()
+    def run(seq):
+        for ph in seq:
+            eng.step(x, phases=ph, stream=ts)
+    run(seq_with)
+    ts.synchronize()
+    graphs = []
+    for seq in (seq_with, seq_without):
+        g = E.Graph(ts)
+        with g:
+            for _ in range(steps):
+                run(seq)
+        g.launch()
+        graphs.append(g)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]   # HIP events
+    ev[0].record(ts)
+    for r in range(reps):
+        graphs[0].launch()
+        ev[2 * r + 1].record(ts)
+        graphs[1].launch()
+        ev[2 * r + 2].record(ts)
+    ev[-1].synchronize()
+    diffs = sorted((ev[2 * r].elapsed_time(ev[2 * r + 1]) - ev[2 * r + 1].elapsed_time(ev[2 * r + 2])) / steps for r in range(reps))
     desc = ("gemm_dgrad_wgrad_kernel<256,256> (fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + "
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
-    return batches[len(batches) // 2], 4.0 * S * H * B, desc, batches
+    return diffs[len(diffs) // 2], 4.0 * S * H * B, desc, diffs
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -671,9 +685,10 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": kern_ms * 1e3,
                          "us_per_launch_batches": [b * 1e3 for b in kern_batches],
-                         "timing": "median of five batches, each one pair of HIP events around 50 back-to-back launches of the "
-                                   "plan's fc4-backward phase (kernel boundary included; rocprofv3's per-kernel duration is "
-                                   "2-3 us shorter)"},
+                         "timing": "in the step: median over 7 alternating replays of (hipGraph of 10 phase-by-phase steps WITH the "
+                                   "plan's fc4-backward launch) - (the same graph WITHOUT it), / 10, HIP events after every "
+                                   "replay; kernel boundaries included (back-to-back batches of this kernel alone slow the "
+                                   "chip down: 33 -> 44 us over 250 launches)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.torch_port import cpu_description, time_cpu_step
