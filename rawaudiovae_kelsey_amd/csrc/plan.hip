@@ -746,10 +746,10 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
     return rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, (void*)on);
   };
-  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, 0, stream));
   RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
   RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
-  RV_TRY(scatter_bucket(0, sc));                              // fc4's whole exchange and update travel behind the
+  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, 0, (void*)sc));
+  RV_TRY(scatter_bucket(0, sc));                              // fc4's slab sum, exchange and update travel behind the
   RV_TRY(update_bucket(0, sc));                               // rest of backward
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
@@ -781,9 +781,9 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
   // Bucket = tensors [t0, t1) of the flat arena: slabs -> flat payload (caller's stream), then the SUM over ranks
   // on stream `on`
-  auto payload = [&](int t0, int t1) -> int {
-    if (p->payload_bf16) return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->grad_bf16, 1, stream);
-    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, 0, stream);
+  auto payload = [&](int t0, int t1, hipStream_t on) -> int {
+    if (p->payload_bf16) return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->grad_bf16, 1, (void*)on);
+    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, 0, (void*)on);
   };
   auto reduce = [&](int b, int t0, int t1, hipStream_t on) -> int {
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
@@ -809,9 +809,9 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  RV_TRY(payload(8, 10));
-  RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) travels behind the rest of backward
-  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
+  RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) is summed over its slabs and
+  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));       // travels behind the rest of backward
+  RV_TRY(payload(8, 10, sc));
   RV_TRY(reduce(0, 8, 10, sc));
   RV_HIP(hipEventRecord(p->ev_done[0], sc));
   RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
@@ -825,7 +825,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
     RV_TRY(adam_bucket(8, 2));
   }
-  RV_TRY(payload(0, 8));                                   // fc1, fc21, fc22, fc3: contiguous in the arena
+  RV_TRY(payload(0, 8, s0));                               // fc1, fc21, fc22, fc3: contiguous in the arena
   RV_TRY(reduce(1, 0, 8, s0));                             // nothing left to hide it behind: on the caller's stream
   RV_TRY(adam_bucket(0, 8));
   RV_TRY(fp8_after_update(p, stream));
