@@ -51,3 +51,10 @@ RV_INTERNAL int rv_adam_flat_msg(const rv_param_desc* descs, int n_desc, float* 
 // max|W1|, max|W4| of the fp8 weight shadows (n1 / n4 bytes) into the 2 x 1024 slots behind the fp8 state block
 // (RV_OPT_FP8): the plan runs it behind the optimizer, the next step's first kernel turns it into the weight scales.
 RV_INTERNAL int rv_fp8_wmax(const void* w1q, long n1, const void* w4q, long n4, float* fp8_state, void* stream);
+// rv_latent_fwd with the fp8 forward's extra outputs of fc3 (NULL = not wanted): h3 also as fp8(h3 * *q_scale), and
+// max|h3| of every wave's outputs in amax_part[8 * (Bp / 16)].
+RV_INTERNAL int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
+                                 const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
+                                 const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                                 float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
+                                 const float* q_scale, float* amax_part, void* stream);

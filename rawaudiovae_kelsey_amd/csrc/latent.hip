@@ -19,6 +19,7 @@
 #include "gemm_bf16.h"
 #include "philox.h"
 #include "../../include/rawvae_hip.h"
+#include "internal.h"
 
 using namespace rv;
 
@@ -69,7 +70,9 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
              const float* __restrict__ b3, const long Hp, const long B, const long L,
              const float* __restrict__ eps_in, float* __restrict__ eps_out, const uint64_t seed,
              const long long* __restrict__ step_counter, float* __restrict__ mulv, bf16_t* __restrict__ z,
-             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3, const int wt) {
+             float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3, const int wt,
+             unsigned char* __restrict__ h3q, const long ldq, const float* __restrict__ q_scale,
+             float* __restrict__ amax_part) {
   constexpr long Lp = 64, L2p = 128;
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   lds_char* smem = (lds_char*)smem_dyn;
@@ -213,6 +216,11 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
   const bf16x8 z1 = *(const __attribute__((address_space(3))) bf16x8*)(zl + j * 128 + 64 + q * 16);
   const lds_char* bl = ring + LX_OFF;   // the wave's bias slice (kw floats)
   bf16_t* out = h3 + (r0 + j) * ldh3 + ks * kw;
+  // fp8 forward (RV_OPT_FP8): h3 also as fp8(h3 * *q_scale), fc4's operand, and max|h3| of this wave's outputs for the
+  // next step's scale (what rv_linear_fwd_ex's epilogue does per block)
+  const float qs = h3q ? *q_scale : 0.f;
+  unsigned char* outq = h3q ? h3q + (r0 + j) * ldq + ks * kw : nullptr;
+  float amax = 0.f;
   for (int u = 0; u < NU; ++u) {
     const lds_char* sl = (u & 1) ? W1 : W0;
     // Outstanding operations issued after slot u's pieces, in order (stores: 2 per iteration):
@@ -262,8 +270,23 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
         o[4 + e] = (bf16_t)hi[e];
       }
       store_out16((bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
+      if (h3q || amax_part) {
+        float q8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          amax = fmaxf(amax, fmaxf(lo[e], hi[e]));   // post-ReLU: non-negative
+          q8[e] = lo[e] * qs;
+          q8[4 + e] = hi[e] * qs;
+        }
+        if (h3q) *(unsigned long long*)(outq + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8) = pack_fp8x8(q8);
+      }
     }
     asm volatile("" ::: "memory");
+  }
+  if (amax_part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) amax_part[blockIdx.x * 8 + wave] = amax;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave's is in flight towards LDS when it ends
 }
@@ -446,6 +469,19 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                   float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream) {
+  return rv_latent_fwd_ex(h_bf16, ldh, wh_bf16, ldwh, bias_heads, w3_bf16, ldw3, bias3, Bp, Hp, Lp, B, L, eps_in, eps_out, seed,
+                          step_counter, mulv, z_bf16, kl_partial, h3_bf16, ldh3, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// rv_latent_fwd with the fp8 forward's extra outputs of fc3 (NULL = not wanted): h3 also as fp8(h3 * *q_scale) and
+// max|h3| of every wave's outputs in amax_part[8 * (Bp / 16)] (rv_linear_fwd_ex's per-block maxima, finer).
+int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
+                     const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
+                     const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                     float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
+                     const float* q_scale, float* amax_part, void* stream) {
+  RV_REQUIRE(!h3_fp8 || (q_scale && ldq >= Hp && ldq % 8 == 0 && ((uintptr_t)h3_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_latent_fwd: the fp8 output needs a scale and 8-byte aligned rows");
   RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && w3_bf16 && bias3 && mulv && z_bf16 && kl_partial && h3_bf16, RV_ERR_NULL,
              "rv_latent_fwd: null pointer");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
@@ -466,7 +502,7 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
   hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

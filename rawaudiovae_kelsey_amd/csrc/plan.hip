@@ -428,7 +428,12 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
     float* f8 = (float*)p->ws("fp8_state");
     int n_amax = 0;
-    if (p->fp8) {
+    // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
+    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048;
+    if (p->fp8 && latent_fused) {
+      n_amax = (int)(Bp / 16) * 8;   // one maximum per wave of rv_latent_fwd_ex
+      RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 8192 batch rows with the fused latent forward");
+    } else if (p->fp8) {
       int bm3 = 128, bn3 = 128;
       rv_gemm_tile(Bp, Hp, 1, &bm3, &bn3);
       n_amax = (int)((Bp / bm3) * (Hp / bn3));
@@ -460,16 +465,16 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     }
-    // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64, bf16), else three
-    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && !p->fp8;
     if (latent_fused)
-      RV_TRY(rv_latent_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
-                           B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp, stream));
+      RV_TRY(rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
+                              B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
+                              p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
+                              p->fp8 ? (float*)p->ws("h3_amax") : nullptr, stream));
     else
       RV_TRY(rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
                                   eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
     if (p->fr_hop) {
-      if (p->fp8)
+      if (p->fp8 && !latent_fused)
         RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       else if (!latent_fused)
@@ -480,7 +485,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                            p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
                                            mse_part, (float*)p->ws("db4p"), stream));
     } else if (p->fp8) {
-      RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+      if (!latent_fused)
+        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
                                         x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
