@@ -313,7 +313,7 @@ def test_heads_reparam_fwd(L, B, Lt, K, splits):
     np.testing.assert_allclose(z.float().cpu().numpy()[:B, :Lt], z2, rtol=1e-2, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,Lt,H", [(100, 3, 512), (4096, 64, 2048), (300, 40, 900)])
+@pytest.mark.parametrize("B,Lt,H", [(100, 3, 512), (4096, 64, 2048), (300, 40, 900), (200, 64, 1536)])
 def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
     """rv_latent_fwd (heads GEMM + reparam + KL partials + fc3 in one launch, model.py:21-29) against the route it
     replaces (rv_heads_reparam_fwd + rv_linear_fwd) and against numpy, on the same bf16 operands and eps."""
@@ -381,7 +381,7 @@ def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
                         h31.data_ptr(), Hp, sp())
 
 
-@pytest.mark.parametrize("B,Lt,H,ext", [(100, 3, 512, False), (4096, 64, 2048, False), (300, 40, 900, True)])
+@pytest.mark.parametrize("B,Lt,H,ext", [(100, 3, 512, False), (4096, 64, 2048, False), (300, 40, 900, True), (200, 64, 1536, True)])
 def test_latent_bwd_one_launch_equals_two(L, B, Lt, H, ext):
     """rv_latent_bwd (dz = dP3 W3 over the full contraction + the reparameterisation / KL backward + the loss scalar
     + fc3's weight gradient on extra workgroups, one launch) against the route it replaces (rv_linear_dgrad into fp32 split-K slabs + rv_reparam_bwd) and against
