@@ -37,6 +37,12 @@ int main() {
   fails += rv_plan_attach_comm(pl, &c) == 0;                           // no collective given
   fails += strstr(rv_last_error(), "no collective") == NULL;
   fails += rv_plan_attach_comm(pl, NULL) == 0;
+  memset(&c, 0, sizeof c);
+  fails += rv_plan_attach_comm(pl, &c) != 0;                           // comm == NULL: detach, always allowed
+  c.comm = x; c.world = 1; c.rank = 0; c.reduce_scatter = (rv_reduce_scatter_fn)x;
+  fails += rv_plan_attach_comm(pl, &c) == 0;                           // sharded mode needs BOTH collectives
+  fails += strstr(rv_last_error(), "reduce_scatter AND all_gather") == NULL;
+  fails += rv_gemm_plan(7, 256, 256, 256, 1, &bm, &bn, &sp, &paired) == 0;   // unknown query
   rv_plan_destroy(pl);
   printf("host checks: %d failures; last error: %s\n", fails, rv_last_error());
   return fails != 0;
