@@ -206,6 +206,17 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
                   const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,
                   const void* z_bf16, long ldz, float* dw3_slabs, long lddw3, int dw3_splits, void* stream);
 
+/* The heads' backward (autograd of fc21 | fc22, model.py:21, with fc1's ReLU) for a padded latent width of 64 as ONE
+ * streaming launch that reads h1 once: dp1 [Bp, Hp] bf16 = (h1 > 0) ? dmulv Wh : 0, its column sums per 512-row group
+ * (db1_partial [Bp / 512][Hp], fc1's bias gradient) and dWh = dmulv^T h1 as one fp32 slab per 512-row group
+ * (dwh_slabs [Bp / 512][128][lddw]: rv_linear_dgrad_wgrad's outputs with Bp / 512 splits).  dmulv [Bp, 128] bf16 (mu
+ * columns 0..63, logvar 64..127: rv_reparam_bwd's output), wh [128, Hp] bf16 (fc21 | fc22, [out, in]), h1 [Bp, Hp]
+ * bf16.  A workgroup keeps its 64-column slice of Wh in LDS and walks 512 rows in tiles of 64; the same staged h1
+ * tile is the ReLU mask of the first product and the operand of the second.  RV_ERR_UNSUPPORTED unless Lp == 64,
+ * Bp % 512 == 0 and Hp % 64 == 0. */
+int rv_heads_bwd(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp, long Hp,
+                 long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* stream);
+
 /* Backward of reparameterize + KL:
  *   dmu = dz + kl_beta mu/(B L);  dlv = dz eps std/2 + kl_beta (exp(logvar)-1)/(2 B L)
  * dz_slabs [splits][Bp][Lp] fp32 -> dmulv bf16 [Bp][2Lp] and per-block column sums

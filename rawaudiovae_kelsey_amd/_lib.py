@@ -132,6 +132,8 @@ _SIGS = {
     "rv_latent_bwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p,
                               c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                               c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p]),
+    "rv_heads_bwd": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long, c_void_p, c_long, c_void_p,
+                             c_void_p, c_long, c_void_p]),
     "rv_gemm_plan": (c_int, [c_int, c_long, c_long, c_long, c_int] + [C.POINTER(c_int)] * 4),
     "rv_adam_multi": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_float, c_float, c_void_p, c_void_p]),

@@ -461,6 +461,213 @@ k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __re
   }
 }
 
+
+// ---- the heads' backward as ONE streaming kernel that reads h1 once ------------------------------------------------
+// dP1 = relu'(h1) * (dmulv Wh)  (autograd of fc21 | fc22 w.r.t. h1, masked by fc1's ReLU; K = 2 Lp = 128 only) and
+// dWh = dmulv^T h1 need the same h1 tile: as the mask of the first and as the operand of the second.  The generic route
+// (a dual launch of a 128 x 128-tile dgrad and a split-K wgrad) reads h1 twice and runs every tile as a block of its
+// own -- load, two K tiles of MFMA, store, in lockstep over the whole chip: 15 us for 58 MB.  Here a workgroup owns
+// 64 columns of h1 and 512 batch rows, keeps its slice of Wh (128 x 64) in LDS and walks the rows in tiles of 64:
+// the tile of h1 and the rows of dmulv are staged once (LDS-DMA, two stages, counted vmcnt), feed both products, and
+// the next tile's loads fly while this tile's dP1 is stored.  dWh accumulates in registers over the 8 tiles and leaves
+// as one fp32 slab per 512-row group (the split-K partials rv_adam_multi sums), the column sums of dP1 (fc1's bias
+// gradient) as one partial row per group.
+constexpr int HB_TR = 64;                       // rows per tile
+constexpr int HB_RG = 512;                      // rows per workgroup
+constexpr int HB_AK = 2 * 8192;                 // dmulv tile, K-major (rows x 128 k as two 64-k images): dgrad's operand
+constexpr int HB_AM = 16384;                    // the same rows, MN-major ([64 rows][128 l]): dWh's operand (its transpose)
+constexpr int HB_HM = 8192;                     // h1 tile, MN-major ([64 rows][64 cols]): dWh's operand AND the mask
+constexpr int HB_STAGE = HB_AK + HB_AM + HB_HM;   // 40 KiB
+constexpr int HB_WH = 2 * 8192;                 // Wh slice, MN-major, two 64-k images
+constexpr int HB_NS = 3;                        // stages: the one in use, the next, and the one being refilled
+constexpr int HB_LDS = HB_WH + HB_NS * HB_STAGE;   // 136 KiB
+
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n in 0..15
+__device__ __forceinline__ void wait_vm_exact(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+  }
+}
+
+__global__ void __launch_bounds__(512)
+k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, const long ldw,
+            const bf16_t* __restrict__ h1, const long ldh, bf16_t* __restrict__ dP1, const long ldp,
+            float* __restrict__ db1_partial, float* __restrict__ dwh_slabs, const long lddw, const long Hp,
+            const int wt) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  lds_char* smem = (lds_char*)smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int q = lane >> 4, j = lane & 15;
+  const int nstrips = (int)(Hp / 64);
+  const int g = (int)blockIdx.x / nstrips, cs_ = (int)blockIdx.x - g * nstrips;
+  const long r_base = (long)g * HB_RG, c0 = (long)cs_ * 64;
+  constexpr int NT = HB_RG / HB_TR;
+  lds_char* const whI = smem;
+  auto stage_at = [&](int s) { return smem + HB_WH + s * HB_STAGE; };
+  // work split over the 8 waves: the dgrad tile (64 rows x 64 columns) as row block rb = wave & 3 and the column-block
+  // PAIR cp = wave >> 2 (columns 32 cp .. 32 cp + 31: one 16-byte store per lane); dWh (128 l x 64 columns) as l block
+  // `wave` and all four column blocks
+  const int rb = wave & 3, cp = wave >> 2;
+
+  // one LDS-DMA instruction (1 KiB) of a stage / of the Wh slice; the 8 waves deal them out round robin
+  auto issue_stage = [&](int t, int s) {
+    lds_char* st = stage_at(s);
+    const bf16_t* dm = dmulv + (r_base + (long)HB_TR * t) * 128;
+    const bf16_t* hh = h1 + (r_base + (long)HB_TR * t) * ldh + c0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = wave + 8 * k;   // 0..39
+      if (idx < 16) {                 // K-major halves of dmulv
+        const int half = idx >> 3, i = idx & 7;
+        const int r = 8 * i + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        dma16(dm + r * 128 + 64 * half + c * 8, st + half * 8192 + i * 1024);
+      } else if (idx < 32) {          // MN-major image of the same rows: [row][128 l]
+        const int t_ = idx - 16;
+        const int kr = 4 * t_ + (lane >> 4), p16 = lane & 15;
+        const int c32 = (p16 >> 1) ^ swz_mn<128>(kr);
+        dma16(dm + kr * 128 + (c32 * 2 + (p16 & 1)) * 8, st + HB_AK + t_ * 1024);
+      } else {                        // h1 tile, MN-major: [row][64 cols]
+        const int i = idx - 32;
+        const int kr = 8 * i + (lane >> 3), p16 = lane & 7;
+        const int c32 = (p16 >> 1) ^ swz_mn<64>(kr);
+        dma16(hh + kr * ldh + (c32 * 2 + (p16 & 1)) * 8, st + HB_AK + HB_AM + i * 1024);
+      }
+    }
+  };
+  // Wh slice: rows k (2 x 64 latent outputs), this block's 64 columns: 16 instructions, 2 per wave
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = wave + 8 * k, half = idx >> 3, i = idx & 7;
+    const int kr = 8 * i + (lane >> 3), p16 = lane & 7;
+    const int c32 = (p16 >> 1) ^ swz_mn<64>(kr);
+    dma16(Wh + (long)(64 * half + kr) * ldw + c0 + (c32 * 2 + (p16 & 1)) * 8, whI + half * 8192 + i * 1024);
+  }
+  issue_stage(0, 0);
+  issue_stage(1, 1);
+
+  f32x4 acc2[4];      // dWh: row l = 16 wave + j, columns 16 cb + 4 q + e
+  float cs[2][4];     // column sums of dP1 over this lane's rows, column blocks 2 cp, 2 cp + 1
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[c][e] = 0.f;
+  bf16x8 wf[2][2][2];   // the Wh slice's fragments [half][kk][column block of the pair]: read from LDS once
+  for (int t = 0; t < NT; ++t) {
+    const int s = t % HB_NS;
+    lds_char* st = stage_at(s);
+    // Vector-memory operations of this wave YOUNGER than its five loads of tile t (one in-order queue of loads and
+    // stores): tiles 0, 1 were requested in the prologue, tile t >= 2 right behind the barrier of tile t - 2; every
+    // tile ends with 1 store
+    const int younger = t == 0 ? 5 : t == 1 ? 6 : (t + 1 < NT ? 7 : 2);
+    wait_vm_exact(younger);               // this wave's share of the stage (and of Wh) has landed ...
+    __builtin_amdgcn_s_barrier();         // ... and so has everybody else's -- and every wave has finished tile t - 1:
+    asm volatile("" ::: "memory");        // ITS stage is free, and takes tile t + 2 (ONE barrier per tile, three stages)
+    if (t + 2 < NT) issue_stage(t + 2, (t + 2) % HB_NS);
+    if (t == 0) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) wf[half][kk][c] = load_frag<64, false>(whI + half * 8192, (2 * cp + c) * 16, kk, lane);
+    }
+    // ---- dgrad: rows 16 rb + j, columns 32 cp .. +31, K = 128
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 x = load_frag<64, true>(st + half * 8192, 16 * rb, kk, lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[half][kk][c], x, acc[c], 0, 0, 0);
+      }
+    // ---- dWh += dmulv_tile^T h1_tile: row block `wave` of l, contraction over the tile's 64 rows
+    const lds_char* am = st + HB_AK;
+    const lds_char* hm = st + HB_AK + HB_AM;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 xa = load_frag<128, false>(am, wave * 16, kk, lane);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const bf16x8 hb = load_frag<64, false>(hm, cb * 16, kk, lane);
+        acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hb, xa, acc2[cb], 0, 0, 0);
+      }
+    }
+    // ---- ReLU mask from the same h1 tile (element (row r, column c) of the MN-major image), column sums
+    const int r = 16 * rb + j;
+    float v[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cb = 2 * cp + c;
+      const bf16x4 m4 = *(const __attribute__((address_space(3))) bf16x4*)(hm + r * 128 + ((cb ^ swz_mn<64>(r)) * 32) + q * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[c][e] = (float)m4[e] > 0.f ? acc[c][e] : 0.f;
+        cs[c][e] += v[c][e];
+      }
+    }
+    // ---- dP1: the accumulator-direct store of gemm_bf16.h (pair the two column blocks: 8 columns per lane)
+    {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a_ = v[0][e], b_ = v[1][e];
+        swap_rows16(a_, b_);
+        lo[e] = a_;
+        hi[e] = b_;
+      }
+      const bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+      bf16_t* out = dP1 + (r_base + (long)HB_TR * t + r) * ldp + c0;
+      store_out16((bf16x8*)(out + (2 * cp + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
+    }
+  }
+  // ---- dWh slab of this row group
+  float* slab = dwh_slabs + (long)g * 128 * lddw + c0;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+    store_out16((f32x4*)(slab + (long)(wave * 16 + j) * lddw + cb * 16 + q * 4), acc2[cb], wt);
+  // ---- column sums: over the 16 row lanes, then over the 4 row-block waves of a column pair (through the Wh slice's
+  // LDS, idle by now)
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = cs[c][e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
+      cs[c][e] = x;
+    }
+  __attribute__((address_space(3))) float* red = (__attribute__((address_space(3))) float*)whI;
+  // (nothing has read LDS since the last tile's second barrier; raw barrier: __syncthreads() would also wait for the
+  // dP1 / slab stores to drain)
+  if (j == 0)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[rb * 64 + (2 * cp + c) * 16 + q * 4 + e] = cs[c][e];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (db1_partial && tid < 64) db1_partial[(long)g * Hp + c0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -543,6 +750,28 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
                      (const bf16_t*)dp3_bf16, lddp, (const bf16_t*)w3_bf16, ldw3, Hp, B, L, S, mulv, eps, kl_beta, dmu_ext,
                      dlv_ext, (bf16_t*)dmulv_bf16, dbh_partial, mse_partial, n_mse, kl_partial, n_kl, loss_out,
                      step_counter, ring, n_rows, g);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_heads_bwd(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp, long Hp,
+                 long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* stream) {
+  RV_REQUIRE(dmulv_bf16 && wh_bf16 && h1_bf16 && dp1_bf16 && dwh_slabs, RV_ERR_NULL, "rv_heads_bwd: null pointer");
+  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_heads_bwd: built for a padded latent width of 64 (got %ld)", Lp);
+  RV_REQUIRE(Bp > 0 && Bp % HB_RG == 0 && Hp > 0 && Hp % 64 == 0, RV_ERR_UNSUPPORTED,
+             "rv_heads_bwd: the padded batch must be a multiple of 512 and the padded hidden width of 64 (got %ld, %ld)", Bp, Hp);
+  RV_REQUIRE(ldw >= Hp && ldh >= Hp && ldp >= Hp && lddw >= Hp && ldw % 8 == 0 && ldh % 8 == 0 && ldp % 8 == 0 && lddw % 4 == 0,
+             RV_ERR_SHAPE, "rv_heads_bwd: bad leading dimensions");
+  RV_REQUIRE((((uintptr_t)dmulv_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)h1_bf16 | (uintptr_t)dp1_bf16 | (uintptr_t)dwh_slabs) & 15) == 0,
+             RV_ERR_SHAPE, "rv_heads_bwd: operands must be 16-byte aligned");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_heads_bwd, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
+                     (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
+                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

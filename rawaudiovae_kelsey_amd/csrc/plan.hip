@@ -46,6 +46,10 @@ struct rv_plan {
   long B, S, H, L, Bp, Sp, Hp, Lp, L2p;
   int s_heads, s_dz, s_w4, s_w3, s_wh, s_w1;  // split-K factors
   int n_mse, n_kl, n_mt4, n_mt3, n_mt1;       // partial counts (row tiles of the producing GEMMs)
+  // the heads' backward has two forms with different partial counts: the generic dual launch (s_wh_gen slabs of dWh,
+  // n_mt1_gen partial rows of fc1's bias gradient) and the streaming kernel rv_heads_bwd (hb_groups of both; 0 = the
+  // shape does not allow it); s_wh / n_mt1 and the descriptors follow the form in use (heads_mode_apply)
+  int s_wh_gen = 1, n_mt1_gen = 1, hb_groups = 0;
   long off[10];                               // element offsets of the 10 params in the flat arenas
   long n_params;
   std::vector<Buf> bufs;
@@ -109,6 +113,24 @@ int w1_tile(const rv_plan* p) {
 }
 }  // namespace
 
+// Which form of the heads' backward runs (see rv_plan: s_wh_gen / hb_groups) and the partial counts that follow from it.
+static bool heads_streaming(const rv_plan* p) {
+  return p->latent_fused && p->hb_groups > 0 && p->Hp % 512 == 0 && p->Hp <= 2048;
+}
+static void heads_mode_apply(rv_plan* p) {
+  const bool st = heads_streaming(p);
+  p->s_wh = st ? p->hb_groups : p->s_wh_gen;
+  p->n_mt1 = st ? p->hb_groups : p->n_mt1_gen;
+  p->d_slab[1].grad_splits = p->n_mt1;
+  p->d_slab[2].grad_splits = p->s_wh;
+  p->d_slab[4].grad_splits = p->s_wh;
+  if (!p->b.grad) {   // without a flat gradient arena d_flat mirrors the slab descriptors
+    p->d_flat[1].grad_splits = p->n_mt1;
+    p->d_flat[2].grad_splits = p->s_wh;
+    p->d_flat[4].grad_splits = p->s_wh;
+  }
+}
+
 extern "C" {
 
 int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
@@ -134,8 +156,9 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     // heads backward (dgrad with the ReLU mask of h1 + wgrad) also goes through rv_linear_dgrad_wgrad
     int paired = 0, bm = 128, sp = 1;
     rv_dgrad_wgrad_pick(Bp, Hp, L2p, &paired, &bm, &sp);
-    p->s_wh = sp;
-    p->n_mt1 = (int)(Bp / bm);
+    p->s_wh = p->s_wh_gen = sp;
+    p->n_mt1 = p->n_mt1_gen = (int)(Bp / bm);
+    p->hb_groups = (Lp == 64 && Bp % 512 == 0 && Hp % 64 == 0) ? (int)(Bp / 512) : 0;
   }
   p->s_w1 = splits_of(Hp, Sp, Bp);
   // per-row-tile partial counts follow the tile each producing GEMM will use
@@ -172,12 +195,12 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dmulv", Bp * L2p * 2);
   p->add("dP1", Bp * Hp * 2);
   p->add("dW1", (long)p->s_w1 * Hp * Sp * 4);
-  p->add("dWh", (long)p->s_wh * L2p * Hp * 4);
+  p->add("dWh", (long)(p->s_wh_gen > p->hb_groups ? p->s_wh_gen : p->hb_groups) * L2p * Hp * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
   p->add("dW1_us", (long)p->s_w1 * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
   p->add("dW4_us", (long)p->s_w4 * (Sp / 32) * (Hp / 32) * 4);
-  p->add("db1p", (long)p->n_mt1 * Hp * 4);
+  p->add("db1p", (long)(p->n_mt1_gen > p->hb_groups ? p->n_mt1_gen : p->hb_groups) * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
   p->add("db4p", (long)p->n_mt4 * Sp * 4);
@@ -268,7 +291,7 @@ static int plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
 int rv_plan_set_option(rv_plan* p, int option, int value) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_option: plan not bound");
   switch (option) {
-    case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; return RV_OK;
+    case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; heads_mode_apply(p); return RV_OK;
     case RV_OPT_FP8: return plan_set_fp8(p, value);
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
   }
@@ -325,6 +348,7 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
       p->d_flat[i].grad_splits = 1;
     }
   }
+  heads_mode_apply(p);
   return plan_set_slab_dtype(p, p->slab_dtype);
 }
 
@@ -397,6 +421,9 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
                        (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter,
                        p->b.ring, z, Lp, (float*)p->ws("dW3"), Lp, p->s_w3, stream);
     if (rc) return rc;
+    if (heads_streaming(p))
+      return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
+                          stream);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream);
   }
@@ -508,6 +535,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                      (float*)p->ws("dW3"), Lp, p->s_w3, st);
   };
   auto heads_bwd = [&](void* st) {
+    if (heads_streaming(p))
+      return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp, st);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, st);
   };

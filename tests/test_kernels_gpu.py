@@ -456,6 +456,56 @@ def test_latent_bwd_one_launch_equals_two(L, B, Lt, H, ext):
                         None, None, dm1.data_ptr(), db1.data_ptr(), None, 0, None, 0, None, None, 0, None, 0, None, 0, 0, sp())
 
 
+@pytest.mark.parametrize("B,Lt,H", [(512, 64, 128), (4096, 64, 2048), (1000, 17, 900)])
+def test_heads_bwd_streaming_equals_the_dual_launch(L, B, Lt, H):
+    """rv_heads_bwd (dP1 = relu'(h1) * (dmulv Wh), its column sums and dWh = dmulv^T h1 from ONE pass over h1) against
+    the route it replaces (rv_linear_dgrad_wgrad: dgrad with mask + split-K wgrad) and against float64 numpy, on the
+    same bf16 operands.  dP1: the K = 128 dot product is accumulated by the same four MFMAs in the same order -> bit
+    equal; dWh and the column sums group the batch differently (512-row groups instead of K splits / 128-row tiles) ->
+    equal to fp32 summation order (stated bound 1e-5 of the term scale)."""
+    rng = np.random.default_rng(23)
+    Bp, Lp, Hp = -(-B // 512) * 512, 64, -(-H // 128) * 128
+    G = Bp // 512
+    dm = np.zeros((Bp, 2 * Lp), np.float32)
+    dm[:B, :Lt] = rand_bf16(rng, (B, Lt), 1e-3); dm[:B, Lp:Lp + Lt] = rand_bf16(rng, (B, Lt), 1e-3)
+    wh = np.zeros((2 * Lp, Hp), np.float32)
+    wh[:Lt, :H] = rand_bf16(rng, (Lt, H), 0.05); wh[Lp:Lp + Lt, :H] = rand_bf16(rng, (Lt, H), 0.05)
+    h1 = np.zeros((Bp, Hp), np.float32); h1[:B, :H] = np.maximum(rand_bf16(rng, (B, H), 0.5), 0)
+    dmd, whd, h1d = dev(dm, torch.bfloat16), dev(wh, torch.bfloat16), dev(h1, torch.bfloat16)
+    dp1 = torch.full((Bp, Hp), 7.0, device="cuda", dtype=torch.bfloat16)
+    db1 = torch.full((G, Hp), 7.0, device="cuda")
+    dwh = torch.full((G, 2 * Lp, Hp), 7.0, device="cuda")
+    L.rv_heads_bwd(dmd.data_ptr(), whd.data_ptr(), Hp, h1d.data_ptr(), Hp, Bp, Hp, Lp, dp1.data_ptr(), Hp, db1.data_ptr(),
+                   dwh.data_ptr(), Hp, sp())
+    # the generic route
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
+    paired, bm, splits = dgrad_wgrad_pick(Bp, Hp, 2 * Lp)
+    dp1r = torch.empty(Bp, Hp, device="cuda", dtype=torch.bfloat16)
+    csr = torch.zeros(Bp // bm, Hp, device="cuda")
+    dwr = torch.empty(splits, 2 * Lp, Hp, device="cuda")
+    L.rv_linear_dgrad_wgrad(dmd.data_ptr(), 2 * Lp, whd.data_ptr(), Hp, h1d.data_ptr(), Hp, Bp, Hp, 2 * Lp, dp1r.data_ptr(), Hp,
+                            csr.data_ptr(), dwr.data_ptr(), Hp, splits, 0, None, sp())
+    assert torch.equal(dp1, dp1r)
+    # float64
+    ref = (dm.astype(np.float64) @ wh.astype(np.float64)) * (h1 > 0)
+    got = dp1.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2.0 ** -7, atol=1e-5 * float(np.abs(ref).max()))
+    assert not got[B:].any() and not got[:, H:].any()
+    refw = dm.astype(np.float64).T @ h1.astype(np.float64)
+    scale_w = float((np.abs(dm).astype(np.float64).T @ np.abs(h1).astype(np.float64)).max())
+    np.testing.assert_allclose(dwh.double().sum(0).cpu().numpy(), refw, rtol=1e-4, atol=1e-5 * scale_w)
+    np.testing.assert_allclose(dwh.double().sum(0).cpu().numpy(), dwr.double().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-5 * scale_w)
+    refc = got.astype(np.float64).sum(0)            # column sums are taken of the fp32 values BEFORE the bf16 rounding:
+    refc32 = ref.sum(0)                             # compare with the unrounded reference
+    np.testing.assert_allclose(db1.double().sum(0).cpu().numpy(), refc32, rtol=1e-4, atol=1e-5 * float(np.abs(ref).sum(0).max()) + 1e-12)
+    np.testing.assert_allclose(db1.double().sum(0).cpu().numpy(), csr.double().sum(0).cpu().numpy(), rtol=1e-4,
+                               atol=1e-5 * float(np.abs(ref).sum(0).max()) + 1e-12)
+    from rawaudiovae_kelsey_amd import _lib
+    with pytest.raises(_lib.RvError):
+        L.rv_heads_bwd(dmd.data_ptr(), whd.data_ptr(), Hp, h1d.data_ptr(), Hp, Bp, Hp, 128, dp1.data_ptr(), Hp, db1.data_ptr(),
+                       dwh.data_ptr(), Hp, sp())
+
+
 def test_adam_multi_and_finalize(L):
     from rawaudiovae_kelsey_amd._lib import ParamDesc
     rng = np.random.default_rng(8)
