@@ -55,6 +55,11 @@ def parse():
                     help="heads + reparam + fc3 of the forward as one row-local launch (1, default) or three launches (0)")
     ap.add_argument("--fp8", action="store_true",
                     help="ignored (kept for old command lines): the headline is bf16; the fp8 forward is timed as the side line `alt_fp8`")
+    ap.add_argument("--step-kernels-only", action="store_true",
+                    help="profiling runs (tools/prof_round3.sh, tools/pmc_round.sh): launch nothing but the timed steps -- "
+                         "the dominant kernel is then timed by ONE batch of 50 back-to-back launches instead of the in-step "
+                         "differential measurement, whose phase-by-phase graphs would put other kernel variants into the "
+                         "profile")
     ap.add_argument("--no-alts", action="store_true",
                     help="skip the side lines `alt_fp8` (fc1 / fc4 forward on e4m3 operands, BASELINE configs[4]) and "
                          "`alt_fp32_slabs`; they are timed after the headline at N=1 and never replace it")
@@ -120,6 +125,25 @@ def time_dominant_kernel(eng, x, steps=10, reps=7):
             "dW=dY^T X 1024x2048x4096 split-K %d, %s slabs)" % (splits, eng.slab_dtype)) if paired else \
         "rv_linear_dgrad + rv_linear_wgrad (fc4 backward, unpaired fallback, split-K %d)" % splits
     return diffs[len(diffs) // 2], 4.0 * S * H * B, desc, diffs
+
+
+def time_dominant_kernel_batch(eng, x, reps=50):
+    """`--step-kernels-only`: one pair of HIP events around `reps` back-to-back launches of the plan's fc4-backward
+    phase (the round's earlier method; see time_dominant_kernel for why it is not the headline method)."""
+    import torch
+    from rawaudiovae_kelsey_amd import engine as E
+    ts = torch.cuda.current_stream()
+    eng.step(x, phases=E.PHASE_FWD, stream=ts)
+    for _ in range(5):
+        eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(ts)
+    for _ in range(reps):
+        eng.step(x, phases=E.PHASE_BWD_FC4, stream=ts)
+    b.record(ts)
+    b.synchronize()
+    ms = a.elapsed_time(b) / reps
+    return ms, 4.0 * S * H * B, "gemm_dgrad_wgrad_kernel<256,256> (fc4 backward; one batch of %d back-to-back launches)" % reps, [ms]
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -589,7 +613,12 @@ def main():
                 alt = {"grad_allreduce": "bf16 payload, same schedule", "error": str(exc)[:200]}
             finally:
                 runner.set_payload("fp32")
-        kern_ms, kern_flops, kern_cfg, kern_batches = time_dominant_kernel(eng, pool[0]) if rank == 0 else (None, None, None, None)
+        if rank != 0:
+            kern_ms, kern_flops, kern_cfg, kern_batches = None, None, None, None
+        elif args.step_kernels_only:
+            kern_ms, kern_flops, kern_cfg, kern_batches = time_dominant_kernel_batch(eng, pool[0])
+        else:
+            kern_ms, kern_flops, kern_cfg, kern_batches = time_dominant_kernel(eng, pool[0])
         # Side lines, never the headline: the same K steps on engines with opt-in reduced-precision storage
         alts = {}
         if world == 1 and not args.no_alts:

@@ -354,7 +354,12 @@ k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __re
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, j = lane & 15;
-  const long r0 = (long)blockIdx.x * LAT_ROWS;
+  // Workgroups b, b + 8, ... share an XCD and its L2.  The launch's dW3 workgroups on XCD x read the batch rows of K
+  // split x (gemm_body deals each XCD a contiguous run of (split, tile) items), so the dz workgroups on XCD x take the
+  // same rows: the second reader of dP3 then finds it in that L2 (PMC: 37.6 -> see profiles/r03_traffic.txt).  Any
+  // bijection of workgroups onto 16-row groups is correct; this one only places them.
+  const int grp = (n_rows & 7) == 0 ? (int)(blockIdx.x & 7) * (n_rows >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const long r0 = (long)grp * LAT_ROWS;
   lds_char* ring = smem + wave * L_RING;
   lds_char* const W0 = ring, * const W1 = ring + LW_SLOT;
   const long kw = Hp / LB_WAVES;
@@ -456,8 +461,8 @@ k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __re
       a += sm[(r * 16 + g) * 4 + e];
       c += sv[(r * 16 + g) * 4 + e];
     }
-    dbh_partial[(long)blockIdx.x * L2p + tid] = a;
-    dbh_partial[(long)blockIdx.x * L2p + Lp + tid] = c;
+    dbh_partial[(long)grp * L2p + tid] = a;
+    dbh_partial[(long)grp * L2p + Lp + tid] = c;
   }
 }
 

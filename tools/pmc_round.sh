@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --no-alts --steps 20 --warmup 3 --repeats 1 > $R/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --no-alts --steps 20 --warmup 3 --repeats 1 > $R/gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --no-alts --step-kernels-only --steps 20 --warmup 3 --repeats 1 > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --no-alts --step-kernels-only --steps 20 --warmup 3 --repeats 1 > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
 python tools/traffic_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic.txt
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write

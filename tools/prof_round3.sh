@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 TAG=$1; shift
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-alts --steps 100 --warmup 10 --repeats 5 "$@" > $O/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-alts --step-kernels-only --steps 100 --warmup 10 --repeats 5 "$@" > $O/${TAG}_stats.log 2>&1
 cd $R
 python tools/timeline_csv.py $(find $O/${TAG}_stats -name "*kernel_trace.csv" | head -1) 5 > $O/${TAG}_timeline.txt
 python tools/prof_summary.py $O/${TAG}_stats 565 > $O/${TAG}_kernel_summary.txt
