@@ -415,11 +415,14 @@ long rv_plan_workspace_bytes(const rv_plan*);
 int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
 /* Plan options (the plan must be bound):
  *   RV_OPT_LATENT_FUSED  1 (default): heads GEMM, reparameterisation and fc3 of the forward are ONE launch
- *     (rv_latent_fwd) when the padded latent width is 64, the padded hidden width a multiple of 512 up to 2048 and the
- *     fp8 path off, and dz + the reparameterisation backward likewise (rv_latent_bwd; not tied to fp8); 0, or any
- *     other shape: three launches (rv_heads_reparam_fwd + fc3) and dz as split-K slabs + rv_reparam_bwd.
+ *     (rv_latent_fwd; with the fp8 forward it also emits fc4's fp8 operand) when the padded latent width is 64 and
+ *     the padded hidden width a multiple of 512 up to 2048, and dz + the reparameterisation backward likewise (rv_latent_bwd); 0, or any
+ *     other shape: three launches (rv_heads_reparam_fwd + fc3) and dz as split-K slabs + rv_reparam_bwd.  The same
+ *     switch selects the heads' backward: rv_heads_bwd (one pass over h1; needs a padded batch that is a multiple of
+ *     512) or the generic rv_linear_dgrad_wgrad; the partial counts of fc21 / fc22 weights and of fc1's bias in
+ *     rv_plan_descs follow the form in use.
  *   RV_OPT_FP8  1: fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay
- *     bf16).  The workspace buffer "fp8_state" holds 8 floats the caller initialises before rv_plan_refresh_shadows:
+ *     bf16).  The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:
  *       [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
  *       [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
  *           "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
