@@ -190,3 +190,35 @@ def test_host_logic_under_asan_ubsan(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_plan_descriptors_follow_the_heads_backward_in_use():
+    """Host-only (rv_plan_create / bind / descs touch no device): with RV_OPT_LATENT_FUSED the heads' backward is the
+    streaming kernel (one dWh slab and one fc1-bias partial row per 512 batch rows), without it the generic dual launch
+    (the picker's split count, one partial row per dgrad row tile); the parameter descriptors the optimizer reads must
+    switch with it, and no other tensor's may move."""
+    import ctypes as C
+    from rawaudiovae_kelsey_amd import _lib
+    L = _lib.lib()
+    for B in (4096, 1024):
+        plan = C.c_void_p()
+        L.rv_plan_create(C.byref(plan), B, 1024, 2048, 64)
+        base = 0x10000000
+        bufs = _lib.PlanBuffers(param=base, exp_avg=base + 0x4000000, exp_avg_sq=base + 0x8000000, grad=base + 0xc000000,
+                                workspace=base + 0x10000000, step_counter=base + 0x100, loss_ring=base + 0x1000, ring=4)
+        L.rv_plan_bind(plan, C.byref(bufs))
+        arr = (_lib.ParamDesc * 10)()
+
+        def splits():
+            L.rv_plan_descs(plan, arr, 0)
+            return [arr[i].grad_splits for i in range(10)]
+        fused = splits()
+        L.rv_plan_set_option(plan, _lib.OPT_LATENT_FUSED, 0)
+        generic = splits()
+        L.rv_plan_set_option(plan, _lib.OPT_LATENT_FUSED, 1)
+        assert splits() == fused
+        paired, bm, sp = _lib.dgrad_wgrad_pick(B, 2048, 128)
+        assert fused[1] == fused[2] == fused[4] == B // 512
+        assert generic[1] == B // bm and generic[2] == generic[4] == sp
+        assert [v for i, v in enumerate(fused) if i not in (1, 2, 4)] == [v for i, v in enumerate(generic) if i not in (1, 2, 4)]
+        L.rv_plan_destroy(plan)
