@@ -441,8 +441,18 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     2 x 33.5 MB of fp32 slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see above), which
  *     halves what the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32
  *     sum over a quarter of the batch; rounding it to fp16 adds ~3e-4 relative noise to those two gradients whatever
- *     their magnitude (the sum over slabs stays fp32). */
-enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2 };
+ *     their magnitude (the sum over slabs stays fp32).
+ *   RV_OPT_ROCTX  1: roctx ranges (rocprofv3 --marker-trace) around the host calls that enqueue the step's phases --
+ *     "rv:fwd", "rv:fc4-bwd", "rv:rest-bwd", "rv:adam" (local step) / "rv:rest-bwd+exchange+adam" (data-parallel step) --
+ *     so that a kernel timeline reads as phases (tracing).  The marker library is loaded at run time
+ *     (librocprofiler-sdk-roctx.so, else libroctx64.so); RV_ERR_UNSUPPORTED when neither can be.  Default 0.
+ *   RV_OPT_DDP_SIGNAL  how the compute stream and the collective stream of rv_plan_step_ddp (all-reduce schedule) hand
+ *     work to each other: 1 (default) device-side sequence flags in the workspace buffer "ddp_flags" -- a one-wave kernel
+ *     behind the producer publishes the step's number, a one-wave kernel in front of the consumer waits for it (~1.8 us
+ *     per crossing; deadlock-free for any stream -> hardware-queue mapping because every waiter is enqueued after its
+ *     setter; bounded at 100 ms, timeouts counted in ddp_flags[8], which must stay 0) -- or 0: HIP events (~9 us per
+ *     crossing).  Steps enqueued under stream capture always use events (a graph needs the edges). */
+enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and

@@ -10,6 +10,13 @@ extern "C" {
  * 7: 256x256 with the ping-pong loop); -1 = the picker's choice.  108 / 102 select the ping-pong (default) / ring
  * main loop of the paired 256x256 launch (the ring is what odd K-tile counts get). */
 int rv_gemm_force_tile(int tile);
+/* Leave launches out of the following FULL steps of a plan (rv_plan_step with RV_PHASE_ALL_LOCAL): bit k of `mask`
+ * skips launch k -- 0 cast, 1 fc1 forward, 2 latent forward (heads + reparameterisation + fc3), 3 fc4 forward + loss,
+ * 4 paired fc4 backward, 5 latent backward, 6 heads backward, 7 fc1 weight gradient + optimizer riders, 8 Adam(fc1).
+ * bench.py times every launch of the step IN the step with it: (a graph of steps) - (the same graph without launch k).
+ * Results of a step with launches missing are meaningless.  0 restores the full step. */
+struct rv_plan;
+int rv_plan_diag_skip(struct rv_plan* plan, unsigned mask);
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,7 @@ class CommDesc(C.Structure):
                 ("msg_send", c_void_p), ("msg_recv", c_void_p), ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
 
 
-OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE = 0, 1, 2
+OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL = 0, 1, 2, 3, 4
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
@@ -57,7 +57,8 @@ _SIGS = {
     "rv_version": (c_int, []),
     "rv_last_error": (C.c_char_p, []),
     "rv_pad_dims": (c_int, [c_long] * 4 + [C.POINTER(c_long)] * 4),
-    "rv_gemm_force_tile": (c_int, [c_int]),   # test hook (include/rawvae_hip_diag.h), not part of the product ABI
+    "rv_gemm_force_tile": (c_int, [c_int]),   # test hooks (include/rawvae_hip_diag.h), not part of the product ABI
+    "rv_plan_diag_skip": (c_int, [c_void_p, C.c_uint]),
     "rv_linear_dgrad_wgrad_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_long,
                                           c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "rv_cast_pad_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,

@@ -929,6 +929,43 @@ int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* 
   return RV_OK;
 }
 
+// ---- device-side cross-stream signalling (plan.hip: the data-parallel step) ----
+// A hand-over between two streams through HIP events costs ~9 us per crossing on this runtime (record -> dependent
+// kernel on the other stream; 4.6 us of bubble on the recording stream alone); through a flag in device memory it
+// costs ~1.8 (measured: tools/scratch microbenchmark).  k_flag_set runs BEHIND the producing kernel
+// in its stream (the kernel boundary in front of it is the agent-scope release of the producer's data) and publishes
+// a sequence number; k_flag_wait sits in the consumer stream IN FRONT of the consuming kernel and returns when the
+// number has arrived.  Deadlock-free by construction whatever the runtime's stream -> hardware-queue mapping is: every
+// waiter is enqueued (host order) after its setter, so the oldest unfinished kernel over all queues never waits on
+// anything unfinished.  The wait is bounded all the same (100 ms): a timeout is counted in `timeouts` and the engine
+// raises when it sees a non-zero count (results of that step are invalid).
+__global__ void __launch_bounds__(64) k_flag_set(int* flag, int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(64) k_flag_wait(const int* flag, int value, int* timeouts) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();   // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 10000000LL) {
+        atomicAdd(timeouts, 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+int rv_flag_set(int* flag, int value, void* stream) {
+  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+int rv_flag_wait(const int* flag, int value, int* timeouts, void* stream) {
+  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timeouts);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
 int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* stream) {
   RV_REQUIRE(a && scalar && out, RV_ERR_NULL, "rv_scale_by: null pointer");
   if (n == 0) return RV_OK;

@@ -5,6 +5,8 @@
 #include "../../include/rawvae_hip.h"
 #include "internal.h"
 
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -40,6 +42,35 @@ int row_tiles(long Mp, long Np) {
   return (int)(Mp / bm);
 }
 
+}  // namespace
+
+// roctx ranges around the phases of a step (RV_OPT_ROCTX): the marker library is looked up at run time, once; without it
+// (or with the option off) a range is two untaken branches.  Ranges bracket the HOST calls that enqueue a phase: in a
+// rocprofv3 --marker-trace --kernel-trace timeline every kernel dispatch falls inside the range that launched it.
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+bool roctx_load() {
+  static int state = 0;   // 0 not tried, 1 loaded, -1 unavailable
+  if (state == 0) {
+    state = -1;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+      g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+      if (g_roctx_push && g_roctx_pop) { state = 1; break; }
+    }
+  }
+  return state == 1;
+}
+struct Range {   // scope guard
+  bool on;
+  Range(bool enabled, const char* name) : on(enabled && g_roctx_push) { if (on) g_roctx_push(name); }
+  ~Range() { if (on) g_roctx_pop(); }
+};
 }  // namespace
 
 struct rv_plan {
@@ -82,6 +113,11 @@ struct rv_plan {
   unsigned short* msg_recv = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (RV_OPT_FP8)
+  int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax"
+  int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
+  int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
+  int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
+  unsigned skip = 0;           // rv_plan_diag_skip (include/rawvae_hip_diag.h): launches of the full step left out
   int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (RV_OPT_SLAB_DTYPE)
   float* us_w1 = nullptr;         // per-granule scale tables of the fp16 slabs (workspace "dW1_us" / "dW4_us")
   float* us_w4 = nullptr;
@@ -209,7 +245,10 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("W4q", Sp * Hp);
   p->add("h3q", Bp * Hp);
   p->add("fp8_state", (32 + 2 * 1024) * 4);   // 16 state floats (+16 pad), then 2 x 1024 max|W| slots
-  p->add("h3_amax", 4096 * 4);    // per-block max|h3| of the fc3 forward (zero until it has run)
+  // per-wave (fused latent forward: 8 per 16 batch rows) or per-tile max|h3| of the fc3 forward (zero until it has run)
+  p->n_amax_cap = (int)(Bp / 2 > 4096 ? Bp / 2 : 4096);
+  p->add("h3_amax", (long)p->n_amax_cap * 4);
+  p->add("ddp_flags", 64 * 4);   // data-parallel step: cross-stream sequence flags [0..3], timeout counter [8]
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
   p->bound = false;
@@ -285,6 +324,11 @@ static int plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
   d1->grad_half = half; d1->grad_unscale = half ? p->us_w1 : nullptr; d1->us_ld = Sp / 32; d1->us_split_stride = (Hp / 32) * (Sp / 32);
   rv_param_desc* d4 = p->d_slab + 8;
   d4->grad_half = half; d4->grad_unscale = half ? p->us_w4 : nullptr; d4->us_ld = Hp / 32; d4->us_split_stride = (Sp / 32) * (Hp / 32);
+  if (!p->b.grad)   // without a flat gradient arena d_flat describes the same slabs (rv_plan_bind): keep their element type
+    for (int i : {0, 8}) {
+      p->d_flat[i].grad_half = p->d_slab[i].grad_half; p->d_flat[i].grad_unscale = p->d_slab[i].grad_unscale;
+      p->d_flat[i].us_ld = p->d_slab[i].us_ld; p->d_flat[i].us_split_stride = p->d_slab[i].us_split_stride;
+    }
   return RV_OK;
 }
 
@@ -294,8 +338,20 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
     case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; heads_mode_apply(p); return RV_OK;
     case RV_OPT_FP8: return plan_set_fp8(p, value);
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
+    case RV_OPT_DDP_SIGNAL: p->ddp_signal = value ? 1 : 0; return RV_OK;
+    case RV_OPT_ROCTX:
+      RV_REQUIRE(!value || roctx_load(), RV_ERR_UNSUPPORTED, "rv_plan_set_option: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) could be loaded");
+      p->roctx = value ? 1 : 0;
+      return RV_OK;
   }
   RV_REQUIRE(false, RV_ERR_UNSUPPORTED, "rv_plan_set_option: unknown option %d", option);
+  return RV_OK;
+}
+
+// Test / measurement hook (include/rawvae_hip_diag.h): leave launches out of the following full steps.
+int rv_plan_diag_skip(rv_plan* p, unsigned mask) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_diag_skip: null plan");
+  p->skip = mask;
   return RV_OK;
 }
 
@@ -415,24 +471,31 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
   void* dP3 = p->ws("dP3"); void* z = p->ws("z"); void* h1 = p->ws("h1"); void* dP1 = p->ws("dP1"); void* dmulv = p->ws("dmulv");
   float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
   float* mse_part = (float*)p->ws("mse_part"); float* kl_part = (float*)p->ws("kl_part");
+  const bool do_latent = !(p->skip >> 5 & 1), do_heads = !(p->skip >> 6 & 1);   // rv_plan_diag_skip
   int rc;
   if (latent_bwd_fused(p)) {
-    rc = rv_latent_bwd(dP3, Hp, p->ws("W3b"), Lp, Bp, Hp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv,
-                       (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter,
-                       p->b.ring, z, Lp, (float*)p->ws("dW3"), Lp, p->s_w3, stream);
-    if (rc) return rc;
+    if (do_latent) {
+      rc = rv_latent_bwd(dP3, Hp, p->ws("W3b"), Lp, Bp, Hp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv,
+                         (float*)p->ws("dbhp"), mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter,
+                         p->b.ring, z, Lp, (float*)p->ws("dW3"), Lp, p->s_w3, stream);
+      if (rc) return rc;
+    }
+    if (!do_heads) return RV_OK;
     if (heads_streaming(p))
       return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
                           stream);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream);
   }
-  rc = rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz, (float*)p->ws("dW3"), Lp,
-                                 p->s_w3, stream);
-  if (rc) return rc;
-  rc = rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv, (float*)p->ws("dbhp"),
-                      mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream);
-  if (rc) return rc;
+  if (do_latent) {
+    rc = rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz, (float*)p->ws("dW3"), Lp,
+                                   p->s_w3, stream);
+    if (rc) return rc;
+    rc = rv_reparam_bwd(dz_slabs, p->s_dz, Bp, Lp, B, L, S, mulv, eps_used, kl_beta, dmu_ext, dlv_ext, dmulv, (float*)p->ws("dbhp"),
+                        mse_part, p->n_mse, kl_part, p->n_kl, p->b.loss_ring, p->b.step_counter, p->b.ring, stream);
+    if (rc) return rc;
+  }
+  if (!do_heads) return RV_OK;
   return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"), p->ws("dWh"), Hp,
                                p->s_wh, RV_SLAB_F32, nullptr, stream);
 }
@@ -451,77 +514,79 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   const float* eps_used = eps ? eps : eps_buf;
   int rc;
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+#define RV_K(k, call) do { if (!(p->skip >> (k) & 1)) RV_TRY(call); } while (0)   /* launch k of the step (rv_plan_diag_skip) */
   if (phases & RV_PHASE_FWD) {
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
+    Range range_fwd(p->roctx, "rv:fwd");
     float* f8 = (float*)p->ws("fp8_state");
     int n_amax = 0;
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
     const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048;
     if (p->fp8 && latent_fused) {
       n_amax = (int)(Bp / 16) * 8;   // one maximum per wave of rv_latent_fwd_ex
-      RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 8192 batch rows with the fused latent forward");
+      RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_STATE, "rv_plan_step: h3_amax holds %d entries, the fused latent forward writes %d", p->n_amax_cap, n_amax);
     } else if (p->fp8) {
       int bm3 = 128, bn3 = 128;
       rv_gemm_tile(Bp, Hp, 1, &bm3, &bn3);
       n_amax = (int)((Bp / bm3) * (Hp / bn3));
-      RV_REQUIRE(n_amax <= 4096, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to 4096 fc3 output tiles (got %d)", n_amax);
+      RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to %d fc3 output tiles (got %d)", p->n_amax_cap, n_amax);
     }
     if (p->fr_hop && p->fr_bf16 && !p->fp8 && p->fr_hop % 8 == 0 && ((uintptr_t)p->fr_bf16 & 15) == 0) {
       // N1 as SURVEY 8f words it: fc1's A-tile loader reads frame i at i * hop of the resident bf16 waveform; the
       // framed bf16 matrix dW1 needs later is a by-product of that launch; no cast / gather kernel
-      RV_TRY(rv_linear_fwd_frames(p->fr_bf16, p->fr_idx, p->fr_first, p->fr_hop, B, p->ws("W1b"), Sp, (float*)p->ws("b1p"),
+      RV_K(1, rv_linear_fwd_frames(p->fr_bf16, p->fr_idx, p->fr_first, p->fr_hop, B, p->ws("W1b"), Sp, (float*)p->ws("b1p"),
                                   Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, xb, Sp, p->b.step_counter, stream));
     } else if (p->fr_hop) {
       // frames come straight from the resident waveform: waveform -> bf16 (and fp8) operand in one kernel
-      RV_TRY(rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb, Bp, Sp, Sp,
+      RV_K(0, rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb, Bp, Sp, Sp,
                                    p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
                                    p->b.step_counter, stream));
       if (p->fp8)
-        RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+        RV_K(1, rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
                                  h1, Hp, stream));
       else
-        RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
+        RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     } else if (p->fp8) {
-      RV_TRY(rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
+      RV_K(0, rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
                                  p->b.step_counter, stream));
-      RV_TRY(rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
+      RV_K(1, rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
                                h1, Hp, stream));
     } else {
-      RV_TRY(rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
-      RV_TRY(rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
+      RV_K(0, rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
+      RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     }
     if (latent_fused)
-      RV_TRY(rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
+      RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
                               B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
                               p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
                               p->fp8 ? (float*)p->ws("h3_amax") : nullptr, stream));
     else
-      RV_TRY(rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
+      RV_K(2, rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
                                   eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
     if (p->fr_hop) {
       if (p->fp8 && !latent_fused)
-        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       else if (!latent_fused)
-        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
-      RV_TRY(rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
+      RV_K(3, rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
                                            (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
                                            p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
                                            mse_part, (float*)p->ws("db4p"), stream));
     } else if (p->fp8) {
       if (!latent_fused)
-        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
-      RV_TRY(rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
+      RV_K(3, rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
                                         x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     } else {
       if (!latent_fused)
-        RV_TRY(rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
-      RV_TRY(rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
+      RV_K(3, rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     }
   }
@@ -553,16 +618,23 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
     // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+    {
+      Range r(p->roctx, "rv:fc4-bwd");
+      RV_K(4, rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
                                     p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-    RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
-    // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
-    // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
-                                8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
-                                p->b.step_counter, 256 - n_gemm, stream));
-    RV_TRY(rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
-                         p->b.step_counter, stream));
+    }
+    {
+      Range r(p->roctx, "rv:rest-bwd");
+      RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
+      // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
+      // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
+      RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
+                                   8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+                                   p->b.step_counter, 256 - n_gemm, stream));
+    }
+    Range r(p->roctx, "rv:adam");
+    RV_K(8, rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
+                          p->b.step_counter, stream));
     return fp8_after_update(p, stream);
   }
   // ---- backward / finalize / Adam as an ordered list of steps, each enabled by the phase mask ----
@@ -641,6 +713,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     i = j;
   }
   if (adam & 0x101) RV_TRY(fp8_after_update(p, stream));   // fc1.weight or fc4.weight were updated
+#undef RV_K
 #undef RV_TRY
   return RV_OK;
 }
@@ -696,6 +769,7 @@ int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
     if (src) return src;
   }
   if (!p->ev_ready[0]) {
+    // (hipEventReleaseToDevice on the fork event was tried: no change in the ~6 us an event costs the compute stream)
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -713,15 +787,21 @@ int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
   return RV_OK;
 }
 
-// Schedule shared by both data-parallel modes (round 3: one-rank cost 255-262 -> see profiles/r03_ddp_one_rank.txt):
-//   * every cross-stream edge costs ~6 us on this runtime (a hipEventRecord on the compute stream is a bubble), so the
-//     step has ONE fork and ONE join: only fc4's bucket, ready after the paired fc4 backward, travels on the collective
-//     stream behind the rest of backward; the second bucket's collective (nothing is left to hide it behind) is issued
-//     on the compute stream itself, and so are the sharded mode's all-gathers;
-//   * collectives of one communicator are never in flight on two streams at once: the compute stream joins the
-//     collective stream (fc4's exchange done) before it issues its own;
-//   * in the all-reduce mode the fc1 weight-gradient launch keeps carrying an optimizer update on the CUs its GEMM
-//     leaves idle, as in the local step: Adam(fc4) from the reduced flat gradient.
+// All-reduce schedule (round 4; DESIGN.md section 5 has the timeline and the model it was sized against):
+//   * two buckets, fc4 | everything else, BOTH exchanged on the collective stream, in order (one communicator, one
+//     stream): fc4's forks off behind the paired fc4 backward and the compute stream never waits for it before the
+//     backward is complete -- the exchange has latent backward + heads backward + fc1's weight gradient (~55 us) to
+//     hide behind;
+//   * behind the backward the compute stream sums the second bucket's slabs, hands it to the collective stream, and runs
+//     Adam(fc4) from the reduced payload while that exchange is on the links -- the update of the step's largest tensor
+//     costs nothing and disturbs no GEMM; only Adam(fc1, heads, fc3) is left behind the last byte;
+//   * the cross-stream edges are device-side flags, not HIP events: an event costs the compute stream a ~5 us bubble
+//     per record and ~9 us from record to the dependent kernel on the other stream, a flag ~1.8 us per crossing
+//     (measured); two of the four edges are on the critical path;
+//   * cutting fc1's gradient into halves buys nothing once each collective pays its own start-up latency, and an early
+//     small bucket (heads + fc3) only delays the last one (modelled: tools/ddp_model.py).
+// The sharded schedule below keeps round 3's shape: fc4's whole bucket behind the fork, the second bucket's collectives
+// on the compute stream behind a join.
 
 // this rank's shard of a bucket [lo, hi) cut into shards of cnt: [own, own + n) with n clipped to the bucket's end
 static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) {
@@ -842,26 +922,63 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
-  RV_HIP(hipEventRecord(p->ev_ready[0], s0));              // the fork: fc4 (8.4 MB at C2) is summed over its slabs and
-  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));       // travels behind the rest of backward
-  RV_TRY(payload(8, 10, sc));
-  RV_TRY(reduce(0, 8, 10, sc));
-  RV_HIP(hipEventRecord(p->ev_done[0], sc));
-  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));        // the join: fc4's sum has arrived
-  const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-  if (!p->payload_bf16 && rv_wgrad_adam_fits(Hp, Sp, Bp, p->s_w1) && n_gemm <= 192) {
-    // dW1's launch carries Adam(fc4) from the reduced flat gradient on the CUs its GEMM leaves idle
-    RV_TRY(rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_flat + 8,
-                                2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, scale, p->b.step_counter, 256 - n_gemm, stream));
-  } else {
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-    RV_TRY(adam_bucket(8, 2));
+  {
+    Range r(p->roctx, "rv:fc4-bwd");
+    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
+                                 p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
   }
+  Range range_rest(p->roctx, "rv:rest-bwd+exchange+adam");
+  // Cross-stream edges: device-side flags (elementwise.hip, k_flag_set / k_flag_wait; ~1.8 us per crossing) when
+  // launching eagerly, HIP events (~9 us per crossing, ~5 us of bubble per record on the compute stream) under stream
+  // capture -- a captured graph needs the event edges to know the collective stream belongs to it -- or when
+  // RV_OPT_DDP_SIGNAL is 0.  Edge 0: fc4's slabs complete (s0 -> sc); 1: second payload complete (s0 -> sc);
+  // 2: fc4's exchange done (sc -> s0); 3: second exchange done (sc -> s0).  Edges 1 and 3 are on the critical path.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  RV_HIP(hipStreamIsCapturing(s0, &cap));
+  const bool flags = p->ddp_signal && cap == hipStreamCaptureStatusNone;
+  int* fl = (int*)p->ws("ddp_flags");
+  const int seq = flags ? ++p->ddp_seq : 0;
+  auto signal = [&](int edge, hipStream_t from, hipStream_t to) -> int {
+    // Edge 0 is an event even with flags on: its waiter would sit on the collective stream from the end of the previous
+    // step, spinning on one wave slot of one CU all through the forward and the paired fc4 backward -- and that kernel
+    // needs EVERY CU whole (256 workgroups, two 256-VGPR waves per SIMD): with one CU short it runs in two rounds
+    // (measured: 34 -> 60 us).  The other waiters start spinning late in the backward, beside kernels that leave room.
+    if (flags && edge != 0) {
+      RV_TRY(rv_flag_set(fl + edge, seq, (void*)from));
+      return rv_flag_wait(fl + edge, seq, fl + 8, (void*)to);
+    }
+    hipEvent_t e = edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2];
+    RV_HIP(hipEventRecord(e, from));
+    RV_HIP(hipStreamWaitEvent(to, e, 0));
+    return RV_OK;
+  };
+  // Edges whose consumer is enqueued later than the signal (the compute stream joins after more of its own work):
+  // the two halves of `signal`
+  auto post = [&](int edge, hipStream_t from) -> int {
+    if (flags) return rv_flag_set(fl + edge, seq, (void*)from);
+    RV_HIP(hipEventRecord(edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2], from));
+    return RV_OK;
+  };
+  auto await = [&](int edge, hipStream_t on) -> int {
+    if (flags) return rv_flag_wait(fl + edge, seq, fl + 8, (void*)on);
+    RV_HIP(hipStreamWaitEvent(on, edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2], 0));
+    return RV_OK;
+  };
+  RV_TRY(signal(0, s0, sc));                               // fork 1: fc4 (8.4 MB of gradient at C2) is summed over its
+  RV_TRY(payload(8, 10, sc));                              // slabs and travels behind ALL the rest of the backward
+  RV_TRY(reduce(0, 8, 10, sc));
+  RV_TRY(post(2, sc));
+  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
+  // dW1 runs WITHOUT optimizer riders here: at several ranks fc4's sum has not arrived when this launch starts (an 8.4 MB
+  // bucket needs 40-65 us on the links; the latent-sized backward in front of this launch lasts 25).
+  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(payload(0, 8, s0));                               // fc1, fc21, fc22, fc3: contiguous in the arena
-  RV_TRY(reduce(1, 0, 8, s0));                             // nothing left to hide it behind: on the caller's stream
+  RV_TRY(signal(1, s0, sc));                               // fork 2: the second exchange follows the first on the
+  RV_TRY(reduce(1, 0, 8, sc));                             // collective stream (one communicator, one stream, in order)
+  RV_TRY(post(3, sc));
+  RV_TRY(await(2, s0));                                    // fc4's sum has arrived (long ago, if the links keep up): its
+  RV_TRY(adam_bucket(8, 2));                               // update runs while the second exchange is on the links
+  RV_TRY(await(3, s0));                                    // the join
   RV_TRY(adam_bucket(0, 8));
   RV_TRY(fp8_after_update(p, stream));
 #undef RV_TRY

@@ -59,6 +59,14 @@ class GradSync:
         return 1.0 / self.world
 
 
+# Gradient payload of the all-reduce schedule when the caller does not choose.  Fixed a priori (round 4), not picked by
+# measurement: "bf16" -- each rank's fp32 slab sum is rounded to bf16 once, RCCL sums in bf16, Adam reads the bf16 sum.
+# Half the bytes of the one exchange nothing can hide (the last gradient of backward), which is what the 1 -> 8 GPU
+# scaling target is sized against.  The rounding is 2^-9 relative per element and rank, far below
+# the batch-to-batch noise of the gradient itself; the data-parallel identity holds to 5e-4 instead of 2e-5 and a
+# 20-step loss trajectory stays within 1e-4 of the fp32 payload's (tests/test_ddp_gpu.py).  "fp32" = the exact mean.
+DEFAULT_PAYLOAD = "bf16"
+
 ARENA_SLACK = 1024   # elements every flat arena extends past n_params (shards of 4-element multiples can overhang)
 
 
@@ -328,7 +336,18 @@ class RcclComm:
 _COMM_STREAMS = {}   # (device index, compute stream handle) -> (collective stream, us per ping-pong, candidates tried)
 
 
-def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0, bad_us=100.0):
+def _agree_max(value, device, group=None):
+    """MAX of a host float over the ranks of `group` (identity without a process group): every rank gets the same
+    answer, so a decision taken from it is taken by all ranks or by none."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0, bad_us=100.0, group=None):
     """A high-priority stream for the collectives whose cross-stream waits against `compute_stream` stay on the
     device.  The HIP runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); when two
     streams that wait on each other share one, the runtime resolves the waits on the host and every kernel behind
@@ -337,8 +356,14 @@ def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0, bad_us=100.0
     wait) between the compute stream and a candidate; a healthy pair takes ~15 us per round trip, an affected one
     >100.  Candidates are created one after the other (each lands on the next hardware queue) until one is healthy;
     the rejected ones are kept alive so that the mapping of the chosen one does not move.  Cached per compute stream.
+
     If even the best candidate takes `bad_us` or more per round trip the call raises instead of silently running a
-    step that is several times slower (RV_COMM_STREAM_ALLOW_SLOW=1 overrides)."""
+    step that is several times slower (RV_COMM_STREAM_ALLOW_SLOW=1 overrides).  With a process group the decision is
+    COLLECTIVE: the ranks agree on the worst rank's best round trip (one MAX all-reduce over torch.distributed), so
+    either every rank raises or none does -- a rank that raised alone would leave its peers inside the step's first
+    RCCL collective with nobody to talk to.  Every rank of `group` must therefore call this at the same point (the
+    engine does: NativeDdpRunner / the first step_ddp on a compute stream).  A rejected pick is not cached: a caller
+    that catches the error and calls again measures again and raises again."""
     key = (device.index, compute_stream.cuda_stream)
     if key in _COMM_STREAMS:
         return _COMM_STREAMS[key][0]
@@ -369,14 +394,20 @@ def pick_comm_stream(compute_stream, device, tries=8, good_us=45.0, bad_us=100.0
             best = (cand, us)
         if us < good_us:
             break
-    _COMM_STREAMS[key] = (best[0], best[1], tried)
-    if best[1] >= bad_us and os.environ.get("RV_COMM_STREAM_ALLOW_SLOW") != "1":
+    worst = _agree_max(best[1], device, group)       # the same number on every rank
+    if worst >= bad_us and os.environ.get("RV_COMM_STREAM_ALLOW_SLOW") != "1":
+        _REJECTED.append(tried)                      # keep the streams alive (the hardware-queue mapping must not move)
         from ._lib import RvError
-        raise RvError("pick_comm_stream: none of %d candidate streams is healthy against the compute stream (best round "
-                      "trip %.0f us, a healthy pair takes ~15): their cross-stream waits would be resolved on the host and "
-                      "every kernel of a data-parallel step would start ~50 us late.  Raise GPU_MAX_HW_QUEUES, or set "
-                      "RV_COMM_STREAM_ALLOW_SLOW=1 to run anyway." % (len(tried), best[1]))
+        raise RvError("pick_comm_stream: no healthy collective stream against the compute stream on at least one rank "
+                      "(this rank: best of %d candidates %.0f us per round trip; worst rank %.0f; a healthy pair takes "
+                      "~15): cross-stream waits would be resolved on the host and every kernel of a data-parallel step "
+                      "would start ~50 us late.  Raise GPU_MAX_HW_QUEUES, or set RV_COMM_STREAM_ALLOW_SLOW=1 to run "
+                      "anyway." % (len(tried), best[1], worst))
+    _COMM_STREAMS[key] = (best[0], best[1], tried)
     return best[0]
+
+
+_REJECTED = []
 
 
 def comm_stream_report():
@@ -388,17 +419,17 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False, payload="fp32", sharded=False, gather=None):
+    def __init__(self, engine, comm, stream, use_graph=False, payload=None, sharded=False, gather=None):
+        """payload (all-reduce schedule): "bf16" (default, `DEFAULT_PAYLOAD`) or "fp32"."""
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
         self.sharded = bool(sharded)
         if stream is not None:
-            engine._pick_comm_stream(stream)    # before any capture: the choice times a few launches
-        engine.attach_comm(comm, sharded=self.sharded, gather=gather)
+            # before any collective of the step and before any capture: the choice times a few launches and is
+            # agreed between the ranks (pick_comm_stream)
+            engine._pick_comm_stream(stream)
+        engine.attach_comm(comm, sharded=self.sharded, gather=gather, payload=payload)
         self._graphs = {}
-        if not self.sharded:
-            self.set_payload(payload)
-        else:
-            self.payload = "fp32"
+        self.payload = "fp32" if self.sharded else engine.ddp_payload
 
     def set_payload(self, payload):
         """"fp32" or "bf16" gradient exchange (captured graphs are dropped: the payload is baked in)."""

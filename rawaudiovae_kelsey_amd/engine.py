@@ -139,6 +139,11 @@ class TrainEngine:
         launches (`rv_plan_set_option`, RV_OPT_LATENT_FUSED)."""
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_FUSED, int(bool(enable)))
 
+    def set_roctx(self, enable):
+        """roctx ranges (rocprofv3 --marker-trace) around the phases of every step this engine enqueues
+        (`rv_plan_set_option`, RV_OPT_ROCTX); raises when no roctx library can be loaded."""
+        lib().rv_plan_set_option(self._plan, _lib.OPT_ROCTX, int(bool(enable)))
+
     def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
         """Write entries of the fp8 state block (include/rawvae_hip.h, RV_OPT_FP8).  Weight scales are
         normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""
@@ -160,8 +165,15 @@ class TrainEngine:
         (world - 1) / world of the arena."""
         owner = self._shared.get("bf16_gather_engine")
         if owner is not None:
+            # the gather is torch.distributed collectives plus arena copies: they must run ON `stream`, behind the
+            # previous step's update / all-gather there (with torch's current stream elsewhere nothing would order
+            # them), and never inside a hipGraph capture (a host collective cannot be captured)
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.RvError("refresh_shadows: the fp32 masters must be gathered from their owner ranks first, which "
+                                   "cannot happen during a hipGraph capture; step this engine once before capturing")
             from . import ddp
-            ddp.gather_sharded_params(owner)
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+                ddp.gather_sharded_params(owner)
         if self.fp8:
             with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
                 st = self.buffer("fp8_state", torch.float32, (-1,))[:16]
@@ -241,7 +253,7 @@ class TrainEngine:
             self._shadow_version = self._shared["version"]
             _ops_invalidate()
 
-    def attach_comm(self, comm, sharded=False, gather=None):
+    def attach_comm(self, comm, sharded=False, gather=None, payload=None):
         """Data-parallel mode with the collectives issued by the library itself: `comm` is a `ddp.RcclComm`
         (RCCL communicator + the addresses of its collectives).  sharded: optimizer state and update sharded
         over the ranks (reduce-scatter gradients, Adam on the own shard, all-gather parameters) instead of an
@@ -249,7 +261,8 @@ class TrainEngine:
         the fp8 forward) all-gathers a 16-bit message -- bf16 of the updated weights plus the biases in fp32,
         half the bytes; every rank's operand shadows and biases are bit-identical to the "fp32" route, but fp32
         weight masters are then current on their owner rank only (`ddp.gather_sharded_params` before a
-        checkpoint); "fp32" all-gathers the fp32 parameters."""
+        checkpoint); "fp32" all-gathers the fp32 parameters.  payload (all-reduce schedule only): "bf16" (the
+        default, `ddp.DEFAULT_PAYLOAD`: half the bytes on the links) or "fp32" (the exact mean) -- `set_ddp_payload`."""
         if sharded:
             from .ddp import ShardPlan
             self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
@@ -282,6 +295,12 @@ class TrainEngine:
                                                 allreduce=comm.allreduce_addr, comm_stream=self._comm_stream_ptr())
         lib().rv_plan_attach_comm(self._plan, C.byref(d))
         self._comm = comm   # keep the communicator alive as long as the plan can use it
+        # cross-stream edges of the all-reduce schedule: device-side flags (default) or HIP events (RV_DDP_SIGNAL=event)
+        lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 0 if os.environ.get("RV_DDP_SIGNAL") == "event" else 1)
+        self.ddp_payload = "fp32"
+        if not sharded:
+            from .ddp import DEFAULT_PAYLOAD
+            self.set_ddp_payload(payload or DEFAULT_PAYLOAD)
 
     def _comm_stream_ptr(self):
         st = getattr(self, "_comm_stream", None)
@@ -296,6 +315,11 @@ class TrainEngine:
             setattr(d, k, v)
         lib().rv_plan_attach_comm(self._plan, C.byref(d))
 
+    @staticmethod
+    def ddp_payload_default():
+        from .ddp import DEFAULT_PAYLOAD
+        return DEFAULT_PAYLOAD
+
     def set_ddp_payload(self, payload):
         """Gradient all-reduce payload of `step_ddp`: "fp32" (default; exact mean of the ranks' fp32
         gradients) or "bf16" (half the bytes: each rank's summed gradient is rounded to bf16 before the
@@ -304,10 +328,11 @@ class TrainEngine:
             raise _lib.RvError("set_ddp_payload: %r (expected 'fp32' or 'bf16')" % (payload,))
         if payload == "bf16":
             if getattr(self, "_grad_bf16", None) is None:
-                self._grad_bf16 = torch.empty(self.param.numel(), dtype=torch.bfloat16, device=self.param.device)
+                self._grad_bf16 = torch.zeros(self.param.numel(), dtype=torch.bfloat16, device=self.param.device)
             self._reattach(grad_bf16=self._grad_bf16.data_ptr())
         else:
             self._reattach(grad_bf16=None)
+        self.ddp_payload = payload
 
     def step_ddp(self, x, eps=None, recon_out=None, stream=None):
         """One whole data-parallel training step in one host call (`rv_plan_step_ddp`): every rank
@@ -373,7 +398,23 @@ class TrainEngine:
 
     def steps_done(self):
         """Number of steps started on the device (reads the device counter; synchronises)."""
-        return int(self.step_counter.item())
+        n = int(self.step_counter.item())
+        self.check_ddp_signals()
+        return n
+
+    def check_ddp_signals(self):
+        """The data-parallel step's device-side flag waits are bounded (100 ms); one that ran out left its consumer
+        running on incomplete data.  Raises if any did since the engine was created (include/rawvae_hip.h,
+        RV_OPT_DDP_SIGNAL).  Called wherever the host reads results back anyway."""
+        if getattr(self, "_comm", None) is None:
+            return
+        fl = getattr(self, "_ddp_flags", None)
+        if fl is None:
+            fl = self._ddp_flags = self.buffer("ddp_flags", torch.int32, (-1,))
+        n = int(fl[8].item())
+        if n:
+            raise _lib.RvError("data-parallel step: %d cross-stream flag wait(s) timed out -- the steps since the last check "
+                               "ran on incomplete gradients; their results are invalid (RV_DDP_SIGNAL=event selects HIP events)" % n)
 
     def last_loss(self):
         """(total, mse, kld) of the most recent step; synchronises."""

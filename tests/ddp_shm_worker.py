@@ -1,0 +1,135 @@
+"""Worker of tests/test_ddp_gpu.py::test_native_ddp_step_two_processes_one_gpu (one process per rank, all on ONE GPU).
+
+`rv_plan_step_ddp` -- the library-driven data-parallel step -- runs here with world > 1 and rank > 0, which RCCL cannot
+do on a one-GPU box (it refuses two ranks on one device).  The collectives are the functional stand-ins of
+tools/fake_collective.hip (`shm_*`: same C signatures as ncclAllReduce / ncclReduceScatter / ncclAllGather, a real
+exchange through shared memory and the host), so everything around them is the product path: bucket boundaries, the
+1/world mean, the bf16 payload, shard ownership of rank > 0, the 16-bit parameter message, fork / join ordering.
+
+Checked per mode, after 3 steps from the same weights on per-rank batches:
+  * every rank ends with identical parameters and operand shadows;
+  * they equal the torch.distributed path's (ddp.DdpRunner over gloo: six host calls and three all-reduces per step --
+    the route that HAS run on several ranks before), bit for bit where the arithmetic is the same (fp32 payload at
+    world 2: a + b is one rounding in any order; sharded Adam = full Adam by construction), within a fraction of lr
+    for the bf16 payload.
+Prints DDP_SHM_OK on rank 0.
+"""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from rawaudiovae_kelsey_amd import ddp  # noqa: E402
+from rawaudiovae_kelsey_amd.engine import TrainEngine  # noqa: E402
+from rawaudiovae_kelsey_amd.synth import make_frames, make_params  # noqa: E402
+
+
+class ShmComm:
+    def __init__(self, lib, name, world, rank, cap):
+        lib.shm_comm_create.restype = C.c_void_p
+        lib.shm_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+        lib.shm_comm_destroy.argtypes = [C.c_void_p]
+        h = lib.shm_comm_create(name.encode(), world, rank, cap)
+        if not h:
+            raise RuntimeError("shm_comm_create failed")
+        self._lib, self.handle, self.world, self.rank = lib, C.c_void_p(h), world, rank
+        self.allreduce_addr = C.cast(lib.shm_allreduce, C.c_void_p)
+        self.reduce_scatter_addr = C.cast(lib.shm_reduce_scatter, C.c_void_p)
+        self.all_gather_addr = C.cast(lib.shm_all_gather, C.c_void_p)
+
+    def destroy(self):
+        self._lib.shm_comm_destroy(self.handle)
+
+
+def agree(flag):
+    """MIN over ranks of a 0/1 flag (gloo, CPU): a failed check on one rank fails every rank, before the next collective."""
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def same_on_all_ranks(*tensors):
+    chk = torch.stack([t.double().sum() for t in tensors] + [t.double().abs().sum() for t in tensors]).cpu()
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = C.CDLL(os.path.join(REPO, "tools", "libfakecoll.so"))
+    shapes = [(256, 512, 16, 128), (1024, 2048, 64, 4096)] if os.environ.get("RV_SHM_C2", "1") == "1" else [(256, 512, 16, 128)]
+    LR = 1e-4
+    failures = []
+    for (S, H, L, B) in shapes:
+        n_params = H * S + H + 2 * (L * H + L) + H * L + H + S * H + S
+        comm = ShmComm(lib, "/rv_shm_%s_%d" % (os.environ.get("MASTER_PORT", "0"), S), world, rank, (n_params + 8192) * 4)
+        xs = [torch.from_numpy(make_frames(B, S, 50 + 10 * rank + i)).to(dev) for i in range(3)]
+        st = torch.cuda.Stream(device=dev)
+
+        def fresh():
+            e = TrainEngine(S, H, L, B, device=dev, kl_beta=1e-4, lr=LR, seed=7, ring=16)
+            e.load_params(make_params(S, H, L, 0))
+            return e
+        # the reference route: phases + torch.distributed all-reduces (gloo carries them through the host)
+        eb = fresh()
+        rb = ddp.DdpRunner(eb, ddp.GradSync(eb.grad, ddp.engine_buckets(eb)), st, use_graphs=False)
+        assert rb.sync.active and rb.sync.world == world
+        with torch.cuda.stream(st):
+            for x in xs:
+                rb.step(x)
+        torch.cuda.synchronize()
+        if not agree(same_on_all_ranks(eb.param)):
+            failures.append("%r torch.distributed route: replicas differ" % ((S, H, L, B),))
+        modes = (("allreduce", "fp32", None), ("allreduce", "bf16", None), ("sharded", None, "fp32"), ("sharded", None, "bf16"))
+        for mode, payload, gather in modes:
+            ea = fresh()
+            ra = ddp.NativeDdpRunner(ea, comm, st, sharded=mode == "sharded", payload=payload, gather=gather)
+            with torch.cuda.stream(st):
+                for x in xs:
+                    ra.step(x)
+            torch.cuda.synchronize()
+            if mode == "sharded" and gather == "bf16":
+                ddp.gather_sharded_params(ea)   # fp32 weight masters live on their owner ranks
+            tag = "%r %s payload=%s gather=%s" % ((S, H, L, B), mode, payload, gather)
+            shadows = [ea.buffer(n, torch.bfloat16, (-1,)) for n in ("W1b", "Whb", "W3b", "W4b")]
+            if not agree(same_on_all_ranks(ea.param, *shadows)):
+                failures.append(tag + ": replicas differ")
+            d = (ea.param - eb.param).abs()
+            if payload == "bf16":
+                ok = float(d.mean()) < 0.05 * LR and float(d.max()) <= 2.1 * 3 * LR
+            else:
+                ok = bool(torch.equal(ea.param, eb.param))
+                if ok and not (mode == "sharded"):   # sharded: moments are valid on their owner rank only
+                    ok = bool(torch.equal(ea.exp_avg, eb.exp_avg)) and bool(torch.equal(ea.exp_avg_sq, eb.exp_avg_sq))
+            for a, b in zip(ea.losses(3), eb.losses(3)):
+                ok = ok and abs(a - b) <= 1e-4 * abs(b)
+            if not agree(ok):
+                failures.append(tag + ": differs from the torch.distributed route (rank %d: mean %.3g max %.3g, lr %.1g)"
+                                % (rank, float(d.mean()), float(d.max()), LR))
+            del ra, ea
+        dist.barrier()
+        comm.destroy()
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.cuda.synchronize()
+    if failures:
+        print("DDP_SHM_FAILED rank %d:\n  " % rank + "\n  ".join(failures), flush=True)
+    elif rank == 0:
+        print("DDP_SHM_OK", flush=True)
+    # leave without running interpreter teardown: what is being tested has been decided above, and the order in which
+    # torch, the HIP runtime and ctypes-loaded libraries unload at exit is not this test's subject
+    os._exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,30 @@ def test_two_rank_bench_flow_keeps_replicas_identical():
     assert "cpu_baseline" not in out          # reported at N=1 only
 
 
+def test_native_ddp_step_two_processes_one_gpu():
+    """`rv_plan_step_ddp` with world = 2 (rank 0 AND rank 1), two processes on this one GPU: RCCL refuses two ranks on a
+    device, so the collectives are the functional stand-ins of tools/fake_collective.hip (`shm_*`, RCCL's signatures, a
+    real exchange through shared memory) -- everything else is the product path.  All four exchange modes (all-reduce
+    with fp32 / bf16 payload, sharded optimizer with fp32 all-gather / 16-bit parameter message), small shape and C2:
+    replicas identical, and equal to the torch.distributed route (tests/ddp_shm_worker.py)."""
+    so = os.path.join(REPO, "tools", "libfakecoll.so")
+    assert os.path.exists(so), "tools/libfakecoll.so missing: __graft_entry__.build() compiles it"
+    env = dict(os.environ, RV_COMM_STREAM_ALLOW_SLOW="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(REPO, "tests", "ddp_shm_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    if r.returncode != 0 or "DDP_SHM_OK" not in r.stdout:
+        keep = [l for l in (r.stdout + "\n" + r.stderr).splitlines() if l.strip() and "amdgpu.ids" not in l and "hostname of the client" not in l]
+        print("\n".join(keep[-80:]))
+        try:   # (gpurun merges gpurun_out/ back: the full output survives the box)
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(REPO, "gpurun_out", "ddp_shm_fail.log"), "w") as f:
+                f.write(r.stdout + "\n==== stderr ====\n" + r.stderr)
+        except OSError:
+            pass
+    assert r.returncode == 0 and "DDP_SHM_OK" in r.stdout
+
+
 def test_native_rccl_step_one_rank_equals_local_step():
     """`rv_plan_step_ddp` (the library issues the RCCL all-reduces itself) with a real one-rank RCCL
     communicator: eager and as a replayed hipGraph it must produce exactly the parameters of the plain
@@ -56,7 +80,8 @@ with torch.cuda.stream(st):
 st.synchronize()
 comm = ddp.RcclComm()
 comm.self_test(torch.device("cuda", 0))
-eager = fresh(); eager.attach_comm(comm)
+eager = fresh(); eager.attach_comm(comm, payload="fp32")
+assert ddp.DEFAULT_PAYLOAD == "bf16" and TrainEngine.ddp_payload_default() == "bf16"
 with torch.cuda.stream(st):
     for _ in range(4):
         eager.step_ddp(x, stream=st)
@@ -77,7 +102,7 @@ with torch.cuda.stream(st):
         ref.step(x, stream=st)
 st.synchronize()
 gr = fresh()
-run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True)
+run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True, payload="fp32")
 with torch.cuda.stream(st):
     for _ in range(4):
         run.step(x)
@@ -87,7 +112,8 @@ assert gr.steps_done() == 4
 # bf16 payload: the summed gradient is rounded to bf16 before the exchange; Adam's first steps move every
 # weight by ~lr whatever the gradient's magnitude, so the parameters stay within a fraction of lr of the
 # fp32-payload run (sign flips of near-zero gradients aside) and the loss trajectory within 1e-4
-bf = fresh(); bf.attach_comm(comm); bf.set_ddp_payload("bf16")
+bf = fresh(); bf.attach_comm(comm)      # the default payload
+assert bf.ddp_payload == "bf16"
 with torch.cuda.stream(st):
     for _ in range(4):
         bf.step_ddp(x, stream=st)
