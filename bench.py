@@ -708,11 +708,13 @@ def main():
             torch.cuda.synchronize()
             comm.destroy()
         dist.destroy_process_group()
-        # every rank's verdict is in `code` and the line is printed: leave without interpreter teardown (the unload order
-        # of torch, RCCL, the HIP runtime and ctypes-loaded libraries at exit must not decide a rank's exit status)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(code)
+        if world > 1:
+            # every rank's verdict is in `code` and the line is printed: leave without interpreter teardown (the unload
+            # order of torch, RCCL, the HIP runtime and ctypes-loaded libraries at exit must not decide a rank's exit
+            # status).  Not in the one-rank rehearsal: a profiler wrapped around it writes its output at exit.
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(code)
     if code:
         sys.exit(code)
 

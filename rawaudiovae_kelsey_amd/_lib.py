@@ -39,7 +39,7 @@ class CommDesc(C.Structure):
                 ("msg_send", c_void_p), ("msg_recv", c_void_p), ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
 
 
-OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL = 0, 1, 2, 3, 4
+OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE = 0, 1, 2, 3, 4, 5
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4

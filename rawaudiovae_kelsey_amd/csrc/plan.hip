@@ -116,6 +116,8 @@ struct rv_plan {
   int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax"
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
+  int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
+  int ddp_w1_wide = 1;
   int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
   unsigned skip = 0;           // rv_plan_diag_skip (include/rawvae_hip_diag.h): launches of the full step left out
   int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (RV_OPT_SLAB_DTYPE)
@@ -230,11 +232,18 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("dz_slabs", (long)p->s_dz * Bp * Lp * 4);
   p->add("dmulv", Bp * L2p * 2);
   p->add("dP1", Bp * Hp * 2);
-  p->add("dW1", (long)p->s_w1 * Hp * Sp * 4);
+  // data-parallel step: fc1's weight gradient has no optimizer riders beside it (the reduced gradients they would need
+  // have not arrived), so it runs on ALL CUs with twice the K splits where the extents allow (256 blocks of 256 x 256
+  // with an even number of >= 2 K tiles each)
+  p->s_w1_ddp = p->s_w1;
+  if (Hp % 256 == 0 && Sp % 256 == 0 && (Hp / 256) * (Sp / 256) * 2 * p->s_w1 <= 256 && (Bp / 64) % (2 * p->s_w1) == 0 &&
+      (Bp / 64) / (2 * p->s_w1) >= 2 && ((Bp / 64) / (2 * p->s_w1)) % 2 == 0 && 2 * p->s_w1 <= 8)
+    p->s_w1_ddp = 2 * p->s_w1;
+  p->add("dW1", (long)p->s_w1_ddp * Hp * Sp * 4);
   p->add("dWh", (long)(p->s_wh_gen > p->hb_groups ? p->s_wh_gen : p->hb_groups) * L2p * Hp * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
-  p->add("dW1_us", (long)p->s_w1 * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
+  p->add("dW1_us", (long)p->s_w1_ddp * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
   p->add("dW4_us", (long)p->s_w4 * (Sp / 32) * (Hp / 32) * 4);
   p->add("db1p", (long)(p->n_mt1_gen > p->hb_groups ? p->n_mt1_gen : p->hb_groups) * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
@@ -339,6 +348,7 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
     case RV_OPT_FP8: return plan_set_fp8(p, value);
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
     case RV_OPT_DDP_SIGNAL: p->ddp_signal = value ? 1 : 0; return RV_OK;
+    case RV_OPT_DDP_W1_WIDE: p->ddp_w1_wide = value ? 1 : 0; return RV_OK;
     case RV_OPT_ROCTX:
       RV_REQUIRE(!value || roctx_load(), RV_ERR_UNSUPPORTED, "rv_plan_set_option: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) could be loaded");
       p->roctx = value ? 1 : 0;
@@ -896,9 +906,14 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
   // Bucket = tensors [t0, t1) of the flat arena: slabs -> flat payload (caller's stream), then the SUM over ranks
   // on stream `on`
+  // fc1's weight gradient on all CUs (see rv_plan_create): its descriptor for the payload kernel carries the split count
+  const int s_w1 = (p->ddp_w1_wide && w1_tile(p) == RV_TILE_256x256) ? p->s_w1_ddp : p->s_w1;
+  rv_param_desc dd[10];
+  for (int i = 0; i < 10; ++i) dd[i] = p->d_slab[i];
+  dd[0].grad_splits = s_w1;
   auto payload = [&](int t0, int t1, hipStream_t on) -> int {
-    if (p->payload_bf16) return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->grad_bf16, 1, (void*)on);
-    return rv_grad_finalize(p->d_slab + t0, t1 - t0, p->b.grad, 0, (void*)on);
+    if (p->payload_bf16) return rv_grad_finalize(dd + t0, t1 - t0, p->grad_bf16, 1, (void*)on);
+    return rv_grad_finalize(dd + t0, t1 - t0, p->b.grad, 0, (void*)on);
   };
   auto reduce = [&](int b, int t0, int t1, hipStream_t on) -> int {
     const long lo = p->off[t0], hi = t1 < 10 ? p->off[t1] : p->n_params;
@@ -971,7 +986,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
   // dW1 runs WITHOUT optimizer riders here: at several ranks fc4's sum has not arrived when this launch starts (an 8.4 MB
   // bucket needs 40-65 us on the links; the latent-sized backward in front of this launch lasts 25).
-  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   RV_TRY(payload(0, 8, s0));                               // fc1, fc21, fc22, fc3: contiguous in the arena
   RV_TRY(signal(1, s0, sc));                               // fork 2: the second exchange follows the first on the
   RV_TRY(reduce(1, 0, 8, sc));                             // collective stream (one communicator, one stream, in order)

@@ -80,7 +80,7 @@ with torch.cuda.stream(st):
 st.synchronize()
 comm = ddp.RcclComm()
 comm.self_test(torch.device("cuda", 0))
-eager = fresh(); eager.attach_comm(comm, payload="fp32")
+eager = fresh(); eager.attach_comm(comm, payload="fp32"); eager.set_ddp_w1_wide(False)   # the local step's arithmetic
 assert ddp.DEFAULT_PAYLOAD == "bf16" and TrainEngine.ddp_payload_default() == "bf16"
 with torch.cuda.stream(st):
     for _ in range(4):
@@ -102,7 +102,7 @@ with torch.cuda.stream(st):
         ref.step(x, stream=st)
 st.synchronize()
 gr = fresh()
-run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True, payload="fp32")
+run = ddp.NativeDdpRunner(gr, comm, st, use_graph=True, payload="fp32"); gr.set_ddp_w1_wide(False)
 with torch.cuda.stream(st):
     for _ in range(4):
         run.step(x)
@@ -112,7 +112,7 @@ assert gr.steps_done() == 4
 # bf16 payload: the summed gradient is rounded to bf16 before the exchange; Adam's first steps move every
 # weight by ~lr whatever the gradient's magnitude, so the parameters stay within a fraction of lr of the
 # fp32-payload run (sign flips of near-zero gradients aside) and the loss trajectory within 1e-4
-bf = fresh(); bf.attach_comm(comm)      # the default payload
+bf = fresh(); bf.attach_comm(comm)      # the defaults: bf16 payload, fc1's weight gradient on all CUs
 assert bf.ddp_payload == "bf16"
 with torch.cuda.stream(st):
     for _ in range(4):
