@@ -101,11 +101,13 @@ __device__ __forceinline__ void adam_update(float& m, float& v, float& w, const 
   w = w - step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 
-// Bias corrections of step t = *step_counter: (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)), through the hardware exp2.
+// Bias corrections of step t = *step_counter: (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)).  1 - beta^t = -expm1(t ln beta):
+// the direct form 1 - exp2(t log2 beta) cancels catastrophically for small t (1 - 0.999 carries 6e-8 / 1e-3 = 6e-5 of
+// relative error in fp32, which went straight into the first updates: torch computes these in double precision).
 __device__ __forceinline__ void adam_step_consts(const long long* step_counter, float lr, float* step_size, float* inv_bc2s) {
   const float tt = (float)(*step_counter);
-  const float bc1 = 1.0f - exp2f(tt * -0.15200309344504997f);          // log2(0.9)
-  const float bc2 = 1.0f - exp2f(tt * -0.0014434168696687f);           // log2(0.999)
+  const float bc1 = -expm1f(tt * -0.10536051565782628f);               // ln(0.9)
+  const float bc2 = -expm1f(tt * -0.0010005003335835344f);             // ln(0.999)
   *step_size = lr / bc1;
   *inv_bc2s = 1.0f / sqrtf(bc2);
 }

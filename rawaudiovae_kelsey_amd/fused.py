@@ -34,8 +34,15 @@ _HOLDERS = weakref.WeakKeyDictionary()   # module -> _Holder; off the module so 
 
 
 def _params(module):
-    return (module.fc1.weight, module.fc1.bias, module.fc21.weight, module.fc21.bias, module.fc22.weight,
-            module.fc22.bias, module.fc3.weight, module.fc3.bias, module.fc4.weight, module.fc4.bias)
+    # (through the modules' own dictionaries: `module.fc1.weight` costs two nn.Module.__getattr__ fallbacks per
+    # parameter, ~20 us per call for the ten -- this runs on every forward of the drop-in loop)
+    mods = module._modules
+    out = []
+    for name in ("fc1", "fc21", "fc22", "fc3", "fc4"):
+        pd = mods[name]._parameters
+        out.append(pd["weight"])
+        out.append(pd["bias"])
+    return tuple(out)
 
 
 class _Holder:
@@ -43,6 +50,9 @@ class _Holder:
         self.engines = collections.OrderedDict()   # batch size -> TrainEngine (all share the first one's arenas)
         self.ptrs = None
         self.versions = None
+        self.last_params = None     # the Parameters and the engine of the most recent fused forward (optim_hook.py)
+        self.last_engine = None
+        self.adam_cache = None
 
     def engine(self, module, B, params):
         eng = self.engines.get(B)
@@ -64,11 +74,14 @@ class _Holder:
             eng.adopt(module)
             self.ptrs = tuple(p.data_ptr() for p in params)
             self.versions = None
+            from . import optim_hook    # torch.optim.Adam.step() on these parameters as one fused launch
+            optim_hook.register(module, params)
         from . import ops
         vers = tuple(p._version for p in params) + (ops._EPOCH[0],)
         if vers != self.versions:       # optimizer.step / load_state_dict / any in-place write / ops.invalidate_shadows()
             eng.params_changed()
             self.versions = vers
+        self.last_params, self.last_engine = params, eng
         return eng
 
 

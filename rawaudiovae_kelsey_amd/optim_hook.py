@@ -1,0 +1,203 @@
+"""`torch.optim.Adam.step()` on a VAE's parameters as ONE fused launch.
+
+The reference's training loop ends with `optimizer.step()` on `optim.Adam(model.parameters(), lr=...)`
+(train.py:163,193).  Stock `torch.optim.Adam` runs its default "foreach" implementation: ~12 multi-tensor kernels over
+the ten parameters, their two moment tensors and their gradients (~100 us of GPU time at C2) enqueued by ~235 us of
+Python -- the largest single item of the drop-in loop's host time (profiles/r04_api_prof.txt).  The fused engine
+already has the same update as one kernel that also refreshes the bf16 operand shadows (`rv_adam_multi`).
+
+This module lets the UNCHANGED loop use it: a global optimizer step pre-hook (torch.optim.optimizer.
+register_optimizer_step_pre_hook) recognises a param group of a plain `torch.optim.Adam` that holds all ten parameters
+of a `rawvae.model.VAE` whose forward ran through the one-node path (fused.py: the Parameters are views of one fp32
+arena), with hyper-parameters `rv_adam_multi` implements (betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad /
+maximize / capturable / differentiable -- the reference's construction), performs the update with ONE launch, and hides
+those parameters' gradients from the stock step for the duration of the call (a parameter without a gradient is
+skipped by torch.optim), restoring them in the post-hook.  Everything else -- other optimizers, other parameter
+groups, other hyper-parameters, closures -- is left to PyTorch untouched.
+
+What stays PyTorch's: `optimizer.state[p]` keeps torch's layout (`step`, `exp_avg`, `exp_avg_sq`), so
+`optimizer.state_dict()` / `load_state_dict()` and the reference's checkpoints (train.py:208-212) are unchanged; the
+moment tensors ARE views of the engine's moment arenas (state loaded from a checkpoint is copied into them on the
+next step).  The update differs from torch's by the hardware sqrt / reciprocal (~3e-7 relative; tests/test_model_gpu.py).
+`rawaudiovae_kelsey_amd.optim_hook.enabled = False` (or RV_OPTIM_HOOK=0) switches it off.
+"""
+import ctypes as C
+import os
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, stream_ptr
+
+enabled = os.environ.get("RV_OPTIM_HOOK", "1") != "0"
+stats = {"fused_steps": 0, "declined": {}}   # how often the hook took a step over / why it left one to PyTorch
+_installed = False
+_OWNER = {}            # id(Parameter) -> (weakref(Parameter), weakref(module))
+_STASH = weakref.WeakKeyDictionary()   # optimizer -> [(param, grad), ...] hidden from the stock step
+_T_RING = {}           # device -> int64 tensor [1, 2, 3, ...]: the step number is passed as a pointer into it
+
+
+def register(module, params):
+    """Called by fused.py when a module's Parameters have been re-pointed at an engine's arena."""
+    for p in params:
+        _OWNER[id(p)] = (weakref.ref(p), weakref.ref(module))
+    install()
+
+
+def install():
+    global _installed
+    if _installed:
+        return
+    from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+    register_optimizer_step_pre_hook(_pre_step)
+    register_optimizer_step_post_hook(_post_step)
+    _installed = True
+
+
+def _t_ptr(dev, t):
+    ring = _T_RING.get(dev)
+    if ring is None or t > ring.numel():
+        n = 1 << 16
+        while n < t:
+            n <<= 1
+        ring = _T_RING[dev] = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
+    return ring.data_ptr() + 8 * (t - 1)
+
+
+def _eligible(opt, group):
+    if type(opt) is not torch.optim.Adam:
+        return False
+    if tuple(group.get("betas", ())) != (0.9, 0.999) or group.get("eps") != 1e-8 or group.get("weight_decay", 0) != 0:
+        return False
+    for flag in ("amsgrad", "maximize", "capturable", "differentiable", "fused", "decoupled_weight_decay"):
+        if group.get(flag):
+            return False
+    return True
+
+
+def _decline(why):
+    stats["declined"][why] = stats["declined"].get(why, 0) + 1
+
+
+_PLANS = weakref.WeakKeyDictionary()   # optimizer -> (signature of its groups, [(group index, weakref(module)), ...])
+
+
+def _discover(opt):
+    """Which (param group, VAE module) pairs of this optimizer the hook may take over: the group holds ALL ten
+    parameters of a module whose Parameters live in an engine's arena.  Re-derived when the groups change."""
+    from . import fused
+    found = []
+    for gi, group in enumerate(opt.param_groups):
+        ids = {id(q) for q in group["params"]}
+        seen = set()
+        for p in group["params"]:
+            own = _OWNER.get(id(p))
+            if own is None or own[0]() is not p:
+                continue
+            module = own[1]()
+            if module is None or id(module) in seen:
+                continue
+            seen.add(id(module))
+            if any(id(q) not in ids for q in fused._params(module)):
+                _decline("group holds only part of the model")   # PyTorch's step
+                continue
+            found.append((gi, weakref.ref(module)))
+    return found
+
+
+def _pre_step(opt, args, kwargs):
+    # (`args` is the step call's positional arguments INCLUDING the optimizer itself)
+    if not enabled or len(args) > 1 or kwargs.get("closure") is not None or not _OWNER:
+        return None
+    from . import fused, ops
+    groups = opt.param_groups
+    sig = (len(_OWNER),) + tuple(len(g["params"]) for g in groups)
+    plans = _PLANS.get(opt)
+    if plans is None or plans[0] != sig:
+        plans = _PLANS[opt] = (sig, _discover(opt))
+    for gi, mref in plans[1]:
+        group, module = groups[gi], mref()
+        if module is None:
+            continue
+        if not _eligible(opt, group):
+            _decline("optimizer type or hyper-parameters")
+            continue
+        holder = fused._HOLDERS.get(module)
+        params = None if holder is None else holder.last_params     # the tensors the last fused forward ran on
+        if params is None or not holder.engines:
+            _decline("no engine")
+            continue
+        eng = holder.last_engine
+        grads = [q.grad for q in params]
+        ok = True
+        for g in grads:
+            if g is None or g.dtype is not torch.float32 or not g.is_cuda or g.is_sparse or not g.is_contiguous():
+                ok = False
+                break
+        if not ok:
+            _decline("gradients missing / not dense fp32 on the device")
+            continue
+        _fused_adam(opt, group, holder, eng, params, grads)
+        stats["fused_steps"] += 1
+        _STASH.setdefault(opt, []).extend(zip(params, grads))
+        for q in params:
+            q.grad = None     # the stock step skips parameters without a gradient
+        # the kernel refreshed this engine's operand shadows; the per-layer Functions' caches (ops.py) are stale
+        ops.invalidate_shadows()
+        eng._shared["version"] += 1
+        eng._shadow_version = eng._shared["version"]
+        holder.versions = tuple([q._version for q in params]) + (ops._EPOCH[0],)
+    return None
+
+
+def _post_step(opt, args, kwargs):
+    stash = _STASH.pop(opt, None)
+    if stash:
+        for p, g in stash:
+            p.grad = g
+
+
+def _fused_adam(opt, group, holder, eng, params, grads):
+    from .engine import PARAM_NAMES
+    state = opt.state
+    cache = holder.adam_cache
+    if cache is None or cache["arena"] is not eng.exp_avg:
+        # moments: views of the engine's arenas (every engine of a holder shares them), in torch's state layout
+        cache = holder.adam_cache = {"arena": eng.exp_avg, "descs": {},
+                                     "m": [eng.view(eng.exp_avg, k) for k in PARAM_NAMES],
+                                     "v": [eng.view(eng.exp_avg_sq, k) for k in PARAM_NAMES]}
+    st0 = state[params[0]]
+    if st0.get("exp_avg") is not cache["m"][0] or state[params[9]].get("exp_avg_sq") is not cache["v"][9]:
+        # first step of this optimizer on these parameters, or state that a stock step / load_state_dict created
+        for i, p in enumerate(params):
+            st = state[p]
+            if len(st) == 0:
+                cache["m"][i].zero_()
+                cache["v"][i].zero_()
+                st["step"] = torch.tensor(0.0, dtype=torch.get_default_dtype())
+            else:
+                if st["exp_avg"] is not cache["m"][i]:
+                    cache["m"][i].copy_(st["exp_avg"])
+                if st["exp_avg_sq"] is not cache["v"][i]:
+                    cache["v"][i].copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"] = cache["m"][i], cache["v"][i]
+        steps = [float(state[p]["step"]) for p in params]
+        if min(steps) != max(steps):
+            raise _lib.RvError("optimizer state: the VAE's parameters are at different step counts (%r)" % (steps,))
+        st0 = state[params[0]]
+    t = int(float(st0["step"])) + 1
+    descs = cache["descs"].get(eng.B)
+    if descs is None:
+        descs = (_lib.ParamDesc * 10)(*eng.plan_descs())
+        for d in descs:            # gradient = one exact-shape tensor per parameter (what autograd left in .grad)
+            d.grad_ld, d.grad_split_stride, d.grad_splits = d.cols, 0, 1
+            d.grad_half, d.grad_unscale = 0, None
+        cache["descs"][eng.B] = descs
+    for i in range(10):
+        descs[i].grad_slabs = grads[i].data_ptr()
+    lr = group["lr"]
+    lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
+    lib().rv_adam_multi(descs, 10, ptr(eng.param), ptr(eng.exp_avg), ptr(eng.exp_avg_sq), None, None, lr, 1.0,
+                        _t_ptr(eng.device, t), stream_ptr())
+    torch._foreach_add_([state[p]["step"] for p in params], 1)

@@ -3,7 +3,9 @@
 through `TrainEngine.step_frames` on a synthetic 10-minute waveform resident in HBM (fresh shuffle every epoch, no
 cast kernel), printing the loss every `--every` steps and checking at the end that every parameter and both Adam
 moments are finite and that the loss went down.
-    python tools/soak.py [--steps 200000] [--every 20000]"""
+    python tools/soak.py [--steps 200000] [--every 20000] [--slab-dtype fp16|fp32]
+    python tools/soak.py --ab [--steps 300000]     three arms from the same weights on the same shuffles: fp16 slabs
+        (the default), fp32 slabs, and fp32 slabs with another eps seed (the run-to-run spread two arms may differ by)"""
 import argparse
 import os
 import sys
@@ -19,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200000)
     ap.add_argument("--every", type=int, default=20000)
+    ap.add_argument("--slab-dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--ab", action="store_true", help="fp16 slabs vs fp32 slabs vs fp32 slabs with another eps seed")
     args = ap.parse_args()
     import torch
     from rawaudiovae_kelsey_amd import data as D
@@ -30,32 +34,57 @@ def main():
     wave = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3300 * t * (1 + 0.1 * np.sin(2 * np.pi * 0.5 * t)))
             + 0.05 * np.random.default_rng(0).normal(size=t.size)).astype(np.float32)
     ds = D.DeviceAudio(np.clip(wave, -1, 1), S, 128)
-    eng = TrainEngine(S, H, L, B, kl_beta=1e-4, lr=1e-4, seed=1)
-    eng.load_params(make_params(S, H, L, 0))
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(0)
-    done, first, t0 = 0, None, time.perf_counter()
-    while done < args.steps:
-        for idx in ds.index_batches(B, shuffle=True, generator=gen):
-            if idx.numel() != B:
-                continue
-            eng.step_frames(ds, idx)
-            done += 1
-            if done == 1 or done % args.every == 0 or done == args.steps:
-                loss = eng.last_loss()[0]
-                first = loss if first is None else first
-                dt = time.perf_counter() - t0
-                print("step %7d  loss %.6f  (%.1f s, %.2f M frames/s so far)" % (done, loss, dt, done * B / dt / 1e6), flush=True)
-                if not np.isfinite(loss):
-                    raise SystemExit("loss is not finite")
-            if done >= args.steps:
-                break
-    torch.cuda.synchronize()
-    last = eng.last_loss()[0]
-    ok = all(bool(torch.isfinite(a).all()) for a in (eng.param, eng.exp_avg, eng.exp_avg_sq))
-    print("finite parameters and moments: %s; loss %.6f -> %.6f" % (ok, first, last))
-    if not ok or not last < first:
-        raise SystemExit("soak failed")
+    p0 = make_params(S, H, L, 0)
+
+    def run(slab_dtype, seed, tag):
+        eng = TrainEngine(S, H, L, B, kl_beta=1e-4, lr=1e-4, seed=seed, slab_dtype=slab_dtype)
+        eng.load_params(p0)
+        start = eng.param.clone()
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(0)                       # the same shuffles in every arm
+        done, curve, t0 = 0, [], time.perf_counter()
+        while done < args.steps:
+            for idx in ds.index_batches(B, shuffle=True, generator=gen):
+                if idx.numel() != B:
+                    continue
+                eng.step_frames(ds, idx)
+                done += 1
+                if done == 1 or done % args.every == 0 or done == args.steps:
+                    loss = float(np.mean(eng.losses(64))) if done >= 64 else eng.last_loss()[0]   # mean of the last 64 steps
+                    curve.append((done, loss))
+                    dt = time.perf_counter() - t0
+                    print("%s step %7d  loss %.6f  (%.1f s, %.2f M frames/s so far)" % (tag, done, loss, dt, done * B / dt / 1e6), flush=True)
+                    if not np.isfinite(loss):
+                        raise SystemExit("loss is not finite")
+                if done >= args.steps:
+                    break
+        torch.cuda.synchronize()
+        ok = all(bool(torch.isfinite(a).all()) for a in (eng.param, eng.exp_avg, eng.exp_avg_sq))
+        print("%s finite parameters and moments: %s; loss %.6f -> %.6f" % (tag, ok, curve[0][1], curve[-1][1]))
+        if not ok or not curve[-1][1] < curve[0][1]:
+            raise SystemExit("soak failed")
+        return curve, eng.param.clone(), start
+
+    if not args.ab:
+        run(args.slab_dtype, 1, "[%s slabs]" % args.slab_dtype)
+        return
+    ca, pa, start = run("fp16", 1, "[A fp16 slabs, eps seed 1]")
+    cb, pb, _ = run("fp32", 1, "[B fp32 slabs, eps seed 1]")
+    cc, pc, _ = run("fp32", 2, "[C fp32 slabs, eps seed 2]")
+    print()
+    print("loss (mean of the last 64 steps) at the same step counts; |A-B| is the effect of the slab element type, |B-C| what")
+    print("two runs differ by when only the eps draws change:")
+    print("%9s %10s %10s %10s %11s %11s" % ("step", "A fp16", "B fp32", "C fp32'", "|A-B|/B", "|B-C|/B"))
+    worst_ab = worst_bc = 0.0
+    for (n, a), (_, b), (_, c) in zip(ca, cb, cc):
+        print("%9d %10.6f %10.6f %10.6f %11.2e %11.2e" % (n, a, b, c, abs(a - b) / b, abs(b - c) / b))
+        if n > 1:
+            worst_ab, worst_bc = max(worst_ab, abs(a - b) / b), max(worst_bc, abs(b - c) / b)
+    trav = float((pb - start).norm())
+    print("final parameters: |A - B| / |B - start| = %.4f   |B - C| / |B - start| = %.4f   (|B - start| = %.3f)"
+          % (float((pa - pb).norm()) / trav, float((pb - pc).norm()) / trav, trav))
+    print("worst relative loss difference after step 1: slab type %.2e, eps seed %.2e -> %s"
+          % (worst_ab, worst_bc, "within run-to-run noise" if worst_ab <= 1.5 * worst_bc else "LARGER than run-to-run noise"))
 
 
 if __name__ == "__main__":

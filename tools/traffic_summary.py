@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """HBM-side bytes per launch of every kernel of the step from the two PMC passes of tools/pmc_round.sh
-(rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, CSV).  FETCH_SIZE (KiB) is doubled as MI355X_MICROARCH.md 'HBM'
-prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE (KiB) is taken as is.
-    python tools/traffic_summary.py gpurun_out/r02_fetch gpurun_out/r02_write profiles/r02_traffic.json"""
+(rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE runs of `bench.py --step-kernels-only`, CSV).  FETCH_SIZE
+(KiB) is doubled as MI355X_MICROARCH.md 'HBM' prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE
+(KiB) is taken as is.  `per_launch_bytes` is keyed by the launch index bench.py's `kernels` table uses.
+    python tools/traffic_summary.py <fetch pass dir> <write pass dir> <out.json>"""
 import collections
 import csv
 import glob
@@ -28,8 +29,15 @@ for k in sorted(set(fetch) | set(write)):
     rd, wr = 2.0 * fetch.get(k, 0.0) * 1024.0, write.get(k, 0.0) * 1024.0
     rows[k[:150]] = {"fetch_size_kib": fetch.get(k, 0.0), "write_size_kib": write.get(k, 0.0),
                      "read_bytes_corrected": rd, "write_bytes": wr, "traffic_bytes": rd + wr, "launches_seen": nf.get(k, 0)}
+LAUNCH = (("k_cast_pad_bf16", 0), ("gemm_bf16_kernel<256, 128", 1), ("k_latent_fwd", 2), ("gemm_bf16_kernel<128, 128", 3),
+          ("gemm_dgrad_wgrad_kernel", 4), ("k_latent_bwd", 5), ("k_heads_bwd", 6), ("gemm_wgrad_adam_kernel", 7), ("k_adam<true>", 8))
+per_launch = {}
+for k, v in rows.items():
+    for pat, idx in LAUNCH:
+        if pat in k:
+            per_launch[str(idx)] = v["traffic_bytes"]
 dom = [k for k in rows if "gemm_dgrad_wgrad_kernel" in k]
-out = {"method": __doc__.strip(), "per_kernel": rows,
+out = {"method": __doc__.strip(), "per_kernel": rows, "per_launch_bytes": per_launch,
        "step_total_bytes_one_launch_each": sum(v["traffic_bytes"] for v in rows.values())}
 if dom:
     d = rows[dom[0]]
