@@ -484,7 +484,8 @@ int rv_plan_step(rv_plan*, int phases, const float* x, const float* eps, float* 
  * samples past n_samples read as 0).  With audio_bf16 (the same waveform as bf16, n_samples + Sp + 8 elements, zero
  * past n_samples; hop % 8 == 0) the step launches NO cast or gather kernel: fc1's A-tile loader reads frame f at
  * f*hop of the bf16 waveform (rv_linear_fwd_frames) and fc4's loss epilogue reads its fp32 target at f*hop of `audio`
- * (rv_decode_out_loss_fwd_frames).  audio_bf16 == NULL (or an unaligned hop, or the fp8 forward) falls back to one
+ * (rv_decode_out_loss_fwd_frames).  audio_bf16 == NULL (or an unaligned hop, a frame length that is not a multiple of
+ * 128 -- the padded columns must be zeros, not the samples behind the frame -- or the fp8 forward) falls back to one
  * cast kernel per step (rv_gather_cast_frames). */
 int rv_plan_step_frames(rv_plan*, int phases, const float* audio, const void* audio_bf16, long n_samples,
                         const long long* frame_index, long first_frame, long hop, const float* eps, float* recon_out,

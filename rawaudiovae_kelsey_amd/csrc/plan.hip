@@ -541,7 +541,10 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       n_amax = (int)((Bp / bm3) * (Hp / bn3));
       RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to %d fc3 output tiles (got %d)", p->n_amax_cap, n_amax);
     }
-    if (p->fr_hop && p->fr_bf16 && !p->fp8 && p->fr_hop % 8 == 0 && ((uintptr_t)p->fr_bf16 & 15) == 0) {
+    // in place only when the padded frame length IS the frame length: with S < Sp the loader's columns S..Sp would be
+    // the samples that follow the frame instead of zeros (harmless to fc1, whose weight columns there are zero, but
+    // they would reach the framed copy and with it fc1's weight gradient and the exponents of its fp16 slabs)
+    if (p->fr_hop && p->fr_bf16 && !p->fp8 && p->fr_hop % 8 == 0 && ((uintptr_t)p->fr_bf16 & 15) == 0 && S == Sp) {
       // N1 as SURVEY 8f words it: fc1's A-tile loader reads frame i at i * hop of the resident bf16 waveform; the
       // framed bf16 matrix dW1 needs later is a by-product of that launch; no cast / gather kernel
       RV_K(1, rv_linear_fwd_frames(p->fr_bf16, p->fr_idx, p->fr_first, p->fr_hop, B, p->ws("W1b"), Sp, (float*)p->ws("b1p"),

@@ -61,6 +61,9 @@ class TrainEngine:
                 n *= d
             o += n
         self.n_params = o
+        self.param_shape_list = [self.shapes[k] for k in PARAM_NAMES]
+        self.param_sizes = [(self.offsets[PARAM_NAMES[i + 1]] if i + 1 < len(PARAM_NAMES) else o) - self.offsets[k]
+                            for i, k in enumerate(PARAM_NAMES)]
         f32 = dict(dtype=torch.float32, device=self.device)
         if share is not None:
             if (share.S, share.H, share.L) != (self.S, self.H, self.L):

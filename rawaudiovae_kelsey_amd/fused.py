@@ -138,8 +138,9 @@ class VaeFn(torch.autograd.Function):
         finally:
             L_.rv_plan_set_external_grads(eng._plan, None, None, None, None, None)
         out = [None, None, None]
-        for i, k in enumerate(PARAM_NAMES):
-            out.append(eng.view(grad, k) if ctx.needs_input_grad[3 + i] else None)
+        need = ctx.needs_input_grad
+        for i, (piece, shape) in enumerate(zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)):
+            out.append(piece.view(shape) if need[3 + i] else None)
         return tuple(out)
 
 

@@ -285,6 +285,9 @@ class DecodeFn(torch.autograd.Function):
         return dz, dW3, db3, dW4, db4
 
 
+_LOSS_WS = {}
+
+
 class LossFn(torch.autograd.Function):
     """loss_function (model.py:38-47) as one fused kernel; gradients are produced in the
     same pass and only scaled by the upstream gradient in backward."""
@@ -296,27 +299,32 @@ class LossFn(torch.autograd.Function):
         B, S = recon.shape
         Ld = mu.shape[1]
         dev = recon.device
-        ws = torch.zeros(lib().rv_loss_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+        # the kernel's workspace is zero-initialised ONCE and left clean by every call: one per device and stream
+        st = stream_ptr()
+        ws = _LOSS_WS.get((dev, st))
+        if ws is None:
+            ws = _LOSS_WS[(dev, st)] = torch.zeros(lib().rv_loss_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
         out = torch.empty(4, dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad
         d_recon = torch.empty_like(recon) if need[0] else None
         d_mu = torch.empty_like(mu) if need[2] else None
         d_lv = torch.empty_like(logvar) if need[3] else None
         lib().rv_loss_fused(ptr(recon), ptr(x), ptr(mu), ptr(logvar), B, S, Ld, float(kl_beta), ptr(out),
-                            ptr(d_recon), ptr(d_mu), ptr(d_lv), ptr(ws), stream_ptr())
+                            ptr(d_recon), ptr(d_mu), ptr(d_lv), ptr(ws), st)
         ctx.grads = (d_recon, d_mu, d_lv)
         ctx.parts = out
-        return out[0].clone()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
         g = _f32c(g).view(1)
         outs = []
+        st = stream_ptr()
         for t in ctx.grads:
             if t is None:
                 outs.append(None)
                 continue
             o = torch.empty_like(t)
-            lib().rv_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), stream_ptr())
+            lib().rv_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), st)
             outs.append(o)
         return outs[0], None, outs[1], outs[2], None

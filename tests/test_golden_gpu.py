@@ -186,15 +186,16 @@ def test_device_framing_vs_reference_dataset_fixtures():
     assert str(ei.value) == ds["bad_segment_raises"]
 
 
-@pytest.mark.parametrize("shape", [(512, 384, 12, 128), (256, 1024, 64, 64), (500, 256, 8, 100)])
+@pytest.mark.parametrize("shape", [(512, 384, 12, 128), (256, 1024, 64, 64), (500, 256, 8, 100), (192, 256, 8, 64)])
 @pytest.mark.parametrize("fp8", [False, True])
 def test_step_on_resident_waveform_equals_step_on_gathered_frames(fp8, shape):
     """N1 as SURVEY 8f specifies it: `step_frames` (fc1's GEMM tile loader reading frame i at i * hop of the resident
     bf16 waveform -- no cast kernel --, fc4's loss epilogue reading its fp32 target there) gives bit for bit what
     gather -> `step` gives, for a shuffled index with the zero-padded tail frames in it, a ragged batch, and
     consecutive frames.  Shapes: hop a multiple of 8 (the in-place path; with fp8 the cast kernel that also quantises),
-    a hidden width that gets the 256 x 128 tile, and hop = 100 with S = 500 (16-byte pieces impossible: cast-kernel
-    fallback, padded columns)."""
+    a hidden width that gets the 256 x 128 tile, hop = 100 with S = 500 (16-byte pieces impossible: cast-kernel
+    fallback, padded columns), and S = 192 with hop 64 (an aligned hop but S < Sp = 256: the padded columns must be
+    zeros, not the 64 samples behind the frame, so the plan takes the cast-kernel route there too)."""
     from rawaudiovae_kelsey_amd import data as D
     from rawaudiovae_kelsey_amd.engine import TrainEngine
     S, H, L, hop = shape

@@ -143,7 +143,8 @@ class DataParallel:
             # per-epoch histograms and evaluation); RV_SHARD_GATHER=bf16 selects the 16-bit message (half the bytes,
             # masters gathered at checkpoints by sync_optimizer_state)
             engine.attach_comm(self.comm, sharded=self.sharded,
-                               gather=os.environ.get("RV_SHARD_GATHER", "fp32") if self.sharded else None)
+                               gather=os.environ.get("RV_SHARD_GATHER", "fp32") if self.sharded else None,
+                               payload=os.environ.get("RV_DDP_PAYLOAD"))   # all-reduce: bf16 by default, fp32 = exact mean
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
         sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
