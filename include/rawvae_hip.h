@@ -452,10 +452,15 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     per crossing; deadlock-free for any stream -> hardware-queue mapping because every waiter is enqueued after its
  *     setter; bounded at 100 ms, timeouts counted in ddp_flags[8], which must stay 0) -- or 0: HIP events (~9 us per
  *     crossing).  Steps enqueued under stream capture always use events (a graph needs the edges).
- *   RV_OPT_DDP_W1_WIDE  1 (default): in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of
- *     the backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all
- *     256 CUs instead of 128 (where the extents allow); 0: the local step's split count, so that a one-rank step with the
- *     fp32 payload reproduces rv_plan_step bit for bit (the sums over 4 and over 8 partial slabs round differently). */
+ *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
+ *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
+ *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider
+ *     blocks sum the slabs of the second bucket's other tensors into the payload meanwhile.  Which is faster depends on
+ *     what the collective that runs beside this launch does to the CUs it occupies: with workgroups that leave room
+ *     for a 256 x 256 GEMM block beside them the wide form wins (modelled: 241 against 247 us per step at 8 ranks), with
+ *     workgroups that take their CUs whole it runs in two rounds and loses (263 against 250) -- the default is the
+ *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
+ *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
 enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:

@@ -109,11 +109,21 @@ template <int NSTAGE>
 __global__ void __launch_bounds__(512)
 gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable tab, float* __restrict__ param,
                        float* __restrict__ m_arena, float* __restrict__ v_arena, const float lr,
-                       const float grad_scale, const long long* __restrict__ step_counter, const int stream_mode) {
+                       const float grad_scale, const long long* __restrict__ step_counter, const int stream_mode,
+                       float* __restrict__ fin_f32, bf16_t* __restrict__ fin_bf16) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   if ((int)blockIdx.x < n_gemm) {
     gemm_body<256, 256, 2, 4, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x, smem_dyn);
   } else {
+    if (fin_f32 || fin_bf16) {
+      // riders that only SUM the slabs of the table's tensors into a flat gradient payload (rv_grad_finalize's work;
+      // rv_linear_wgrad_finalize): the data-parallel step's second bucket minus the gradient this GEMM produces
+      const long total = tab.blk_start[tab.n];
+      const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+      for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += 2L * ((long)gridDim.x - n_gemm))
+        adam_block<false>(tab, vb, (int)(threadIdx.x & 255), nullptr, nullptr, nullptr, fin_f32, 0.f, 1.f, nullptr, fin_bf16, nullptr);
+      return;
+    }
     if (stream_mode) {
       // each wave streams its own chunks through a private two-slot LDS ring (adam_stream)
       const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -456,18 +466,18 @@ int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {   // (plan.hip's
          (Kp / 64) % splits == 0 && g_force_tile < 0;
 }
 
-int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
-                         void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
-                         float* param, float* exp_avg,
-                         float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
-                         int n_adam_blocks, void* stream) {
-  RV_REQUIRE(dy && x && dw && param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_linear_wgrad_adam: null pointer");
+}  // extern "C" (the rider launchers below carry their own linkage)
+
+static int wgrad_riders(const char* who, const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                        void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
+                        float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
+                        const long long* step_counter, float* fin_f32, bf16_t* fin_bf16, int n_rider_blocks, void* stream) {
   RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 64 == 0 && splits >= 1 &&
                  (Kp / 64) % splits == 0, RV_ERR_SHAPE,
-             "rv_linear_wgrad_adam: %ld x %ld x %ld / %d splits does not tile by 256x256x64", Mp, Np, Kp, splits);
+             "%s: %ld x %ld x %ld / %d splits does not tile by 256x256x64", who, Mp, Np, Kp, splits);
   RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE,
-             "rv_linear_wgrad_adam: operands must be 16-byte aligned with leading dims multiples of 8");
-  RV_REQUIRE(n_adam_blocks >= 1 && n_adam_blocks <= 4096, RV_ERR_SHAPE, "rv_linear_wgrad_adam: n_adam_blocks %d", n_adam_blocks);
+             "%s: operands must be 16-byte aligned with leading dims multiples of 8", who);
+  RV_REQUIRE(n_rider_blocks >= 1 && n_rider_blocks <= 4096, RV_ERR_SHAPE, "%s: %d rider blocks", who, n_rider_blocks);
   DescTable tab;
   int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
@@ -491,12 +501,36 @@ int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, lon
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done[pp] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_adam_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
-                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_rider_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
+                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode, fin_f32, fin_bf16);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
 
+extern "C" int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                         void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
+                         float* param, float* exp_avg,
+                         float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
+                         int n_adam_blocks, void* stream) {
+  RV_REQUIRE(dy && x && dw && param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_linear_wgrad_adam: null pointer");
+  return wgrad_riders("rv_linear_wgrad_adam", dy, lddy, x, ldx, Mp, Np, Kp, splits, dw, lddw, slab_dtype, slab_unscale, descs,
+                      n_desc, param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, nullptr, nullptr, n_adam_blocks, stream);
+}
+
+// The same launch whose rider blocks only sum OTHER tensors' gradient slabs into a flat payload arena (fp32, or bf16
+// when out_bf16): rv_grad_finalize's work on the CUs the GEMM leaves idle (plan.hip: the data-parallel step's second
+// bucket, except the gradient this GEMM is producing).  Not in the public header.
+extern "C" int rv_linear_wgrad_finalize(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
+                             void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
+                             void* grad_out, int out_bf16, int n_rider_blocks, void* stream) {
+  RV_REQUIRE(dy && x && dw && grad_out, RV_ERR_NULL, "rv_linear_wgrad_finalize: null pointer");
+  return wgrad_riders("rv_linear_wgrad_finalize", dy, lddy, x, ldx, Mp, Np, Kp, splits, dw, lddw, slab_dtype, slab_unscale, descs,
+                      n_desc, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr, out_bf16 ? nullptr : (float*)grad_out,
+                      out_bf16 ? (bf16_t*)grad_out : nullptr, n_rider_blocks, stream);
+}
+
+
+extern "C" {
 
 // ---- paired backward of one Linear layer: dX = relu'(dY W) and dW = dY^T X in one launch ----
 // dy [Mp(batch), Kp(out features)], w [Kp, Np] ([out,in]), x [Mp, Np] is BOTH the ReLU output that

@@ -62,3 +62,9 @@ RV_INTERNAL int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf
 // stream until the flag has reached `value` (bounded; timeouts are counted in *timeouts).
 RV_INTERNAL int rv_flag_set(int* flag, int value, void* stream);
 RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, void* stream);
+// rv_linear_wgrad_adam's launch shape (256 x 256 weight-gradient GEMM + rider blocks on the idle CUs) whose riders sum
+// the gradient slabs of `descs` into a flat payload arena instead of updating them (gemm_launch.hip).
+RV_INTERNAL int rv_linear_wgrad_finalize(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
+                                         int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
+                                         const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16,
+                                         int n_rider_blocks, void* stream);

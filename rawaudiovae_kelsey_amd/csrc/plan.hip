@@ -117,7 +117,7 @@ struct rv_plan {
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
   int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
-  int ddp_w1_wide = 1;
+  int ddp_w1_wide = 0;
   int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
   unsigned skip = 0;           // rv_plan_diag_skip (include/rawvae_hip_diag.h): launches of the full step left out
   int slab_dtype = RV_SLAB_F16;   // element type of the dW1 / dW4 split-K slabs (RV_OPT_SLAB_DTYPE)
@@ -988,9 +988,20 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(post(2, sc));
   RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
   // dW1 runs WITHOUT optimizer riders here: at several ranks fc4's sum has not arrived when this launch starts (an 8.4 MB
-  // bucket needs 40-65 us on the links; the latent-sized backward in front of this launch lasts 25).
-  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-  RV_TRY(payload(0, 8, s0));                               // fc1, fc21, fc22, fc3: contiguous in the arena
+  // bucket needs 40-65 us on the links; the latent-sized backward in front of this launch lasts 25).  It keeps the local
+  // step's 128 workgroups by default: this launch runs beside fc4's exchange, whose workgroups hold CUs, and a GEMM that
+  // needs every CU whole then runs in two rounds (RV_OPT_DDP_W1_WIDE; modelled both ways in tools/ddp_model.py).
+  const int n_gemm = (int)((Hp / 256) * (Sp / 256) * s_w1);
+  if (w1_tile(p) == RV_TILE_256x256 && n_gemm <= 192) {
+    // the GEMM leaves CUs idle: rider blocks sum the slabs of everything else in the second bucket (fc1.bias, heads, fc3:
+    // complete since the heads' backward) into the payload meanwhile, and only fc1.weight's own slabs are left to sum
+    RV_TRY(rv_linear_wgrad_finalize(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, dd + 1, 7,
+                                    p->payload_bf16 ? p->grad_bf16 : (void*)p->b.grad, p->payload_bf16, 256 - n_gemm, stream));
+    RV_TRY(payload(0, 1, s0));
+  } else {
+    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_TRY(payload(0, 8, s0));                             // fc1, fc21, fc22, fc3: contiguous in the arena
+  }
   RV_TRY(signal(1, s0, sc));                               // fork 2: the second exchange follows the first on the
   RV_TRY(reduce(1, 0, 8, sc));                             // collective stream (one communicator, one stream, in order)
   RV_TRY(post(3, sc));

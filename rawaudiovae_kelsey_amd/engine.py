@@ -300,9 +300,9 @@ class TrainEngine:
         self._comm = comm   # keep the communicator alive as long as the plan can use it
         # cross-stream edges of the all-reduce schedule: device-side flags (default) or HIP events (RV_DDP_SIGNAL=event)
         lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 0 if os.environ.get("RV_DDP_SIGNAL") == "event" else 1)
-        # fc1's weight gradient on all CUs in the all-reduce schedule (twice the local step's K splits); RV_DDP_W1_WIDE=0
-        # or set_ddp_w1_wide(False) keeps the local split count (bit-for-bit comparisons with the local step)
-        self.set_ddp_w1_wide(os.environ.get("RV_DDP_W1_WIDE", "1") != "0")
+        # RV_DDP_W1_WIDE=1 / set_ddp_w1_wide(True): fc1's weight gradient on all CUs in the all-reduce schedule (twice the
+        # local step's K splits) -- faster only beside a collective whose workgroups leave room on their CUs
+        self.set_ddp_w1_wide(os.environ.get("RV_DDP_W1_WIDE", "0") == "1")
         self.ddp_payload = "fp32"
         if not sharded:
             from .ddp import DEFAULT_PAYLOAD

@@ -118,8 +118,11 @@ def main():
             for a, b in zip(ea.losses(3), eb.losses(3)):
                 ok = ok and abs(a - b) <= 1e-4 * abs(b)
             if not agree(ok):
-                failures.append(tag + ": differs from the torch.distributed route (rank %d: mean %.3g max %.3g, lr %.1g)"
-                                % (rank, float(d.mean()), float(d.max()), LR))
+                per = ", ".join("%s %.2g/%.2g" % (k, float((ea.view(ea.param, k) - eb.view(eb.param, k)).abs().mean()),
+                                                   float((ea.view(ea.param, k) - eb.view(eb.param, k)).abs().max()))
+                                for k in ("fc1.weight", "fc1.bias", "fc21.weight", "fc22.weight", "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias"))
+                failures.append(tag + ": differs from the torch.distributed route (rank %d: mean %.3g max %.3g, lr %.1g; per tensor "
+                                "mean/max: %s; losses %r vs %r)" % (rank, float(d.mean()), float(d.max()), LR, per, ea.losses(3), eb.losses(3)))
             del ra, ea
         dist.barrier()
         comm.destroy()

@@ -89,9 +89,15 @@ def main():
             (1, 0.0, 0.0, "bf16"), (1, 0.0, 0.0, "fp32")]
     if len(sys.argv) > 1:
         cfgs = [(int(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3]), sys.argv[4])]
+    # RV_MODEL_LDS: dynamic LDS of every stand-in workgroup in bytes (default 0).  With 65536 a CU that hosts one cannot
+    # host a 256 x 256 GEMM block (128 KiB) beside it: the pessimistic reading of what a real collective's workgroups do
+    lds = int(os.environ.get("RV_MODEL_LDS", "0"))
+    nblk = int(os.environ.get("RV_MODEL_BLOCKS", "32"))
+    if lds or nblk != 32:
+        print("(stand-in workgroups: %d x 256 threads, %d bytes of LDS each)" % (nblk, lds))
     for world, bus, lat, payload in cfgs:
         e = engine()
-        e.attach_comm(Comm(lib, world, lat, bus, blocks=32 if bus > 0 else 0), payload=payload)
+        e.attach_comm(Comm(lib, world, lat, bus, blocks=nblk if bus > 0 else 0, lds=lds), payload=payload)
         t = time_steps(lambda i: e.step_ddp(xs[i % 8], stream=st), st)
         es = 2 if payload == "bf16" else 4
         if bus > 0:
