@@ -421,16 +421,23 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     switch selects the heads' backward: rv_heads_bwd (one pass over h1; needs a padded batch that is a multiple of
  *     512) or the generic rv_linear_dgrad_wgrad; the partial counts of fc21 / fc22 weights and of fc1's bias in
  *     rv_plan_descs follow the form in use.
- *   RV_OPT_FP8  1: fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3; backward, heads, fc3 stay
- *     bf16).  The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:
+ *   RV_OPT_FP8  the fp8 (e4m3) weight path.  2: fp8 forward for fc1 and fc4 (weights AND their input activations in e4m3;
+ *     backward, heads, fc3 stay bf16).  1: that forward AND fc4's backward -- dgrad and wgrad in one 256 x 256 launch -- on
+ *     fp8 operands: the fc4 forward's epilogue writes dP4 as fp8(dP4 * [12]) instead of bf16 (|dP4| <= 2 * 2 / (B S) by
+ *     construction, so the scale is fixed), the dgrad multiplies it with the fp8 weight shadow (read MN-major through
+ *     ds_read_b64_tr_b8), the wgrad with the fp8 image of h3 the fc3 forward wrote; K tiles are 128 deep, half the LDS
+ *     fill per flop of the bf16 pair.  Where the extents do not tile (256 x 256 tiles, an even number of 128-deep K
+ *     tiles per block) and for gradients from outside (rv_plan_set_external_grads) the backward stays bf16.  The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:
  *       [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
  *       [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
  *           "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
  *       [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
  *       [7] non-zero: keep [3] and the weight scales fixed (parity runs)
+ *       [10] 1/([12][2])   [11] 1/([12][3])   (fc4's fp8 backward: dgrad / wgrad dequantisation, rewritten every step)
+ *       [12] scale of dP4's fp8 image: 112 / (2 / (B S)), set by the caller
  *       [8] max|W1|, [9] max|W4| as the last optimizer update left them in the fp8 shadows (0 = none yet; reduced by
  *           the step's first kernel from [32 ..]: 2 x 1024 slots that a small kernel behind the optimizer fills with
- *           max|q| / scale over slices of the two shadows, and that the first kernel resets); [10..31] reserved.  The
+ *           max|q| / scale over slices of the two shadows, and that the first kernel resets); [13..31] reserved.  The
  *           caller zero-initialises the whole buffer.
  *     Weight scales start as the caller's (224 / max|W| at refresh).  Adam rewrites the fp8 shadows with the current
  *     scale; the first kernel of the next step, AFTER latching [5] / [6] from the scales the shadows were written

@@ -84,11 +84,12 @@ def decode(params, z, quant=None, fp8_scales=None):
     h3f = np.maximum(zq @ _q(params["fc3.weight"], quant).T + params["fc3.bias"], 0)
     h3 = _q(h3f, quant)
     if quant == "fp8":
-        pre = (_q8(h3f, fp8_scales["h3"]) @ _q8(params["fc4.weight"], fp8_scales["w4"]).T).astype(z.dtype)
+        h3q = _q8(h3f, fp8_scales["h3"])
+        pre = (h3q @ _q8(params["fc4.weight"], fp8_scales["w4"]).T).astype(z.dtype)
         recon = np.tanh(pre + params["fc4.bias"])
-    else:
-        recon = np.tanh(h3 @ _q(params["fc4.weight"], quant).T + params["fc4.bias"])
-    return h3, recon
+        return h3, recon, h3q.astype(z.dtype)
+    recon = np.tanh(h3 @ _q(params["fc4.weight"], quant).T + params["fc4.bias"])
+    return h3, recon, None
 
 
 def forward(params, x, eps, quant=None, fp8_scales=None):
@@ -99,8 +100,8 @@ def forward(params, x, eps, quant=None, fp8_scales=None):
     x = x.reshape(-1, S)
     h1, mu, logvar = encode(params, x, quant, fp8_scales)
     z, std = reparameterize(mu, logvar, eps)
-    h3, recon = decode(params, z, quant, fp8_scales)
-    return dict(x=x, h1=h1, mu=mu, logvar=logvar, std=std, eps=eps, z=_q(z, quant),
+    h3, recon, h3q = decode(params, z, quant, fp8_scales)
+    return dict(x=x, h1=h1, mu=mu, logvar=logvar, std=std, eps=eps, z=_q(z, quant), h3q=h3q,
                 h3=h3, recon=recon)
 
 
@@ -113,9 +114,13 @@ def loss_function(recon, x, mu, logvar, kl_beta):
     return mse + kl_beta * kld, mse, kld
 
 
-def backward(params, c, kl_beta, quant=None):
+def backward(params, c, kl_beta, quant=None, fp8_scales=None):
     """Gradients of loss_function(forward(x)) w.r.t. the ten parameters.
-    Stands in for `loss.backward()` (train.py:191); derivation SURVEY.md 3.4."""
+    Stands in for `loss.backward()` (train.py:191); derivation SURVEY.md 3.4.
+    quant="fp8" with fp8_scales (the forward's, plus "dp4"): the HIP path's fp8 backward of fc4 -- dP4 leaves the fc4
+    forward's epilogue as fp8(dP4 * s_dp4) (from the fp32 value; the bias gradient is summed in fp32 before that), the
+    dgrad multiplies it with fp8(W4 * s_w4), the wgrad with the fp8 image of h3 the fc3 forward wrote; everything else at
+    the bf16 rounding points.  quant="fp8" without fp8_scales: bf16 rounding points throughout (the forward-only mode)."""
     x, h1, mu, logvar, std, eps, z, h3, recon = (
         c[k] for k in ("x", "h1", "mu", "logvar", "std", "eps", "z", "h3", "recon"))
     B, S = x.shape
@@ -126,10 +131,17 @@ def backward(params, c, kl_beta, quant=None):
     W4, W3 = _q(params["fc4.weight"], quant), _q(params["fc3.weight"], quant)
     W21, W22 = _q(params["fc21.weight"], quant), _q(params["fc22.weight"], quant)
     g = {}
-    dP4 = _q((2.0 / n_r) * (recon - x) * (1.0 - recon * recon), quant)
-    g["fc4.weight"] = dP4.T @ h3
-    g["fc4.bias"] = dP4.sum(0)
-    dP3 = _q((dP4 @ W4) * (h3 > 0), quant)
+    if quant == "fp8" and fp8_scales is not None:
+        dP4f = (2.0 / n_r) * (recon - x) * (1.0 - recon * recon)
+        dP4 = _q8(dP4f, fp8_scales["dp4"])
+        g["fc4.weight"] = dP4.T @ c["h3q"]
+        g["fc4.bias"] = dP4f.sum(0)
+        dP3 = _q((dP4 @ _q8(params["fc4.weight"], fp8_scales["w4"])) * (h3 > 0), quant)
+    else:
+        dP4 = _q((2.0 / n_r) * (recon - x) * (1.0 - recon * recon), quant)
+        g["fc4.weight"] = dP4.T @ h3
+        g["fc4.bias"] = dP4.sum(0)
+        dP3 = _q((dP4 @ W4) * (h3 > 0), quant)
     g["fc3.weight"] = dP3.T @ z
     g["fc3.bias"] = dP3.sum(0)
     dz = dP3 @ W3

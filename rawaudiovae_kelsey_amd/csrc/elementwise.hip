@@ -92,6 +92,10 @@ __device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_par
     if (st[7] == 0.f && m > 0.f) st[3] = 224.f / m;
     st[5] = 1.f / (st[0] * st[1]);
     st[6] = 1.f / (st[3] * st[2]);
+    // fp8 backward of fc4: dP4's image is written with the fixed scale st[12] (set by the caller: 112 / (2 / (B S)), so
+    // that |dP4| <= 2 * 2 / (B S) lands within +-224); the dgrad multiplies it with W4's shadow, the wgrad with h3's image
+    st[10] = 1.f / (st[12] * st[2]);
+    st[11] = 1.f / (st[12] * st[3]);
     // the weight shadows read by this step were written with st[1] / st[2] (now inside st[5] / st[6]); the coming
     // optimizer update quantises with scales that follow the weights it last saw
     st[8] = w1;

@@ -106,22 +106,36 @@ __device__ __forceinline__ int swz_mn(int k) {
     return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);  // 4 x 32-B chunks per 128-B k-row
 }
 
+// MN-major fp8 (e4m3) operand of the 256 x 256 ping-pong kernels (the fp8 fc4 backward): a half tile is 128 k-rows of
+// 128 bytes (128 rows of the operand, one byte each); 16-byte chunk c of k-row k is stored at chunk c ^ swz_mn8(k).
+// ds_read_b64_tr_b8 hands each group of 16 lanes an 8 (k) x 16 (byte) block -- lane i addresses row i >> 1, byte
+// 8 (i & 1) of it; lane j receives column j, eight consecutive k -- so one 32-lane half touches 16 k-rows of one chunk:
+// rows alternate between the two halves of the 64 banks by themselves (128-byte pitch), the swizzle spreads the four
+// rows of equal parity of each 16-lane group and the two groups (k apart by 16) over the eight chunks: no conflicts.
+__device__ __forceinline__ int swz_mn8(int k) { return ((k >> 1) & 3) | (((k >> 4) & 1) << 2); }
+
 // Per-lane element offsets (from the tile origin) of the 16-byte pieces this lane stages for one
 // ROWS x 64 operand tile: computed once, so the K loop only adds a wave-uniform tile base
 // (scalar) to a 32-bit per-lane offset -- global_load_lds then uses its saddr+voffset form and
 // the loop carries one VGPR per piece instead of a 64-bit pointer.
-template <int ROWS, bool KMAJ, int NW>
+template <int ROWS, bool KMAJ, int NW, bool F8MN = false>
 struct StageOffsets {
   static constexpr int NINSTR = ROWS * 128 / 1024;  // 1-KiB wave-instructions per tile
   static constexpr int PER_WAVE = NINSTR / NW;
   static_assert(NINSTR % NW == 0, "tile must split evenly over the waves");
+  static_assert(!F8MN || (!KMAJ && ROWS == 128), "MN-major fp8: half tiles of 128 k-rows x 128 bytes");
   unsigned off[PER_WAVE];
 
   __device__ __forceinline__ void init(long ld, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int t = wave + NW * i;
-      if constexpr (KMAJ) {
+      if constexpr (F8MN) {
+        // k-row pitch `ld` in 2-byte units (the operand pointers are typed bf16); 8 k-rows of 8 chunks per instruction
+        const int k = 8 * t + (lane >> 3);
+        const int c = (lane & 7) ^ swz_mn8(k);
+        off[i] = (unsigned)(k * (int)ld + c * 8);
+      } else if constexpr (KMAJ) {
         const int r = 8 * t + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         off[i] = (unsigned)(r * (int)ld + c * 8);
@@ -162,9 +176,24 @@ struct StageOffsets {
 
 // One 16(rows) x 32(k) MFMA operand fragment: lane l holds rows row0+(l&15),
 // k = 32*kk + 8*(l>>4) + j, j = 0..7.
-template <int ROWS, bool KMAJ>
+typedef int v2i32_ __attribute__((ext_vector_type(2)));
+typedef int v4i32_ __attribute__((ext_vector_type(4)));
+template <int ROWS, bool KMAJ, bool F8 = false>
 __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int kk, int lane) {
-  if constexpr (KMAJ) {
+  if constexpr (F8 && !KMAJ) {
+    // 16 consecutive k (bytes) of operand row row0 + (lane & 15), k = 16 (4 kk + (lane >> 4)) ..: the positions the
+    // K-major fragment of the other operand holds (chunk 4 kk + (lane >> 4) of a 128-byte row)
+    static_assert(ROWS == 128, "MN-major fp8: 128-byte k-rows");
+    const int i = lane & 15;
+    const int k0 = 16 * (kk * 4 + (lane >> 4)) + (i >> 1), k1 = k0 + 8;
+    const int c = row0 >> 4;
+    const lds_char* a0 = lds + k0 * 128 + ((c ^ swz_mn8(k0)) << 4) + 8 * (i & 1);
+    const lds_char* a1 = lds + k1 * 128 + ((c ^ swz_mn8(k1)) << 4) + 8 * (i & 1);
+    const v2i32_ lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i32_*)a0);
+    const v2i32_ hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i32_*)a1);
+    const v4i32_ v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else if constexpr (KMAJ) {
     const int r = row0 + (lane & 15);
     const int c = (kk * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
     return *(const __attribute__((address_space(3))) bf16x8*)(lds + r * 128 + c * 16);
@@ -203,6 +232,43 @@ __device__ __forceinline__ f32x4 mfma_fp8_k128(const bf16x8 f0, const bf16x8 f1,
   const i32x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
   const i32x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// The same on operands that were LOADED as 8-dword tuples (the ping-pong loop: with a dozen fragments alive, assembling
+// the tuples at the MFMA from separate 4-dword halves doubled the fragment registers and spilled).
+__device__ __forceinline__ f32x4 mfma_fp8_k128(const i32x8 a, const i32x8 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+// ... accumulating IN PLACE, as inline asm: through the builtin hipcc (ROCm 7.2) gave a third of the ping-pong loop's
+// MFMAs a destination other than their accumulator input (the three-address form), which doubles the live accumulators
+// of a kernel that has none to spare: 317 dwords spilled.  "+v" ties destination and accumulator.  The results are first
+// read by ordinary instructions in the epilogue, behind two workgroup barriers (the wait states an MFMA result needs
+// before a VALU read have long passed; nothing pads them inside an asm).
+__device__ __forceinline__ void mfma_fp8_k128_acc(const i32x8 a, const i32x8 b, f32x4& c, const int unit_scale) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+               : "+v"(c) : "v"(a), "v"(b), "v"(unit_scale));
+}
+// Both k halves (kk = 0, 1) of one fp8 fragment as the instruction's 8-dword operand.
+template <int ROWS, bool KMAJ>
+__device__ __forceinline__ i32x8 load_frag8(const lds_char* lds, int row0, int lane) {
+  if constexpr (KMAJ) {
+    const i32x4 f0 = __builtin_bit_cast(i32x4, load_frag<ROWS, true, true>(lds, row0, 0, lane));
+    const i32x4 f1 = __builtin_bit_cast(i32x4, load_frag<ROWS, true, true>(lds, row0, 1, lane));
+    return i32x8{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+  } else {
+    // MN-major: the swizzle of k-rows k, k + 8 and k + 64 is the same (swz_mn8 reads bits 1, 2 and 4 of k; the lane's
+    // first row is 16 (lane >> 4) + ((lane & 15) >> 1)), so ONE per-lane address serves the four reads of a fragment
+    // through immediate offsets: + 8 k-rows, + 64 k-rows (kk = 1), + 72
+    static_assert(ROWS == 128, "MN-major fp8: 128-byte k-rows");
+    const int i = lane & 15, k = 16 * (lane >> 4) + (i >> 1);
+    const lds_char* a = lds + k * 128 + (((row0 >> 4) ^ swz_mn8(k)) << 4) + 8 * (i & 1);
+    typedef __attribute__((address_space(3))) v2i32_* lp;
+    const v2i32_ r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)a);
+    const v2i32_ r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(a + 8 * 128));
+    const v2i32_ r2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(a + 64 * 128));
+    const v2i32_ r3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(a + 72 * 128));
+    return i32x8{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+  }
 }
 
 // fp32 x 8 -> 8 fp8 (e4m3, OCP) bytes, saturating at +-448 (v_cvt_pk_fp8_f32 rounds to nearest even).
@@ -258,56 +324,82 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // behind), and read two barriers after the counted vmcnt that retires its LDS-DMA.
 // `tail_hook` runs once per wave in phase 0 of the LAST K tile, where the loop has nothing left to stage: a place to
 // put LDS-DMA of epilogue operands in flight (they are retired by the loop's final vmcnt(0)).
-template <bool A_KMAJ, bool B_KMAJ, typename Hook>
+// FP8: e4m3 operands (pointers typed bf16, leading dims in 2-byte units): a K tile is 128 deep, the LDS images hold the
+// same 16 KiB per half (K-major: 128 rows x 128 k-bytes; MN-major: 128 k-rows x 128 row-bytes, StageOffsets F8MN),
+// and a phase's 16 MFMAs of 16x16x32 become 8 of 16x16x128 -- the same matrix-pipe time for twice the contraction.
+template <bool A_KMAJ, bool B_KMAJ, bool FP8, typename Hook>
 __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                   const long lda, const long ldb, const int nk, lds_char* smem,
                                                   const int wave, const int lane, f32x4 (&acc)[8][4], Hook tail_hook) {
   constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k half tile
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
   const int wr = wave >> 2, wc = wave & 3;
-  StageOffsets<128, A_KMAJ, 8> sa;
-  StageOffsets<128, B_KMAJ, 8> sb;
+  StageOffsets<128, A_KMAJ, 8, FP8 && !A_KMAJ> sa;
+  StageOffsets<128, B_KMAJ, 8, FP8 && !B_KMAJ> sb;
   sa.init(lda, wave, lane);
   sb.init(ldb, wave, lane);
-  const long a_step = A_KMAJ ? 64 : 64 * lda, b_step = B_KMAJ ? 64 : 64 * ldb;
-  const long a_half = A_KMAJ ? 128 * lda : 128, b_half = B_KMAJ ? 128 * ldb : 128;
+  const int unit_scale = 0x7F7F7F7F;     // fp8: E8M0 block scales of 1.0 for both operands (held in one VGPR)
+  constexpr int KROWS = FP8 ? 128 : 64;  // k-rows of an MN-major tile
+  constexpr int MNH = FP8 ? 64 : 128;    // 128 operand rows of an MN-major image, in 2-byte units
+  const long a_step = A_KMAJ ? 64 : KROWS * lda, b_step = B_KMAJ ? 64 : KROWS * ldb;
+  const long a_half = A_KMAJ ? 128 * lda : MNH, b_half = B_KMAJ ? 128 * ldb : MNH;
   auto stage_a = [&](int h, int t) {
     if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, smem + (t & 1) * BUF + h * HALF, wave);
   };
   auto stage_b = [&](int h, int t) {
     if (t < nk) sb.stage(Bg + h * b_half + (long)t * b_step, smem + (t & 1) * BUF + (2 + h) * HALF, wave);
   };
-  bf16x8 a[4][2], b0[2][2], b1[2][2], b2[2][2];
+  // fragment registers: bf16 -- [.][kk] 4-dword fragments; fp8 -- the 8 dwords of a fragment's two k halves live in ONE
+  // tuple (elements [.][0] and [.][1] of these arrays are then the low and high half of that tuple's storage)
+  struct Frag { bf16x8 h[2]; };
+  union FragU { Frag f; i32x8 t; __device__ FragU() {} };
+  FragU a[4], b0[2], b1[2], b2[2];
   const int brow = (wc & 1) * 64;
   auto rd_a = [&](const lds_char* buf, int mq) {
     const lds_char* base = buf + wr * HALF;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (FP8) a[i].t = load_frag8<128, A_KMAJ>(base, mq * 64 + i * 16, lane);
+      else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) a[i][kk] = load_frag<128, A_KMAJ>(base, mq * 64 + i * 16, kk, lane);
+        for (int kk = 0; kk < 2; ++kk) a[i].f.h[kk] = load_frag<128, A_KMAJ>(base, mq * 64 + i * 16, kk, lane);
+      }
+    }
   };
-  auto rd_b = [&](bf16x8 (&b)[2][2], const lds_char* buf, int nq) {
+  auto rd_b = [&](FragU (&b)[2], const lds_char* buf, int nq) {
     const lds_char* base = buf + (2 + (wc >> 1)) * HALF;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (FP8) b[j].t = load_frag8<128, B_KMAJ>(base, brow + nq * 32 + j * 16, lane);
+      else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) b[j][kk] = load_frag<128, B_KMAJ>(base, brow + nq * 32 + j * 16, kk, lane);
+        for (int kk = 0; kk < 2; ++kk) b[j].f.h[kk] = load_frag<128, B_KMAJ>(base, brow + nq * 32 + j * 16, kk, lane);
+      }
+    }
   };
   // close the memory half of a phase, run its MFMA cluster between two barriers
-  auto mma = [&](auto mq_c, auto nq_c, bf16x8 (&b)[2][2]) {
+  auto mma = [&](auto mq_c, auto nq_c, FragU (&b)[2]) {
     constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    if constexpr (FP8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[MQ * 4 + i][NQ * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[MQ * 4 + i][NQ * 2 + j], 0, 0, 0);
+          mfma_fp8_k128_acc(b[j].t, a[i].t, acc[MQ * 4 + i][NQ * 2 + j], unit_scale);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[MQ * 4 + i][NQ * 2 + j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j].f.h[kk], a[i].f.h[kk], acc[MQ * 4 + i][NQ * 2 + j], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -321,7 +413,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
   // bq holds B(n0) of tile kt on entry and bn receives B(n0) of tile kt+1 in phase 3, which spreads the
   // fragment reads 8 / 4 / 8 / 4 over the phases; otherwise B(n0) is read in phase 0 (12 / 4 / 8 / 0).
   constexpr bool EARLY_B = A_KMAJ && B_KMAJ;
-  auto k_tile = [&](int kt, const lds_char* cur, const lds_char* nxt, bf16x8 (&bq)[2][2], bf16x8 (&bn)[2][2]) {
+  auto k_tile = [&](int kt, const lds_char* cur, const lds_char* nxt, FragU (&bq)[2], FragU (&bn)[2]) {
     // phase 0: (B(n0),) A(m0);  stage B-half 1 of tile kt+1
     if constexpr (!EARLY_B) rd_b(bq, cur, 0);
     rd_a(cur, 0);
@@ -370,6 +462,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows
+  if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs' results, before any VALU reads them
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -387,7 +480,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
 template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
-  static_assert(!FP8 || (A_KMAJ && B_KMAJ && NSTAGE < 8), "fp8 operands: K-major (forward) GEMMs on the ring loop");
+  static_assert(!FP8 || NSTAGE == 8 || (A_KMAJ && B_KMAJ), "fp8 operands: K-major (forward) GEMMs on the ring loop, any layout on the ping-pong loop");
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -423,9 +516,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   }
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const long k0 = (long)split * p.k_tiles * 64;
-
-  const bf16_t* Ag = A_KMAJ ? p.A + m0 * p.lda + k0 : p.A + k0 * p.lda + m0;
-  const bf16_t* Bg = B_KMAJ ? p.B + n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
+  // (fp8: one byte per element and pointers typed bf16 -- a K-major row advances by k0 two-byte units for 2 k0 bytes, an
+  // MN-major image starts 2 k0 k-rows down and m0 / 2 two-byte units in)
+  constexpr int F8S = FP8 ? 2 : 1;
+  const bf16_t* Ag = A_KMAJ ? p.A + m0 * p.lda + k0 : p.A + (F8S * k0) * p.lda + m0 / F8S;
+  const bf16_t* Bg = B_KMAJ ? p.B + n0 * p.ldb + k0 : p.B + (F8S * k0) * p.ldb + n0 / F8S;
   const long a_step = A_KMAJ ? 64 : 64 * p.lda;
   const long b_step = B_KMAJ ? 64 : 64 * p.ldb;
 
@@ -514,7 +609,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
                                        (__attribute__((address_space(3))) void*)(base + (i - i0) * 1024), 16, 0, 0);
   };
   if constexpr (PINGPONG) {
-    mainloop_pingpong<A_KMAJ, B_KMAJ>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc, [&]() {
+    mainloop_pingpong<A_KMAJ, B_KMAJ, FP8>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc, [&]() {
       if constexpr (MASK_LDS) {
         if (mask_lds) mask_dma(0, 2 * CM, mk_lds0);
       }
@@ -738,7 +833,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
   }
   const float dq = (FP8 && p.dq) ? *p.dq : 1.f;   // fp8 operands: undo the operand scales on the accumulator
-  const float qs = (EPI == EPI_BIAS_ACT_BF16 && p.out_fp8) ? *p.q_scale : 0.f;
+  const float qs = ((EPI == EPI_BIAS_ACT_BF16 || EPI == EPI_TANH_LOSS) && p.out_fp8) ? *p.q_scale : 0.f;
   float amax = 0.f;
   const bool x_al = EPI == EPI_TANH_LOSS && p.x && (p.ld_x & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
   // fp16 slabs: the wave tile's exponent (see GemmArgs::out_f16).  max|acc| over the wave (order-independent, so
@@ -758,6 +853,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(acc[mi][ni][r]));
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if constexpr (FP8) mx *= dq;   // the stored values are the accumulators times the (positive) dequantisation factor
       const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
       int sb = 268 - e;                       // biased exponent of the scale
       sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
@@ -897,6 +993,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         float rec[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) rec[e] = fast_tanh(v[it][e] + bias[it % NP][e]);
+        float gq[8];   // the same gradient for the fp8 image of dP4 (the fp8 fc4 backward's operand)
         if (p.x && interior) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -905,6 +1002,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
             const float g = p.scale * d * (1.f - rec[e] * rec[e]);
             cs[it % NP][e] += g;
             o[e] = (bf16_t)g;
+            gq[e] = g * qs;
           }
         } else {
 #pragma unroll
@@ -918,9 +1016,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
               cs[it % NP][e] += g;
             }
             o[e] = (bf16_t)g;
+            gq[e] = g * qs;
           }
         }
-        if (p.x) store_out16((bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col), o, p.wt);
+        if (p.x && p.out_bf16) store_out16((bf16x8*)(p.out_bf16 + r * p.ld_bf16 + col), o, p.wt);
+        if (p.x && p.out_fp8) *(unsigned long long*)(p.out_fp8 + r * p.ld_fp8 + col) = pack_fp8x8(gq);
         if (p.recon && rv_) {
           if ((p.ld_recon & 3) == 0 && col + 8 <= p.N_valid) {
             store_out16((f32x4*)(p.recon + r * p.ld_recon + col), f32x4{rec[0], rec[1], rec[2], rec[3]}, p.wt);
@@ -1044,14 +1144,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArg
 // Two independent GEMMs in ONE launch (blocks [0, n_first) run the first): neither of the
 // paired problems has enough 256x256 output tiles to fill 256 CUs on its own, together they do.
 // Used for the backward of a Linear layer: dX = relu'(dY W) (NN) and dW = dY^T X (TN).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool FP8 = false>
 __global__ void __launch_bounds__(64 * WGM * WGN)
 gemm_dgrad_wgrad_kernel(const GemmArgs dgrad, const GemmArgs wgrad, const int n_first) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   if ((int)blockIdx.x < n_first)
-    gemm_body<BM, BN, WGM, WGN, true, false, EPI_MASK_BF16, NSTAGE>(dgrad, blockIdx.x, smem_dyn);
+    gemm_body<BM, BN, WGM, WGN, true, false, EPI_MASK_BF16, NSTAGE, FP8>(dgrad, blockIdx.x, smem_dyn);
   else
-    gemm_body<BM, BN, WGM, WGN, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x - n_first, smem_dyn);
+    gemm_body<BM, BN, WGM, WGN, false, false, EPI_F32, NSTAGE, FP8>(wgrad, blockIdx.x - n_first, smem_dyn);
 }
 
 // Two independent GEMMs of the same block-tile configuration in ONE launch (blocks [0, n_first) run

@@ -173,7 +173,7 @@ int set_slabs(GemmArgs& g, void* dw, long lddw, long split_stride, int dtype, fl
 
 int g_pair_loop = 8;  // main loop of the paired 256x256 kernel: 8 = ping-pong (default), 2 = two-slot ring
 
-template <int NSTAGE>
+template <int NSTAGE, bool FP8 = false>
 int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
   GemmArgs d = d_in, g = g_in;
@@ -181,7 +181,7 @@ int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
   constexpr int smem = 2 * (BM + BN) * 128 + 8 * 4096;  // the ring (the epilogue's reductions reuse its first bytes) + the
                                                          // first ReLU-mask chunk of the dgrad blocks (gemm_bf16.h MASK_LDS)
-  auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE>;
+  auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE, FP8>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -362,17 +362,20 @@ int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, 
 
 int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4, const float* dq,
                                long Bp, long Sp, long Hp, long B, long S, const float* x, long ldx, float* recon,
-                               long ld_recon, void* dP4, long ld_dp4, float* mse_partial, float* db4_partial,
-                               void* stream) {
+                               long ld_recon, void* dP4, long ld_dp4, void* dP4_fp8, long ld_dp4q, const float* dp4_scale,
+                               float* mse_partial, float* db4_partial, void* stream) {
   RV_REQUIRE(h3_fp8 && w4_fp8 && dq, RV_ERR_NULL, "rv_decode_out_loss_fwd_fp8: null operand");
   RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_fp8: B,S exceed padded extents");
-  RV_REQUIRE(!x || dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd_fp8: x given without dP4 output");
+  RV_REQUIRE(!x || dP4 || dP4_fp8, RV_ERR_NULL, "rv_decode_out_loss_fwd_fp8: x given without dP4 output");
+  RV_REQUIRE(!dP4_fp8 || (dp4_scale && ld_dp4q % 8 == 0 && ((uintptr_t)dP4_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_decode_out_loss_fwd_fp8: the fp8 image of dP4 needs its scale and 8-byte aligned rows");
   RV_REQUIRE(Hp % 128 == 0 && ldh % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_fp8: K and leading dims must be multiples of 128 / 16 fp8 elements");
   GemmArgs a{};
   a.A = (const bf16_t*)h3_fp8; a.lda = ldh / 2; a.B = (const bf16_t*)w4_fp8; a.ldb = ldw / 2;
   a.k_tiles = (int)(Hp / 128); a.M_valid = (int)B; a.N_valid = (int)S;
   a.bias = b4; a.x = x; a.ld_x = ldx; a.recon = recon; a.ld_recon = ld_recon;
   a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
+  a.out_fp8 = (unsigned char*)dP4_fp8; a.ld_fp8 = ld_dp4q; a.q_scale = dp4_scale;
   a.scale = 2.0f / ((float)B * (float)S); a.dq = dq;
   return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
 }
@@ -408,14 +411,18 @@ int rv_decode_out_loss_fwd(const void* h3, long ldh, const void* w4, long ldw, c
 int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4, const float* dq,
                                   long Bp, long Sp, long Hp, long B, long S, const float* audio, long n_samples,
                                   const long long* frame_index, long first_frame, long hop, float* recon, long ld_recon,
-                                  void* dP4, long ld_dp4, float* mse_partial, float* db4_partial, void* stream) {
-  RV_REQUIRE(h3 && w4 && audio && dP4, RV_ERR_NULL, "rv_decode_out_loss_fwd_frames: null operand");
+                                  void* dP4, long ld_dp4, void* dP4_fp8, long ld_dp4q, const float* dp4_scale,
+                                  float* mse_partial, float* db4_partial, void* stream) {
+  RV_REQUIRE(h3 && w4 && audio && (dP4 || dP4_fp8), RV_ERR_NULL, "rv_decode_out_loss_fwd_frames: null operand");
+  RV_REQUIRE(!dP4_fp8 || (dq && dp4_scale && ld_dp4q % 8 == 0 && ((uintptr_t)dP4_fp8 & 7) == 0), RV_ERR_SHAPE,
+             "rv_decode_out_loss_fwd_frames: the fp8 image of dP4 belongs to the fp8 forward and needs its scale");
   RV_REQUIRE(B <= Bp && S <= Sp && hop > 0 && n_samples > 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_frames: bad extents");
   GemmArgs a{};
   a.M_valid = (int)B; a.N_valid = (int)S;
   a.bias = b4; a.x = audio; a.ld_x = 0; a.x_idx = frame_index; a.x_first = first_frame; a.x_hop = hop; a.x_nsamples = n_samples;
   a.recon = recon; a.ld_recon = ld_recon;
   a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
+  a.out_fp8 = (unsigned char*)dP4_fp8; a.ld_fp8 = ld_dp4q; a.q_scale = dp4_scale;
   a.scale = 2.0f / ((float)B * (float)S);
   if (dq) {
     RV_REQUIRE(Hp % 128 == 0 && ldh % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_frames: fp8 K and leading dims must be multiples of 128 / 16");
@@ -637,6 +644,47 @@ int rv_linear_dgrad_wgrad_f32(const void* dy, long lddy, const void* w, long ldw
   rc = rv_linear_dgrad(dy, lddy, w, ldw, Mp, Np, Kp, nullptr, 0, nullptr, 0, nullptr, dx_slabs, lddx, dgrad_splits, stream);
   if (rc) return rc;
   return rv_linear_wgrad(dy, lddy, x, ldx, Kp, Np, Mp, wgrad_splits, RV_TILE_AUTO, dw_slabs, lddw, RV_SLAB_F32, nullptr, stream);
+}
+
+// The paired backward of fc4 on fp8 (e4m3) operands (RV_OPT_FP8; plan.hip): dX = relu'(dYq Wq) and dW = dYq^T Xq in
+// one 256 x 256 ping-pong launch, every operand one byte per element -- dy_fp8 [Mp(batch), Kp(out)] (the fp8 image of
+// dP4 that the fc4 forward's epilogue wrote, K-major for the dgrad and MN-major for the wgrad), w_fp8 [Kp, Np] (the
+// fp8 weight shadow, MN-major through ds_read_b64_tr_b8), x_fp8 [Mp, Np] (the fp8 image of h3, the wgrad's MN-major
+// right operand); mask_bf16 is the bf16 h3 (ReLU').  dq_dgrad / dq_wgrad: device scalars 1 / (scale_dy * scale_w) and
+// 1 / (scale_dy * scale_x).  Same outputs, splits and slab formats as rv_linear_dgrad_wgrad.  Not in the public header.
+int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,
+                              const void* mask_bf16, long ldmask, const float* dq_dgrad, const float* dq_wgrad, long Mp, long Np,
+                              long Kp, void* dx_bf16, long lddx, float* colsum_partial, void* dw_slabs, long lddw, int splits,
+                              int slab_dtype, float* slab_unscale, void* stream) {
+  RV_REQUIRE(dy_fp8 && w_fp8 && x_fp8 && mask_bf16 && dx_bf16 && dw_slabs && dq_dgrad && dq_wgrad, RV_ERR_NULL,
+             "rv_linear_dgrad_wgrad_fp8: null operand");
+  RV_REQUIRE(rv_dgrad_wgrad_fp8_fits(Mp, Np, Kp, splits), RV_ERR_SHAPE,
+             "rv_linear_dgrad_wgrad_fp8: %ld x %ld x %ld / %d splits: extents must tile by 256 x 256 with an even number of 128-deep K tiles", Mp, Np, Kp, splits);
+  RV_REQUIRE(lddy % 16 == 0 && ldw % 16 == 0 && ldx % 16 == 0 && ldmask % 8 == 0, RV_ERR_SHAPE,
+             "rv_linear_dgrad_wgrad_fp8: leading dims must be multiples of 16 bytes");
+  RV_REQUIRE((((uintptr_t)dy_fp8 | (uintptr_t)w_fp8 | (uintptr_t)x_fp8 | (uintptr_t)mask_bf16) & 15) == 0, RV_ERR_SHAPE,
+             "rv_linear_dgrad_wgrad_fp8: operands must be 16-byte aligned");
+  constexpr int BM = 256, BN = 256;
+  GemmArgs d{}, g{};
+  d.A = (const bf16_t*)dy_fp8; d.lda = lddy / 2; d.B = (const bf16_t*)w_fp8; d.ldb = ldw / 2;
+  d.k_tiles = (int)(Kp / 128); d.M_valid = (int)Mp; d.N_valid = (int)Np;
+  d.mask = (const bf16_t*)mask_bf16; d.ld_mask = ldmask; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+  d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1; d.dq = dq_dgrad;
+  g.A = (const bf16_t*)dy_fp8; g.lda = lddy / 2; g.B = (const bf16_t*)x_fp8; g.ldb = ldx / 2;
+  g.k_tiles = (int)(Mp / 128 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np; g.dq = dq_wgrad;
+  const int rc = set_slabs(g, dw_slabs, lddw, Kp * lddw, slab_dtype, slab_unscale, Kp, Np);
+  if (rc) return rc;
+  g.tiles_m = (int)(Kp / BM); g.tiles_n = (int)(Np / BN); g.splits = splits;
+  return launch_pair<8, true>(d, g, (hipStream_t)stream);
+}
+
+int rv_dgrad_wgrad_fp8_fits(long Mp, long Np, long Kp, int splits) {
+  if (!(Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 256 == 0 && splits >= 1)) return 0;
+  if (Kp % 128 || (Kp / 128) % 2 || (Kp / 128) < 2) return 0;                       // dgrad: even count of 128-deep K tiles
+  if (Mp % (128L * splits) || (Mp / 128 / splits) % 2 || (Mp / 128 / splits) < 2) return 0;   // wgrad, per split
+  int paired = 0, bm = 0, sp = 0;
+  if (rv_dgrad_wgrad_pick(Mp, Np, Kp, &paired, &bm, &sp) || !paired || sp != splits) return 0;
+  return g_force_tile < 0 && g_pair_loop == 8;
 }
 
 int rv_gemm_plan(int what, long Mp, long Np, long Kp, int splits_in, int* bm, int* bn, int* splits, int* paired) {

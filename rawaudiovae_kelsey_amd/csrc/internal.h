@@ -32,16 +32,19 @@ RV_INTERNAL int rv_linear_fwd_ex(const void* x_bf16, long ldx, const void* w_bf1
 RV_INTERNAL int rv_linear_fwd_fp8(const void* x_fp8, long ldx, const void* w_fp8, long ldw, const float* bias,
                                   const float* dq, long Mp, long Np, long Kp, int act, void* y_bf16, long ldy,
                                   void* stream);
+// (dP4_fp8 != NULL: the epilogue also writes fp8(dP4 * *dp4_scale), the fp8 fc4 backward's operand; dP4_bf16 may then be NULL)
 RV_INTERNAL int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8, long ldw, const float* b4,
                                            const float* dq, long Bp, long Sp, long Hp, long B, long S, const float* x,
                                            long ldx, float* recon, long ld_recon, void* dP4_bf16, long ld_dp4,
+                                           void* dP4_fp8, long ld_dp4q, const float* dp4_scale,
                                            float* mse_partial, float* db4_partial, void* stream);
 // rv_decode_out_loss_fwd whose fp32 target rows are read in place from the waveform (dq != NULL: fp8 operands).
 RV_INTERNAL int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long ldw, const float* b4,
                                               const float* dq, long Bp, long Sp, long Hp, long B, long S,
                                               const float* audio, long n_samples, const long long* frame_index,
                                               long first_frame, long hop, float* recon, long ld_recon, void* dP4_bf16,
-                                              long ld_dp4, float* mse_partial, float* db4_partial, void* stream);
+                                              long ld_dp4, void* dP4_fp8, long ld_dp4q, const float* dp4_scale,
+                                              float* mse_partial, float* db4_partial, void* stream);
 // rv_adam_flat that also emits the rank's 16-bit parameter message for the bucket `descs` (rv_shard_encode's output from
 // the updated parameters, bit for bit; the caller zero-initialises `msg` once): the sharded step's update and encode in
 // one pass.
@@ -68,3 +71,10 @@ RV_INTERNAL int rv_linear_wgrad_finalize(const void* dy_bf16, long lddy, const v
                                          int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
                                          const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16,
                                          int n_rider_blocks, void* stream);
+// The paired fc4 backward on fp8 operands (gemm_launch.hip) and whether the extents allow it.
+RV_INTERNAL int rv_dgrad_wgrad_fp8_fits(long Mp, long Np, long Kp, int splits);
+RV_INTERNAL int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,
+                                          const void* mask_bf16, long ldmask, const float* dq_dgrad, const float* dq_wgrad,
+                                          long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
+                                          void* dw_slabs, long lddw, int splits, int slab_dtype, float* slab_unscale,
+                                          void* stream);

@@ -253,6 +253,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("W1q", Hp * Sp);
   p->add("W4q", Sp * Hp);
   p->add("h3q", Bp * Hp);
+  p->add("dP4q", Bp * Sp);        // fp8 image of dP4: the fp8 fc4 backward's operand (RV_OPT_FP8 = 1)
   p->add("fp8_state", (32 + 2 * 1024) * 4);   // 16 state floats (+16 pad), then 2 x 1024 max|W| slots
   // per-wave (fused latent forward: 8 per 16 batch rows) or per-tile max|h3| of the fc3 forward (zero until it has run)
   p->n_amax_cap = (int)(Bp / 2 > 4096 ? Bp / 2 : 4096);
@@ -314,7 +315,8 @@ int rv_plan_set_external_grads(rv_plan* p, const float* d_recon, const float* re
 }
 
 static int plan_set_fp8(rv_plan* p, int enable) {
-  p->fp8 = enable ? 1 : 0;
+  RV_REQUIRE(enable >= 0 && enable <= 2, RV_ERR_UNSUPPORTED, "rv_plan_set_option: RV_OPT_FP8 takes 0, 1 or 2 (got %d)", enable);
+  p->fp8 = enable;   // 1: forward of fc1 / fc4 and backward of fc4; 2: forward only
   float* st = (float*)p->ws("fp8_state");
   // Adam keeps the fp8 shadows of fc1.weight / fc4.weight current (descriptor 0 and 8)
   for (rv_param_desc* d : {p->d_slab, p->d_flat}) {
@@ -469,6 +471,29 @@ static int fp8_after_update(rv_plan* p, void* stream) {
   return rv_fp8_wmax(p->ws("W1q"), p->Hp * p->Sp, p->ws("W4q"), p->Sp * p->Hp, (float*)p->ws("fp8_state"), stream);
 }
 
+// fc4's backward on fp8 operands (RV_OPT_FP8 = 1): the fp8 images of dP4 (written by the fc4 forward's epilogue), of
+// W4 (the weight shadow Adam keeps) and of h3 (written by the fc3 forward) feed ONE 256 x 256 ping-pong launch whose K
+// tiles are 128 deep -- half the LDS fill per flop of the bf16 pair, which is what bounds that loop.  Not with gradients
+// from outside (rv_plan_set_external_grads: dP4 then comes from rv_tanh_bwd_pack in bf16) and only where the extents
+// tile (256 x 256 tiles, an even count of 128-deep K tiles per block).
+static bool fp8_bwd(const rv_plan* p) {
+  return p->fp8 == 1 && !p->ext_d_recon && rv_dgrad_wgrad_fp8_fits(p->Bp, p->Hp, p->Sp, p->s_w4);
+}
+static bool fp8_bwd_possible(const rv_plan* p) {   // (at forward time: which images of dP4 to write)
+  return p->fp8 == 1 && rv_dgrad_wgrad_fp8_fits(p->Bp, p->Hp, p->Sp, p->s_w4);
+}
+static int fc4_backward(rv_plan* p, void* stream) {
+  const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
+  if (fp8_bwd(p)) {
+    float* f8 = (float*)p->ws("fp8_state");
+    return rv_linear_dgrad_wgrad_fp8(p->ws("dP4q"), Sp, p->ws("W4q"), Hp, p->ws("h3q"), Hp, p->ws("h3"), Hp, f8 + 10, f8 + 11, Bp, Hp,
+                                     Sp, p->ws("dP3"), Hp, (float*)p->ws("db3p"), p->ws("dW4"), Hp, p->s_w4, p->slab_dtype,
+                                     p->us_w4, stream);
+  }
+  return rv_linear_dgrad_wgrad(p->ws("dP4"), Sp, p->ws("W4b"), Hp, p->ws("h3"), Hp, Bp, Hp, Sp, p->ws("dP3"), Hp,
+                               (float*)p->ws("db3p"), p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream);
+}
+
 // The latent-sized backward between the fc4 pair and fc1's weight gradient: dz, the reparameterisation backward (which
 // also finishes the loss), fc3's weight gradient, and the heads' dgrad + wgrad.  Row-local form (RV_OPT_LATENT_FUSED,
 // padded latent width 64): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of the same launch) and the
@@ -529,6 +554,9 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
     Range range_fwd(p->roctx, "rv:fwd");
     float* f8 = (float*)p->ws("fp8_state");
+    // fp8 backward of fc4: the forward writes dP4 as fp8 (dP4q) INSTEAD of bf16 (a caller that then supplies its own
+    // gradients gets its bf16 dP4 from rv_tanh_bwd_pack)
+    const bool f8_bwd = fp8_bwd_possible(p);
     int n_amax = 0;
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
     const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048;
@@ -587,14 +615,16 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                 nullptr, nullptr, stream));
       RV_K(3, rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
                                            (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
-                                           p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S, dP4, Sp,
+                                           p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S,
+                                           f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp, f8 + 12,
                                            mse_part, (float*)p->ws("db4p"), stream));
     } else if (p->fp8) {
       if (!latent_fused)
         RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
                                 p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
       RV_K(3, rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
-                                        x, S, recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+                                        x, S, recon_out, S, f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp,
+                                        f8 + 12, mse_part, (float*)p->ws("db4p"), stream));
     } else {
       if (!latent_fused)
         RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
@@ -633,8 +663,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
     {
       Range r(p->roctx, "rv:fc4-bwd");
-      RV_K(4, rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+      RV_K(4, fc4_backward(p, stream));
     }
     {
       Range r(p->roctx, "rv:rest-bwd");
@@ -663,9 +692,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_tanh_bwd_pack(p->ext_d_recon, p->ext_recon, B, S, dP4, Bp, Sp, stream));
     RV_TRY(rv_colsum_partial(dP4, 1, Bp, Sp, Sp, (float*)p->ws("db4p"), Sp, stream));
   }
-  if (do_pair)
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+  if (do_pair) RV_TRY(fc4_backward(p, stream));
   bool w3_done = false;
   if (do_chain_a && do_chain_b && do_w3) {
     RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, stream));
@@ -829,8 +856,7 @@ static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) 
 static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                             unsigned long long seed, void* stream) {
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
-  void* xb = p->ws("xb"); void* h3 = p->ws("h3");
-  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dP1 = p->ws("dP1");
+  void* xb = p->ws("xb"); void* dP1 = p->ws("dP1");
   const float* eps_used = eps ? eps : (float*)p->ws("eps");
   hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
   const float scale = 1.0f / (float)p->world;
@@ -847,8 +873,7 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
     return RV_OK;
   };
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                    p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+  RV_TRY(fc4_backward(p, stream));
   // What follows a bucket's reduce-scatter -- Adam on the own shard, the parameter exchange, the shadow rebuild -- on
   // stream `on` (bucket 0: the collective stream, behind the rest of backward; nothing there reads fc4's parameters).
   const bool use_msg = p->msg_send && !p->fp8;
@@ -900,8 +925,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
-  void* xb = p->ws("xb"); void* h3 = p->ws("h3");
-  void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dP1 = p->ws("dP1");
+  void* xb = p->ws("xb"); void* dP1 = p->ws("dP1");
   const float* eps_used = eps ? eps : (float*)p->ws("eps");
   hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
   const float scale = 1.0f / (float)p->world;
@@ -942,8 +966,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
   {
     Range r(p->roctx, "rv:fc4-bwd");
-    RV_TRY(rv_linear_dgrad_wgrad(dP4, Sp, p->ws("W4b"), Hp, h3, Hp, Bp, Hp, Sp, dP3, Hp, (float*)p->ws("db3p"),
-                                 p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream));
+    RV_TRY(fc4_backward(p, stream));
   }
   Range range_rest(p->roctx, "rv:rest-bwd+exchange+adam");
   // Cross-stream edges: device-side flags (elementwise.hip, k_flag_set / k_flag_wait; ~1.8 us per crossing) when

@@ -91,11 +91,16 @@ class TrainEngine:
         L_.rv_plan_bind(self._plan, C.byref(self._bufs))
         self.host_steps = 0
         # fp8 (e4m3) operands for the fc1 / fc4 forward GEMMs (BASELINE configs[4]; build extension)
+        # fp8: True / "full" = forward of fc1 and fc4 AND backward of fc4 (its dgrad + wgrad pair) on e4m3 operands;
+        # "fwd" = the two forward GEMMs only (round 3's path); False = bf16 everywhere
+        if fp8 not in (False, True, None, "full", "fwd"):
+            raise _lib.RvError("fp8=%r (expected False, True / 'full', or 'fwd')" % (fp8,))
         self.fp8 = bool(fp8)
+        self.fp8_mode = 0 if not fp8 else (2 if fp8 == "fwd" else 1)
         self.fp8_x_scale = 256.0        # frames are in [-1, 1]
         self.fp8_h3_scale = 16.0        # first step only; afterwards 224 / max|h3| of the previous step
         if self.fp8:
-            L_.rv_plan_set_option(self._plan, _lib.OPT_FP8, 1)
+            L_.rv_plan_set_option(self._plan, _lib.OPT_FP8, self.fp8_mode)
         # element type of the fc1 / fc4 weight-gradient split-K slabs: "fp16" (default) = block-floating-point fp16, one
         # power-of-two scale per wave tile and slab (half the bytes written and re-read, any gradient magnitude); "fp32"
         if slab_dtype not in ("fp32", "fp16"):
@@ -188,6 +193,8 @@ class TrainEngine:
                 st[2] = 224.0 / max(amax4, 1e-12)
                 if cur[3] == 0.0:
                     st[3] = self.fp8_h3_scale
+                # scale of dP4's fp8 image (the fp8 backward of fc4): |dP4| <= 2 * 2 / (B S) lands within +-224
+                st[12] = 56.0 * self.B * self.S
                 st[8:10] = 0.0   # max|W| of the last update: none yet for these weights
                 self.buffer("fp8_state", torch.float32, (-1,))[32:] = 0.0
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
