@@ -1,12 +1,20 @@
-"""Data-parallel gradient exchange for the fused engine: one process per GPU,
-`torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+"""Data-parallel training for the fused engine: one process per GPU, `torch.distributed` for the process group
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
 
-The reference has no distributed code; frames are independent, so the
-exchange is one SUM all-reduce of the flat fp32 gradient arena per step, issued in three
-buckets in the order the gradients become available (fc4, fc1, the rest) so that the two
-large exchanges overlap the remaining backward GEMMs and the first optimizer launch.  Every rank holds the same per-rank batch size, so mean-of-rank-gradients
-equals the gradient of the global-batch mean loss (the reference's loss is a mean,
-rawvae/model.py:39,45); Adam then applies `grad_scale = 1/world`.
+The reference has no distributed code; frames are independent, so data parallelism is a SUM of the
+ranks' gradients per step with every rank on the same per-rank batch size: the mean of rank gradients is the gradient
+of the global-batch mean loss (the reference's loss is a mean, rawvae/model.py:39,45), and Adam applies 1/world.
+
+Two routes, same arithmetic:
+  * `NativeDdpRunner` (the product path; train.py, bench.py): the LIBRARY issues the collectives --
+    `rv_plan_step_ddp` gets the communicator handle and the addresses of ncclAllReduce / ncclReduceScatter /
+    ncclAllGather, and runs the whole step from one host call on two streams (the caller's and a collective stream
+    chosen by `pick_comm_stream`): buckets fc4 | the rest, each exchanged as soon as its gradients exist, bf16 payload
+    by default (`DEFAULT_PAYLOAD`; "fp32" = the exact mean), device-side flags between the two streams, fc4's Adam
+    beside the second exchange.  `sharded=True` is the reduce-scatter / sharded-Adam / all-gather schedule.
+    DESIGN.md 5 has the schedule, its one-GPU model of 8 ranks and the one-rank RCCL rehearsal.
+  * `DdpRunner` + `GradSync`: the phases of `rv_plan_step` with `torch.distributed` all-reduces between them
+    (works with any backend, gloo on CPU included): the route the CPU tests and the startup cross-check use.
 """
 import ctypes as C
 import os

@@ -107,6 +107,45 @@ class TrainEngine:
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
         L_.rv_plan_set_option(self._plan, _lib.OPT_SLAB_DTYPE, _lib.SLAB_F16 if slab_dtype == "fp16" else _lib.SLAB_F32)
+        self._note_init()     # the zero fills above ran on the current stream
+
+    # ---- stream hygiene ---------------------------------------------------
+    # Arenas, workspace and shadows are (re)initialised by torch ops and library launches on whatever stream is current
+    # at that moment (usually torch's default stream), while steps usually run on a stream of the caller's choice.
+    # PyTorch's rule -- synchronise before using memory on another stream than the one that wrote it -- is easy to
+    # miss here (`TrainEngine(...); load_params(...); step(x, stream=s)` reads the shadows on `s`), and a miss is a
+    # rare, silent wrong first step (seen: two processes sharing one GPU, the other process holding the device while
+    # this one's zero-fill was still queued).  So every initialising call notes an event on the stream it used and the
+    # next step on ANOTHER stream waits for it once.
+    def _note_init(self, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._shared["init_events"] = [e for e in self._shared.get("init_events", []) if e[1] != st.cuda_stream][-3:] + [(ev, st.cuda_stream)]
+        self._local_init = (ev, st.cuda_stream)     # this engine's own workspace / shadows
+
+    def _await_init(self, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        # a stream under hipGraph capture may not wait for an event from outside the capture: the host waits instead
+        # (the initialisation was enqueued before the capture began)
+        capturing = torch.cuda.is_current_stream_capturing()
+
+        def wait(ev, sp):
+            if sp == st.cuda_stream:
+                return
+            if capturing:
+                ev.synchronize()
+            else:
+                st.wait_event(ev)
+        evs = self._shared.get("init_events")
+        if evs:
+            for ev, sp in evs:
+                wait(ev, sp)
+            self._shared["init_events"] = []
+        loc = getattr(self, "_local_init", None)
+        if loc is not None:
+            wait(*loc)
+            self._local_init = None
 
     def __del__(self):
         try:
@@ -140,6 +179,7 @@ class TrainEngine:
                 self.view(self.param, k).copy_(src.to(self.device, torch.float32))
         self.params_changed()
         self.refresh_shadows()
+        self._note_init()
 
     def set_latent_fused(self, enable):
         """True (default): heads GEMM + reparameterisation + fc3 of the forward as one launch where the library has the
@@ -197,6 +237,7 @@ class TrainEngine:
                 st[12] = 56.0 * self.B * self.S
                 st[8:10] = 0.0   # max|W| of the last update: none yet for these weights
                 self.buffer("fp8_state", torch.float32, (-1,))[32:] = 0.0
+        self._await_init(stream)      # (the parameters may have been written on another stream)
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
         self._shadow_version = self._shared["version"]
 
@@ -215,6 +256,7 @@ class TrainEngine:
                 sd[k].data = v
         self.params_changed()
         self.refresh_shadows()
+        self._note_init()
 
     # ---- stepping -------------------------------------------------------
     def step(self, x, eps=None, recon_out=None, phases=PHASE_ALL_LOCAL, grad_scale=1.0,
@@ -227,6 +269,8 @@ class TrainEngine:
             raise _lib.RvError("step: eps must be contiguous fp32 [B, L]")
         if (phases & PHASE_FWD) and self._shadow_version != self._shared["version"]:
             self.refresh_shadows(stream)   # another engine sharing the arena stepped since
+        if self._shared.get("init_events") or getattr(self, "_local_init", None) is not None:
+            self._await_init(stream)
         lib().rv_plan_step(self._plan, int(phases), ptr(x), ptr(eps), ptr(recon_out), self.kl_beta,
                            self.lr, float(grad_scale), int(bool(adam_from_flat)), self.seed,
                            stream_ptr(stream))
@@ -251,6 +295,8 @@ class TrainEngine:
             raise _lib.RvError("step_frames: eps must be contiguous fp32 [B, L]")
         if (phases & PHASE_FWD) and self._shadow_version != self._shared["version"]:
             self.refresh_shadows(stream)
+        if self._shared.get("init_events") or getattr(self, "_local_init", None) is not None:
+            self._await_init(stream)
         # the waveform's bf16 copy (data.DeviceAudio.audio_bf16) lets fc1's tile loader read the frames in place: no cast kernel
         a16 = getattr(audio, "audio_bf16", None)
         lib().rv_plan_step_frames(self._plan, int(phases), ptr(audio.audio), ptr(a16), audio.padded, ptr(index), int(first_frame),
@@ -360,6 +406,8 @@ class TrainEngine:
             raise _lib.RvError("step_ddp: eps must be contiguous fp32 [B, L]")
         if self._shadow_version != self._shared["version"]:
             self.refresh_shadows(stream)
+        if self._shared.get("init_events") or getattr(self, "_local_init", None) is not None:
+            self._await_init(stream)
         self._pick_comm_stream(stream)
         lib().rv_plan_step_ddp(self._plan, ptr(x), ptr(eps), ptr(recon_out), self.kl_beta, self.lr, self.seed,
                                stream_ptr(stream))
@@ -478,6 +526,7 @@ class TrainEngine:
         self._shared["drained"] = int(self.step_counter.item())
         if sd.get("param_groups"):
             self.lr = float(sd["param_groups"][0].get("lr", self.lr))
+        self._note_init()
 
 
 class Graph:

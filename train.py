@@ -58,12 +58,15 @@ def read_config(path):
 
 def engine_options(hw):
     """TrainEngine keyword arguments from the optional [mi355x] section: `fp8 = True` runs the fc1 / fc4 forward
-    GEMMs on fp8 (e4m3) operands (BASELINE configs[4]); `wgrad_slabs = fp16` (default) stores the split-K partial sums
+    GEMMs and fc4's backward on fp8 (e4m3) operands (BASELINE configs[4]; `fp8 = fwd`: the forward only); `wgrad_slabs = fp16` (default) stores the split-K partial sums
     of the two large weight gradients as block-floating-point fp16 (one power-of-two scale per wave tile), `fp32`
     keeps them fp32."""
     kw = {}
-    if str(hw.get('fp8', 'False')).lower() in ('1', 'true', 'yes'):
+    fp8 = str(hw.get('fp8', 'False')).lower()
+    if fp8 in ('1', 'true', 'yes', 'full'):
         kw['fp8'] = True
+    elif fp8 == 'fwd':
+        kw['fp8'] = 'fwd'    # the two forward GEMMs only (round 3's path)
     slabs = str(hw.get('wgrad_slabs', 'fp16')).lower()
     if slabs not in ('fp32', 'fp16'):
         raise ValueError("[mi355x] wgrad_slabs = {} (expected fp32 or fp16)".format(slabs))
