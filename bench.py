@@ -600,9 +600,10 @@ def main():
                 except Exception as exc:   # the headline is already measured: report, do not lose it
                     return {"what": what, "error": str(exc)[:200]}
             alts["alt_fp8"] = time_alt(
-                "fp8 weight path (BASELINE configs[4]): fc1 / fc4 forward AND fc4's backward (dgrad + wgrad, one 256x256 launch, "
-                "128-deep K tiles) on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, per-tensor scales, delayed activation "
-                "scaling, fixed scale for dP4); heads, fc3 and fc1's weight gradient bf16", fp8=True)
+                "fp8 weight path (BASELINE configs[4]): all four large GEMM launches on e4m3 operands -- fc1 / fc4 forward, fc4's "
+                "backward (dgrad + wgrad, one 256x256 launch) and fc1's weight gradient (256x256, beside the optimizer riders, which "
+                "hand 15 % of their work to the GEMM blocks) -- v_mfma_scale_f32_16x16x128_f8f6f4, 128-deep K tiles, per-tensor "
+                "scales, delayed scaling for h3 and dP1, fixed scale for dP4; heads and fc3 bf16", fp8=True)
             alts["alt_fp8_forward_only"] = time_alt("round 3's fp8 path: fc1 / fc4 forward on e4m3 operands, whole backward bf16", fp8="fwd")
             try:
                 alts["alt_deep_c4"] = time_deep_c4(dev, comp, max(10, args.steps // 4), 5)

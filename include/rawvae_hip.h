@@ -274,6 +274,10 @@ int rv_colsum_partial(const void* src, int is_bf16, long rows, long cols, long l
 /* out[i] = a[i] * scalar[0] (device scalar): applies the upstream gradient of the 0-dim
  * loss tensor to the gradients rv_loss_fused saved. */
 int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* stream);
+/* The same for up to three tensors in one launch (out_k[i] = a_k[i] * scalar[0]; n_k = 0 skips tensor k): the three
+ * gradients loss_function's backward hands on -- the autograd path is bound by host time per launch. */
+int rv_scale_by3(const float* a0, float* out0, long n0, const float* a1, float* out1, long n1, const float* a2,
+                 float* out2, long n2, const float* scalar, void* stream);
 
 /* Hop-strided framing on the device (AudioDataset, rawvae/dataset.py:99-121): the padded
  * waveform stays in HBM and out[i, :] = audio[f*hop : f*hop + S] with f = frame_index[i]
@@ -427,17 +431,25 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     construction, so the scale is fixed), the dgrad multiplies it with the fp8 weight shadow (read MN-major through
  *     ds_read_b64_tr_b8), the wgrad with the fp8 image of h3 the fc3 forward wrote; K tiles are 128 deep, half the LDS
  *     fill per flop of the bf16 pair.  Where the extents do not tile (256 x 256 tiles, an even number of 128-deep K
- *     tiles per block) and for gradients from outside (rv_plan_set_external_grads) the backward stays bf16.  The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:
+ *     tiles per block) and for gradients from outside (rv_plan_set_external_grads) the backward stays bf16.  In the full
+ *     local step (all phases in one call) fc1's weight gradient -- the launch that also carries the optimizer riders --
+ *     runs on fp8 operands as well, under the same tiling conditions: the heads' backward writes dP1 as fp8(dP1 * [13])
+ *     only, the GEMM multiplies it with the fp8 image of the frames fc1's forward read (both MN-major), and neither
+ *     bf16 copy is written; [13] follows the maximum of |dP1| measured in the previous step, like h3's scale.
+ *     The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:
  *       [0] scale of x   [1] scale of W1   [2] scale of W4   [3] scale of h3 (this step)
  *       [4] max|h3| of the previous step (reduced from the fc3 forward's per-block maxima, workspace buffer
  *           "h3_amax"; this step's h3 scale is 224 / it: delayed scaling)
  *       [5] 1/([0][1])   [6] 1/([3][2])   (both rewritten at the start of every step)
- *       [7] non-zero: keep [3] and the weight scales fixed (parity runs)
+ *       [7] non-zero: keep [3], [13] and the weight scales fixed (parity runs)
  *       [10] 1/([12][2])   [11] 1/([12][3])   (fc4's fp8 backward: dgrad / wgrad dequantisation, rewritten every step)
  *       [12] scale of dP4's fp8 image: 112 / (2 / (B S)), set by the caller
+ *       [13] scale of dP1's fp8 image (this step; the caller's first guess, then 224 / [14])   [14] max|dP1| of the
+ *           previous step (reduced from the per-wave maxima rv_heads_bwd left behind h3's in "h3_amax")
+ *       [15] 1/([13][0])   (fc1's fp8 weight gradient: dequantisation, rewritten every step)
  *       [8] max|W1|, [9] max|W4| as the last optimizer update left them in the fp8 shadows (0 = none yet; reduced by
  *           the step's first kernel from [32 ..]: 2 x 1024 slots that a small kernel behind the optimizer fills with
- *           max|q| / scale over slices of the two shadows, and that the first kernel resets); [13..31] reserved.  The
+ *           max|q| / scale over slices of the two shadows, and that the first kernel resets); [16..31] reserved.  The
  *           caller zero-initialises the whole buffer.
  *     Weight scales start as the caller's (224 / max|W| at refresh).  Adam rewrites the fp8 shadows with the current
  *     scale; the first kernel of the next step, AFTER latching [5] / [6] from the scales the shadows were written
@@ -457,8 +469,13 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     work to each other: 1 (default) device-side sequence flags in the workspace buffer "ddp_flags" -- a one-wave kernel
  *     behind the producer publishes the step's number, a one-wave kernel in front of the consumer waits for it (~1.8 us
  *     per crossing; deadlock-free for any stream -> hardware-queue mapping because every waiter is enqueued after its
- *     setter; bounded at 100 ms, timeouts counted in ddp_flags[8], which must stay 0) -- or 0: HIP events (~9 us per
- *     crossing).  Steps enqueued under stream capture always use events (a graph needs the edges).
+ *     setter; every wait is bounded -- 5 s where the setter follows this device's own kernels, RV_OPT_DDP_WAIT_MS where
+ *     it follows a collective -- and timeouts are counted in ddp_flags[8], which must stay 0) -- or 0: HIP events (~9 us
+ *     per crossing).  Steps enqueued under stream capture always use events (a graph needs the edges).
+ *   RV_OPT_DDP_WAIT_MS  bound, in milliseconds, of a flag wait whose setter sits behind a collective, i.e. behind the
+ *     slowest peer rank (default 600000 = ten minutes, the order of a collective library's own watchdog: ranks reach a
+ *     step seconds apart around a checkpoint or an evaluation pass as a matter of course).  A wait that runs out is
+ *     counted in ddp_flags[8]; the step's results are then invalid and the host side must raise.
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider
@@ -468,7 +485,8 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     workgroups that take their CUs whole it runs in two rounds and loses (263 against 250) -- the default is the
  *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
  *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
-enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5 };
+enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5,
+       RV_OPT_DDP_WAIT_MS = 6 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and

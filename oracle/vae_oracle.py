@@ -120,7 +120,8 @@ def backward(params, c, kl_beta, quant=None, fp8_scales=None):
     quant="fp8" with fp8_scales (the forward's, plus "dp4"): the HIP path's fp8 backward of fc4 -- dP4 leaves the fc4
     forward's epilogue as fp8(dP4 * s_dp4) (from the fp32 value; the bias gradient is summed in fp32 before that), the
     dgrad multiplies it with fp8(W4 * s_w4), the wgrad with the fp8 image of h3 the fc3 forward wrote; everything else at
-    the bf16 rounding points.  quant="fp8" without fp8_scales: bf16 rounding points throughout (the forward-only mode)."""
+    the bf16 rounding points; with "dp1" as well, fc1's weight gradient on fp8 operands.  quant="fp8" without
+    fp8_scales: bf16 rounding points throughout (the forward-only mode)."""
     x, h1, mu, logvar, std, eps, z, h3, recon = (
         c[k] for k in ("x", "h1", "mu", "logvar", "std", "eps", "z", "h3", "recon"))
     B, S = x.shape
@@ -151,6 +152,14 @@ def backward(params, c, kl_beta, quant=None, fp8_scales=None):
     g["fc21.bias"] = dmu.sum(0)
     g["fc22.weight"] = dlv.T @ h1
     g["fc22.bias"] = dlv.sum(0)
+    if quant == "fp8" and fp8_scales is not None and "dp1" in fp8_scales:
+        # fc1's fp8 weight gradient (the full local step of the fp8 weight path): dP1 leaves the heads' backward as
+        # fp8(dP1 * s_dp1) from the fp32 value (fc1's bias gradient is summed in fp32 before that), the GEMM multiplies
+        # it with the fp8 image of x fc1's forward read
+        dP1f = (dmu @ W21 + dlv @ W22) * (h1 > 0)
+        g["fc1.weight"] = _q8(dP1f, fp8_scales["dp1"]).T @ _q8(x, fp8_scales["x"])
+        g["fc1.bias"] = dP1f.sum(0)
+        return g
     dP1 = _q((dmu @ W21 + dlv @ W22) * (h1 > 0), quant)
     g["fc1.weight"] = dP1.T @ xq
     g["fc1.bias"] = dP1.sum(0)

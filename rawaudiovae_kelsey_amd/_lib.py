@@ -39,7 +39,7 @@ class CommDesc(C.Structure):
                 ("msg_send", c_void_p), ("msg_recv", c_void_p), ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
 
 
-OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE = 0, 1, 2, 3, 4, 5
+OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE, OPT_DDP_WAIT_MS = 0, 1, 2, 3, 4, 5, 6
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
@@ -69,6 +69,7 @@ _SIGS = {
     "rv_colsum_partial": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_void_p, c_long, c_void_p]),
     "rv_ew_f32": (c_int, [c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "rv_scale_by": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "rv_scale_by3": (c_int, [c_void_p, c_void_p, c_long] * 3 + [c_void_p, c_void_p]),
     "rv_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long,
                               c_int, c_void_p, c_long, c_void_p]),
     "rv_linear_fp32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_int,
@@ -191,10 +192,24 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr(stream=None):
-    import torch
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return s.cuda_stream or None
+    """hipStream_t of `stream`, or of the current stream of the current device (None = the null stream).  The current
+    stream is read through torch's raw accessor: `torch.cuda.current_stream()` builds a Stream object per call, ~5 us
+    of host time on a path that is called several times per step."""
+    if stream is not None:
+        return stream.cuda_stream or None
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get_dev, get_raw = getattr(torch._C, "_cuda_getDevice", None), getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if get_dev is not None and get_raw is not None:
+            _raw_stream = lambda: get_raw(get_dev())   # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
+    return _raw_stream() or None
 
 
 def _gemm_plan(what, Mp, Np, Kp, splits_in):

@@ -362,9 +362,9 @@ struct AdamItem {
 
 // `vblock` must be wave-uniform (it is in both callers: a virtual block is 256 consecutive threads); the
 // readfirstlane makes that provable, so the descriptor is read with scalar loads instead of a per-lane loop.
-__device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long vblock, const int tid) {
+__device__ __forceinline__ AdamItem adam_locate(const DescTable& tab, const long vblock, const int tid, const long limit = -1) {
   AdamItem it{0, 0, 0, 0, 0};
-  if (vblock >= tab.blk_start[tab.n]) return it;
+  if (vblock >= (limit >= 0 ? limit : tab.blk_start[tab.n])) return it;   // (limit: the caller walks only a prefix of the table)
   int t = 0;
   while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
   t = __builtin_amdgcn_readfirstlane(t);
@@ -389,12 +389,12 @@ template <int U>
 __device__ __forceinline__ void adam_group(const DescTable& tab, const long vb0, const long vb_stride, const int tid,
                                            float* __restrict__ param, float* __restrict__ m_arena,
                                            float* __restrict__ v_arena, const float lr, const float grad_scale,
-                                           const long long* __restrict__ step_counter) {
+                                           const long long* __restrict__ step_counter, const long limit = -1) {
   AdamItem it[U];
   bool all_vec = true;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    it[u] = adam_locate(tab, vb0 + u * vb_stride, tid);
+    it[u] = adam_locate(tab, vb0 + u * vb_stride, tid, limit);
     all_vec = all_vec && it[u].state != 2;   // state 0 (past the end of the table) is skipped item by item
   }
   if (all_vec) {

@@ -57,8 +57,8 @@ __device__ __forceinline__ unsigned long long q8x8(const float (&v)[8], float sc
 // 32 floats of the state block proper (k_fp8_wmax below fills them behind the optimizer); they are reduced with every
 // load of a thread in flight at once and reset here.
 constexpr int FP8_WSLOTS = 1024;
-__device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_part, int n_amax) {
-  __shared__ float red[3][4];
+__device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_part, int n_amax, int n_amax2) {
+  __shared__ float red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* w_amax = st + 32;
   float a[FP8_WSLOTS / 256], b[FP8_WSLOTS / 256];
@@ -67,8 +67,9 @@ __device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_par
     a[k] = w_amax[tid + 256 * k];
     b[k] = w_amax[FP8_WSLOTS + tid + 256 * k];
   }
-  float m = 0.f, w1 = 0.f, w4 = 0.f;
+  float m = 0.f, w1 = 0.f, w4 = 0.f, g1 = 0.f;
   for (int i = tid; i < n_amax; i += 256) m = fmaxf(m, amax_part[i]);
+  for (int i = tid; i < n_amax2; i += 256) g1 = fmaxf(g1, amax_part[n_amax + i]);   // max|dP1| of the previous step
 #pragma unroll
   for (int k = 0; k < FP8_WSLOTS / 256; ++k) {
     w1 = fmaxf(w1, a[k]);
@@ -81,29 +82,49 @@ __device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_par
     m = fmaxf(m, __shfl_xor(m, o, 64));
     w1 = fmaxf(w1, __shfl_xor(w1, o, 64));
     w4 = fmaxf(w4, __shfl_xor(w4, o, 64));
+    g1 = fmaxf(g1, __shfl_xor(g1, o, 64));
   }
-  if (lane == 0) { red[0][wave] = m; red[1][wave] = w1; red[2][wave] = w4; }
+  if (lane == 0) { red[0][wave] = m; red[1][wave] = w1; red[2][wave] = w4; red[3][wave] = g1; }
   __syncthreads();
   if (tid == 0) {
     m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
     w1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
     w4 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-    st[4] = m;
-    if (st[7] == 0.f && m > 0.f) st[3] = 224.f / m;
-    st[5] = 1.f / (st[0] * st[1]);
-    st[6] = 1.f / (st[3] * st[2]);
-    // fp8 backward of fc4: dP4's image is written with the fixed scale st[12] (set by the caller: 112 / (2 / (B S)), so
-    // that |dP4| <= 2 * 2 / (B S) lands within +-224); the dgrad multiplies it with W4's shadow, the wgrad with h3's image
-    st[10] = 1.f / (st[12] * st[2]);
-    st[11] = 1.f / (st[12] * st[3]);
-    // the weight shadows read by this step were written with st[1] / st[2] (now inside st[5] / st[6]); the coming
-    // optimizer update quantises with scales that follow the weights it last saw
-    st[8] = w1;
-    st[9] = w4;
-    if (st[7] == 0.f) {
-      if (w1 > 0.f) st[1] = 224.f / w1;
-      if (w4 > 0.f) st[2] = 224.f / w4;
+    g1 = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+    // the whole block in registers first: read entry by entry between the writes below, every access would be a round
+    // trip of its own (the compiler cannot move a load of st[] over a store to st[]) -- ~4 us at the head of the step
+    float s[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(st)[k];
+      s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w;
     }
+    const bool live = s[7] == 0.f;
+    s[4] = m;
+    if (live && m > 0.f) s[3] = 224.f / m;
+    s[5] = 1.f / (s[0] * s[1]);
+    s[6] = 1.f / (s[3] * s[2]);
+    // fp8 backward of fc4: dP4's image is written with the fixed scale [12] (set by the caller: 112 / (2 / (B S)), so
+    // that |dP4| <= 2 * 2 / (B S) lands within +-224); the dgrad multiplies it with W4's shadow, the wgrad with h3's image
+    s[10] = 1.f / (s[12] * s[2]);
+    s[11] = 1.f / (s[12] * s[3]);
+    // fp8 weight gradient of fc1: the heads' backward writes dP1's image with [13], which follows the maximum it
+    // measured in the previous step (delayed scaling, as h3's); the GEMM multiplies it with x's image
+    if (n_amax2 > 0) {
+      s[14] = g1;
+      if (live && g1 > 0.f) s[13] = 224.f / g1;
+    }
+    s[15] = 1.f / (s[13] * s[0]);
+    // the weight shadows read by this step were written with [1] / [2] (now inside [5] / [6]); the coming optimizer
+    // update quantises with scales that follow the weights it last saw
+    s[8] = w1;
+    s[9] = w4;
+    if (live) {
+      if (w1 > 0.f) s[1] = 224.f / w1;
+      if (w4 > 0.f) s[2] = 224.f / w4;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(st)[k] = make_float4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
   }
 }
 
@@ -149,18 +170,24 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
                                                        long long* step_counter,
                                                        unsigned char* __restrict__ dst_fp8, long ld_fp8,
                                                        float* fp8_state, const float* __restrict__ fp8_scale,
-                                                       const float* __restrict__ amax_part, int n_amax,
+                                                       const float* __restrict__ amax_part, int n_amax, int n_amax2,
                                                        const long long* __restrict__ frame_idx, long first_frame,
                                                        long hop, long n_samples) {
   if (blockIdx.x == 0) {
     if (step_counter && threadIdx.x == 0) *step_counter += 1;
-    if (fp8_state) fp8_latch_block(fp8_state, amax_part, n_amax);
+    if (fp8_state) {
+      // with the fp8 state block the launch has one block more than the cast needs: this one only latches (a chain of
+      // dependent loads, a reduction and a write-back: ~2 us that would otherwise sit in front of a share of the cast)
+      fp8_latch_block(fp8_state, amax_part, n_amax, n_amax2);
+      return;
+    }
   }
   const float qs = dst_fp8 ? *fp8_scale : 0.f;   // the x / weight scale is constant across the latch
   const long cpr = cols_p / 8;
   const long total = rows_p * cpr;
   const bool vec_ok = (ld_src % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const long blk = fp8_state ? (long)blockIdx.x - 1 : (long)blockIdx.x, nblk = fp8_state ? (long)gridDim.x - 1 : (long)gridDim.x;
+  for (long i = blk * 256 + threadIdx.x; i < total; i += nblk * 256) {
     const unsigned r32 = (unsigned)i / (unsigned)cpr;   // total < 2^31 (checked by the launchers)
     const long r = r32, c = (long)((unsigned)i - r32 * (unsigned)cpr) * 8;
     float v[8];
@@ -540,6 +567,32 @@ k_scale_by(const float* __restrict__ a, const float* __restrict__ scalar, long n
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * g;
 }
 
+// The same for up to three tensors in ONE launch (the three gradients loss_function's backward hands on: d_recon,
+// d_mu, d_logvar): the API path is bound by host time per launch, not by these bytes.
+__device__ __forceinline__ void scale_span(const float* __restrict__ a, float* __restrict__ out, long n, float g) {
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  if ((((uintptr_t)a | (uintptr_t)out) & 15) == 0) {
+    const long n4 = n >> 2;
+    for (long i = i0; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(a)[i];
+      v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+      reinterpret_cast<float4*>(out)[i] = v;
+    }
+    for (long i = (n4 << 2) + i0; i < n; i += stride) out[i] = a[i] * g;
+  } else {
+    for (long i = i0; i < n; i += stride) out[i] = a[i] * g;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_scale_by3(const float* __restrict__ a0, float* __restrict__ o0, long n0, const float* __restrict__ a1,
+            float* __restrict__ o1, long n1, const float* __restrict__ a2, float* __restrict__ o2, long n2,
+            const float* __restrict__ scalar) {
+  const float g = scalar[0];
+  if (n0) scale_span(a0, o0, n0, g);
+  if (n1) scale_span(a1, o1, n1, g);
+  if (n2) scale_span(a2, o2, n2, g);
+}
+
 // ------------------------------------------------------------------ hop-strided framing (N1)
 // frame i = audio[idx[i]*hop : idx[i]*hop + S]  (AudioDataset.__getitem__, dataset.py:108-118;
 // idx == NULL -> consecutive frames first_frame + i).  The waveform stays resident in HBM;
@@ -742,7 +795,7 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
   RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
-                     (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                     (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0,
                      (const long long*)nullptr, 0L, 0L, 0L);
   RV_CHECK_LAUNCH();
   return RV_OK;
@@ -750,38 +803,39 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
 
 int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst, long rows_p, long cols_p,
                         long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part, int n_amax,
-                        long long* step_counter, void* stream) {
-  RV_REQUIRE(src && dst, RV_ERR_NULL, "rv_cast_pad_bf16_q8: null pointer");
+                        int n_amax2, long long* step_counter, void* stream) {
+  RV_REQUIRE(src && (dst || dst_fp8), RV_ERR_NULL, "rv_cast_pad_bf16_q8: null pointer");
   RV_REQUIRE(rows >= 0 && cols >= 0 && rows <= rows_p && cols <= cols_p && cols_p % 8 == 0 && ld_src >= cols &&
-                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst & 15) == 0,
+                 (!dst || (ld_dst >= cols_p && ld_dst % 8 == 0)) && ((uintptr_t)dst & 15) == 0,
              RV_ERR_SHAPE, "rv_cast_pad_bf16_q8: bad extents %ld %ld -> %ld %ld (ld %ld)", rows, cols, rows_p, cols_p, ld_dst);
   RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_cast_pad_bf16_q8: the fp8 output needs the state block and 8-byte aligned rows");
   const long total = rows_p * (cols_p / 8);
   RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
-  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192) + (fp8_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state /* [0] = scale of x */,
-                     amax_part, amax_part ? n_amax : 0, (const long long*)nullptr, 0L, 0L, 0L);
+                     amax_part, amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, (const long long*)nullptr, 0L, 0L, 0L);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
 
 int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame, long n_frames,
                           long S, long hop, void* dst_bf16, long rows_p, long cols_p, long ld_dst, void* dst_fp8, long ld_fp8,
-                          float* fp8_state, const float* amax_part, int n_amax, long long* step_counter, void* stream) {
-  RV_REQUIRE(audio && dst_bf16, RV_ERR_NULL, "rv_gather_cast_frames: null pointer");
+                          float* fp8_state, const float* amax_part, int n_amax, int n_amax2, long long* step_counter,
+                          void* stream) {
+  RV_REQUIRE(audio && (dst_bf16 || dst_fp8), RV_ERR_NULL, "rv_gather_cast_frames: null pointer");
   RV_REQUIRE(n_samples > 0 && n_frames >= 0 && S > 0 && hop > 0 && n_frames <= rows_p && S <= cols_p && cols_p % 8 == 0 &&
-                 ld_dst >= cols_p && ld_dst % 8 == 0 && ((uintptr_t)dst_bf16 & 15) == 0,
+                 (!dst_bf16 || (ld_dst >= cols_p && ld_dst % 8 == 0)) && ((uintptr_t)dst_bf16 & 15) == 0,
              RV_ERR_SHAPE, "rv_gather_cast_frames: bad extents %ld frames of %ld -> %ld x %ld", n_frames, S, rows_p, cols_p);
   RV_REQUIRE(!dst_fp8 || (fp8_state && ld_fp8 >= cols_p && ld_fp8 % 8 == 0 && ((uintptr_t)dst_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_gather_cast_frames: the fp8 output needs the state block and 8-byte aligned rows");
   const long total = rows_p * (cols_p / 8);
   RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
-  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192) + (fp8_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
                      audio, n_frames, S, 0L, (bf16_t*)dst_bf16, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state, amax_part,
-                     amax_part ? n_amax : 0, frame_index, first_frame, hop, n_samples);
+                     amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, frame_index, first_frame, hop, n_samples);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -806,7 +860,7 @@ int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* d
   RV_REQUIRE(total < 0x7fffffffL, RV_ERR_SHAPE, "cast: %ld x %ld is too large for one launch", rows_p, cols_p);
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)nullptr, rows_p, cols_p, ld_dst, (long long*)nullptr,
-                     (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0,
+                     (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0, 0,
                      (const long long*)nullptr, 0L, 0L, 0L);
   RV_CHECK_LAUNCH();
   return RV_OK;
@@ -941,17 +995,20 @@ int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* 
 // a sequence number; k_flag_wait sits in the consumer stream IN FRONT of the consuming kernel and returns when the
 // number has arrived.  Deadlock-free by construction whatever the runtime's stream -> hardware-queue mapping is: every
 // waiter is enqueued (host order) after its setter, so the oldest unfinished kernel over all queues never waits on
-// anything unfinished.  The wait is bounded all the same (100 ms): a timeout is counted in `timeouts` and the engine
-// raises when it sees a non-zero count (results of that step are invalid).
+// anything unfinished ON THIS DEVICE.  The wait is bounded all the same: `max_ticks` of the 100 MHz wall clock, chosen by
+// the caller per edge -- seconds for an edge whose setter follows this device's own kernels, minutes (the order of a
+// collective library's own watchdog) for an edge whose setter sits behind a collective, i.e. behind the slowest PEER:
+// ranks reach a step tens of milliseconds apart as a matter of course and seconds apart around a checkpoint.  A
+// timeout is counted in `timeouts` and the engine raises when it sees a non-zero count (that step's results are invalid).
 __global__ void __launch_bounds__(64) k_flag_set(int* flag, int value) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void __launch_bounds__(64) k_flag_wait(const int* flag, int value, int* timeouts) {
+__global__ void __launch_bounds__(64) k_flag_wait(const int* flag, int value, int* timeouts, long long max_ticks) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();   // 100 MHz
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value < 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > 10000000LL) {
+      if (wall_clock64() - t0 > max_ticks) {
         atomicAdd(timeouts, 1);
         break;
       }
@@ -964,8 +1021,9 @@ int rv_flag_set(int* flag, int value, void* stream) {
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
-int rv_flag_wait(const int* flag, int value, int* timeouts, void* stream) {
-  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timeouts);
+int rv_flag_wait(const int* flag, int value, int* timeouts, long max_ms, void* stream) {
+  hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timeouts,
+                     (long long)(max_ms < 1 ? 1 : max_ms) * 100000LL);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -974,6 +1032,19 @@ int rv_scale_by(const float* a, const float* scalar, long n, float* out, void* s
   RV_REQUIRE(a && scalar && out, RV_ERR_NULL, "rv_scale_by: null pointer");
   if (n == 0) return RV_OK;
   hipLaunchKernelGGL(k_scale_by, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, scalar, n, out);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
+int rv_scale_by3(const float* a0, float* out0, long n0, const float* a1, float* out1, long n1, const float* a2,
+                 float* out2, long n2, const float* scalar, void* stream) {
+  RV_REQUIRE(scalar, RV_ERR_NULL, "rv_scale_by3: null scalar");
+  RV_REQUIRE(n0 >= 0 && n1 >= 0 && n2 >= 0 && (!n0 || (a0 && out0)) && (!n1 || (a1 && out1)) && (!n2 || (a2 && out2)),
+             RV_ERR_NULL, "rv_scale_by3: a tensor with a non-zero count needs both pointers");
+  const long nmax = n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2);
+  if (nmax == 0) return RV_OK;
+  hipLaunchKernelGGL(k_scale_by3, dim3(grid_for((nmax + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a0, out0, n0, a1, out1,
+                     n1, a2, out2, n2, scalar);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -105,15 +105,26 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
 // block of a launch gets the same dynamic LDS, so an optimizer block cannot share a CU with a GEMM block: the
 // optimizer blocks take the CUs the GEMM does not fill.  (Two streams instead cost a 6 us bubble per event
 // record on this runtime and slowed the co-running GEMMs by more than was hidden: profiles/r02_sched2_*.)
-template <int NSTAGE>
+template <int NSTAGE, bool FP8 = false>
 __global__ void __launch_bounds__(512)
 gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable tab, float* __restrict__ param,
                        float* __restrict__ m_arena, float* __restrict__ v_arena, const float lr,
                        const float grad_scale, const long long* __restrict__ step_counter, const int stream_mode,
-                       float* __restrict__ fin_f32, bf16_t* __restrict__ fin_bf16) {
+                       float* __restrict__ fin_f32, bf16_t* __restrict__ fin_bf16, const int tail_vb) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   if ((int)blockIdx.x < n_gemm) {
-    gemm_body<256, 256, 2, 4, false, false, EPI_F32, NSTAGE>(wgrad, blockIdx.x, smem_dyn);
+    gemm_body<256, 256, 2, 4, false, false, EPI_F32, NSTAGE, FP8>(wgrad, blockIdx.x, smem_dyn);
+    if (tail_vb > 0) {
+      // The LAST `tail_vb` virtual blocks of the riders' table are left to the GEMM blocks: when its tile is done, every
+      // wave takes quarters of them (a virtual block is 256 threads that do not talk to each other).  A static share, sized
+      // by the host so that both kinds of block finish together -- where the GEMM is the shorter half of the launch (fp8
+      // operands) its CUs would otherwise idle while the riders stream on at their per-CU rate.
+      const long total = tab.blk_start[tab.n];
+      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+      for (long u = (long)blockIdx.x * 8 + wave; u < 4L * tail_vb; u += 8L * n_gemm)
+        adam_block<true>(tab, total - tail_vb + (u >> 2), (int)(u & 3) * 64 + lane, param, m_arena, v_arena, nullptr, lr,
+                         grad_scale, step_counter, nullptr, nullptr);
+    }
   } else {
     if (fin_f32 || fin_bf16) {
       // riders that only SUM the slabs of the table's tensors into a flat gradient payload (rv_grad_finalize's work;
@@ -132,12 +143,12 @@ gemm_wgrad_adam_kernel(const GemmArgs wgrad, const int n_gemm, const DescTable t
                   (int)(threadIdx.x & 63), param, m_arena, v_arena, lr, grad_scale, step_counter);
       return;
     }
-    const long total = tab.blk_start[tab.n];
+    const long total = tab.blk_start[tab.n] - tail_vb;     // (the rest is the GEMM blocks' share, above)
     const long stride = 2L * ((long)gridDim.x - n_gemm);   // virtual blocks taken per sweep of the optimizer blocks
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // wave-uniform
     constexpr int U = 2;   // virtual blocks in flight per thread (4 measured 0.6 us slower: more registers, same bytes/s)
     for (long vb = 2L * ((long)blockIdx.x - n_gemm) + half; vb < total; vb += U * stride)
-      adam_group<U>(tab, vb, stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter);
+      adam_group<U>(tab, vb, stride, (int)(threadIdx.x & 255), param, m_arena, v_arena, lr, grad_scale, step_counter, total);
   }
 }
 
@@ -475,13 +486,19 @@ int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits) {   // (plan.hip's
 
 }  // extern "C" (the rider launchers below carry their own linkage)
 
+constexpr int TAIL_PCT_BF16 = 0, TAIL_PCT_FP8 = 15;   // C2 sweep: bf16 176 us per step at 0, 178-182 above; fp8 163 at 0, 158 from 12 to 22
 static int wgrad_riders(const char* who, const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,
                         void* dw, long lddw, int slab_dtype, float* slab_unscale, const rv_param_desc* descs, int n_desc,
                         float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
-                        const long long* step_counter, float* fin_f32, bf16_t* fin_bf16, int n_rider_blocks, void* stream) {
-  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % 64 == 0 && splits >= 1 &&
-                 (Kp / 64) % splits == 0, RV_ERR_SHAPE,
-             "%s: %ld x %ld x %ld / %d splits does not tile by 256x256x64", who, Mp, Np, Kp, splits);
+                        const long long* step_counter, float* fin_f32, bf16_t* fin_bf16, int n_rider_blocks, void* stream,
+                        const float* fp8_dq = nullptr) {
+  const bool fp8 = fp8_dq != nullptr;   // operands are e4m3 bytes (leading dims in bytes), K tiles 128 deep, ping-pong loop only
+  const long kt = fp8 ? 128 : 64;
+  RV_REQUIRE(Mp > 0 && Np > 0 && Kp > 0 && Mp % 256 == 0 && Np % 256 == 0 && Kp % kt == 0 && splits >= 1 &&
+                 (Kp / kt) % splits == 0, RV_ERR_SHAPE,
+             "%s: %ld x %ld x %ld / %d splits does not tile by 256x256x%ld", who, Mp, Np, Kp, splits, kt);
+  RV_REQUIRE(!fp8 || ((Kp / kt / splits) % 2 == 0 && lddy % 16 == 0 && ldx % 16 == 0), RV_ERR_SHAPE,
+             "%s: fp8 operands need an even number of 128-deep K tiles per split and leading dims that are multiples of 16 bytes", who);
   RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, RV_ERR_SHAPE,
              "%s: operands must be 16-byte aligned with leading dims multiples of 8", who);
   RV_REQUIRE(n_rider_blocks >= 1 && n_rider_blocks <= 4096, RV_ERR_SHAPE, "%s: %d rider blocks", who, n_rider_blocks);
@@ -489,8 +506,8 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
   int rc = adam_build_table(descs, n_desc, &tab);
   if (rc) return rc;
   GemmArgs g{};
-  g.A = (const bf16_t*)dy; g.lda = lddy; g.B = (const bf16_t*)x; g.ldb = ldx;
-  g.k_tiles = (int)(Kp / 64 / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np;
+  g.A = (const bf16_t*)dy; g.lda = fp8 ? lddy / 2 : lddy; g.B = (const bf16_t*)x; g.ldb = fp8 ? ldx / 2 : ldx;
+  g.k_tiles = (int)(Kp / kt / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np; g.dq = fp8_dq;
   rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
   g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.wt = rv_store_wt;
@@ -501,17 +518,39 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
   int stream_mode = 1;
   for (int i = 0; i < n_desc; ++i)
     if (descs[i].grad_half) stream_mode = 0;
+  // Share of the riders' table the GEMM blocks take over behind their tiles (percent of its virtual blocks; update mode
+  // with plain-load riders only).  The riders stream at a per-CU rate whatever the GEMM does, so the share is what evens
+  // the two halves out: measured per operand type at C2; RV_WGRAD_TAIL_PCT overrides.
+  int tail_vb = 0;
+  if (!fin_f32 && !fin_bf16 && !stream_mode) {
+    static const int env_pct = [] { const char* e = getenv("RV_WGRAD_TAIL_PCT"); return e ? atoi(e) : -1; }();
+    const int pct = env_pct >= 0 ? (env_pct > 50 ? 50 : env_pct) : (fp8 ? TAIL_PCT_FP8 : TAIL_PCT_BF16);
+    tail_vb = (int)(tab.blk_start[n_desc] * pct / 100);
+  }
   const bool pp = g.k_tiles % 2 == 0;
-  auto kern = pp ? gemm_wgrad_adam_kernel<8> : gemm_wgrad_adam_kernel<2>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[pp]) {
+  const int which = fp8 ? 2 : (pp ? 1 : 0);
+  auto kern = fp8 ? gemm_wgrad_adam_kernel<8, true> : (pp ? gemm_wgrad_adam_kernel<8, false> : gemm_wgrad_adam_kernel<2, false>);
+  static bool attr_done[3] = {false, false, false};
+  if (!attr_done[which]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done[pp] = true;
+    attr_done[which] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_rider_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
-                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode, fin_f32, fin_bf16);
+                     param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode, fin_f32, fin_bf16, tail_vb);
   RV_CHECK_LAUNCH();
   return RV_OK;
+}
+
+// rv_linear_wgrad_adam on fp8 (e4m3) operands (RV_OPT_FP8 = 1; plan.hip): dy_fp8 [Kp(batch), Mp] and x_fp8 [Kp, Np], one
+// byte per element, both read MN-major through ds_read_b64_tr_b8 (the contraction index is the row of both matrices);
+// dq: device scalar 1 / (scale_dy * scale_x).  Same slabs, riders and launch shape.  Not in the public header.
+extern "C" int rv_linear_wgrad_adam_fp8(const void* dy_fp8, long lddy, const void* x_fp8, long ldx, const float* dq, long Mp, long Np,
+                             long Kp, int splits, void* dw, long lddw, int slab_dtype, float* slab_unscale,
+                             const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq, float lr,
+                             float grad_scale, const long long* step_counter, int n_adam_blocks, void* stream) {
+  RV_REQUIRE(dy_fp8 && x_fp8 && dq && dw && param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_linear_wgrad_adam_fp8: null pointer");
+  return wgrad_riders("rv_linear_wgrad_adam_fp8", dy_fp8, lddy, x_fp8, ldx, Mp, Np, Kp, splits, dw, lddw, slab_dtype, slab_unscale, descs,
+                      n_desc, param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, nullptr, nullptr, n_adam_blocks, stream, dq);
 }
 
 extern "C" int rv_linear_wgrad_adam(const void* dy, long lddy, const void* x, long ldx, long Mp, long Np, long Kp, int splits,

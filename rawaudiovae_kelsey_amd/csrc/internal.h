@@ -13,15 +13,16 @@ RV_INTERNAL int rv_wgrad_adam_fits(long Mp, long Np, long Kp, int splits);
 
 // rv_cast_pad_bf16 that also writes the fp8 operand (dst_fp8 may be NULL) and, when `fp8_state` is given, latches the
 // delayed activation scale for this step in its first wave from the previous step's per-block maxima
-// `amax_part[n_amax]` (state block layout: RV_OPT_FP8 in the public header).
+// `amax_part[n_amax]` (state block layout: RV_OPT_FP8 in the public header), and dP1's scale likewise from the
+// `n_amax2` maxima that follow them (rv_heads_bwd_ex; 0 = none).  dst_bf16 may be NULL when dst_fp8 is given.
 RV_INTERNAL int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long rows_p,
                                     long cols_p, long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state,
-                                    const float* amax_part, int n_amax, long long* step_counter, void* stream);
+                                    const float* amax_part, int n_amax, int n_amax2, long long* step_counter, void* stream);
 // The same from hop-strided frames of a resident fp32 waveform (rv_gather_frames + the cast in one kernel).
 RV_INTERNAL int rv_gather_cast_frames(const float* audio, long n_samples, const long long* frame_index, long first_frame,
                                       long n_frames, long S, long hop, void* dst_bf16, long rows_p, long cols_p,
                                       long ld_dst, void* dst_fp8, long ld_fp8, float* fp8_state, const float* amax_part,
-                                      int n_amax, long long* step_counter, void* stream);
+                                      int n_amax, int n_amax2, long long* step_counter, void* stream);
 // rv_linear_fwd with every optional output of a bias/ReLU forward GEMM (NULL = not wanted): the output also as
 // fp8(y * *q_scale) (the next layer's fp8 operand) and max|y| of every block in amax_part[block], from which the next
 // step derives its scale (delayed scaling).
@@ -64,13 +65,23 @@ RV_INTERNAL int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf
 // Device-side cross-stream signalling (elementwise.hip): publish `value` behind the stream's earlier work / hold the
 // stream until the flag has reached `value` (bounded; timeouts are counted in *timeouts).
 RV_INTERNAL int rv_flag_set(int* flag, int value, void* stream);
-RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, void* stream);
+RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, long max_ms, void* stream);
 // rv_linear_wgrad_adam's launch shape (256 x 256 weight-gradient GEMM + rider blocks on the idle CUs) whose riders sum
 // the gradient slabs of `descs` into a flat payload arena instead of updating them (gemm_launch.hip).
 RV_INTERNAL int rv_linear_wgrad_finalize(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,
                                          int splits, void* dw_slabs, long lddw, int slab_dtype, float* slab_unscale,
                                          const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16,
                                          int n_rider_blocks, void* stream);
+// fc1's weight gradient + optimizer riders on fp8 operands (gemm_launch.hip), and the heads' backward that writes its
+// fp8 left operand (latent.hip).
+RV_INTERNAL int rv_linear_wgrad_adam_fp8(const void* dy_fp8, long lddy, const void* x_fp8, long ldx, const float* dq, long Mp,
+                                         long Np, long Kp, int splits, void* dw, long lddw, int slab_dtype, float* slab_unscale,
+                                         const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                                         float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
+                                         int n_adam_blocks, void* stream);
+RV_INTERNAL int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp,
+                                long Hp, long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw,
+                                void* dp1_fp8, long ldq, const float* q_scale, float* amax_part, void* stream);
 // The paired fc4 backward on fp8 operands (gemm_launch.hip) and whether the extents allow it.
 RV_INTERNAL int rv_dgrad_wgrad_fp8_fits(long Mp, long Np, long Kp, int splits);
 RV_INTERNAL int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,

@@ -511,11 +511,16 @@ __global__ void __launch_bounds__(512)
 k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, const long ldw,
             const bf16_t* __restrict__ h1, const long ldh, bf16_t* __restrict__ dP1, const long ldp,
             float* __restrict__ db1_partial, float* __restrict__ dwh_slabs, const long lddw, const long Hp,
-            const int wt) {
+            const int wt, unsigned char* __restrict__ dP1q, const long ldq, const float* __restrict__ q_scale,
+            float* __restrict__ amax_part) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   lds_char* smem = (lds_char*)smem_dyn;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  // fp8 weight path (RV_OPT_FP8 = 1): dP1 also -- or only, when dP1 is NULL -- as fp8(dP1 * *q_scale), the MN-major
+  // operand of fc1's fp8 weight gradient; max|dP1| of every wave's outputs for next step's scale (delayed scaling)
+  const float qs = dP1q ? *q_scale : 0.f;
+  float amax = 0.f;
   const int q = lane >> 4, j = lane & 15;
   const int nstrips = (int)(Hp / 64);
   const int g = (int)blockIdx.x / nstrips, cs_ = (int)blockIdx.x - g * nstrips;
@@ -637,10 +642,23 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
         lo[e] = a_;
         hi[e] = b_;
       }
-      const bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-      bf16_t* out = dP1 + (r_base + (long)HB_TR * t + r) * ldp + c0;
-      store_out16((bf16x8*)(out + (2 * cp + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
+      const long orow = r_base + (long)HB_TR * t + r;
+      const int ocol = (2 * cp + (q & 1)) * 16 + (q >> 1) * 8;
+      if (dP1) {
+        const bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                          (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+        store_out16((bf16x8*)(dP1 + orow * ldp + c0 + ocol), o, wt);
+      }
+      if (dP1q || amax_part) {
+        float q8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          amax = fmaxf(amax, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+          q8[e] = lo[e] * qs;
+          q8[4 + e] = hi[e] * qs;
+        }
+        if (dP1q) *(unsigned long long*)(dP1q + orow * ldq + c0 + ocol) = pack_fp8x8(q8);
+      }
     }
   }
   // ---- dWh slab of this row group
@@ -671,6 +689,11 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (db1_partial && tid < 64) db1_partial[(long)g * Hp + c0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+  if (amax_part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) amax_part[blockIdx.x * 8 + wave] = amax;
+  }
 }
 
 }  // namespace
@@ -761,14 +784,28 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
 
 int rv_heads_bwd(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp, long Hp,
                  long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* stream) {
-  RV_REQUIRE(dmulv_bf16 && wh_bf16 && h1_bf16 && dp1_bf16 && dwh_slabs, RV_ERR_NULL, "rv_heads_bwd: null pointer");
+  RV_REQUIRE(dp1_bf16, RV_ERR_NULL, "rv_heads_bwd: null pointer");
+  return rv_heads_bwd_ex(dmulv_bf16, wh_bf16, ldw, h1_bf16, ldh, Bp, Hp, Lp, dp1_bf16, ldp, db1_partial, dwh_slabs, lddw, nullptr,
+                         0, nullptr, nullptr, stream);
+}
+
+// rv_heads_bwd with the fp8 weight path's extra outputs (NULL = not wanted): dP1 also as fp8(dP1 * *q_scale) in
+// dp1_fp8 [Bp, ldq bytes] -- then dp1_bf16 may be NULL -- and max|dP1| of every wave's outputs in
+// amax_part[8 * (Bp / 512) * (Hp / 64)].
+int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp, long Hp,
+                    long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* dp1_fp8, long ldq,
+                    const float* q_scale, float* amax_part, void* stream) {
+  RV_REQUIRE(dmulv_bf16 && wh_bf16 && h1_bf16 && (dp1_bf16 || dp1_fp8) && dwh_slabs, RV_ERR_NULL, "rv_heads_bwd: null pointer");
+  RV_REQUIRE(!dp1_fp8 || (q_scale && ldq >= Hp && ldq % 16 == 0 && ((uintptr_t)dp1_fp8 & 15) == 0), RV_ERR_SHAPE,
+             "rv_heads_bwd: the fp8 output needs a scale and 16-byte aligned rows");
   RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_heads_bwd: built for a padded latent width of 64 (got %ld)", Lp);
   RV_REQUIRE(Bp > 0 && Bp % HB_RG == 0 && Hp > 0 && Hp % 64 == 0, RV_ERR_UNSUPPORTED,
              "rv_heads_bwd: the padded batch must be a multiple of 512 and the padded hidden width of 64 (got %ld, %ld)", Bp, Hp);
-  RV_REQUIRE(ldw >= Hp && ldh >= Hp && ldp >= Hp && lddw >= Hp && ldw % 8 == 0 && ldh % 8 == 0 && ldp % 8 == 0 && lddw % 4 == 0,
+  RV_REQUIRE(ldw >= Hp && ldh >= Hp && lddw >= Hp && ldw % 8 == 0 && ldh % 8 == 0 && lddw % 4 == 0,
              RV_ERR_SHAPE, "rv_heads_bwd: bad leading dimensions");
   RV_REQUIRE((((uintptr_t)dmulv_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)h1_bf16 | (uintptr_t)dp1_bf16 | (uintptr_t)dwh_slabs) & 15) == 0,
              RV_ERR_SHAPE, "rv_heads_bwd: operands must be 16-byte aligned");
+  RV_REQUIRE(!dp1_bf16 || (ldp >= Hp && ldp % 8 == 0), RV_ERR_SHAPE, "rv_heads_bwd: bad leading dimension of dP1");
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
@@ -776,7 +813,7 @@ int rv_heads_bwd(const void* dmulv_bf16, const void* wh_bf16, long ldw, const vo
   }
   hipLaunchKernelGGL(k_heads_bwd, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
-                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt);
+                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -113,9 +113,12 @@ struct rv_plan {
   unsigned short* msg_recv = nullptr;
   hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (RV_OPT_FP8)
-  int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax"
+  int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax" for h3's maxima
+  int n_amax_dp1 = 0;          // ... and for dP1's behind them (fp8 weight gradient of fc1)
+  int n_amax_h3 = 0;           // how many of h3's the forward in use writes (set by the forward phase)
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
+  long ddp_wait_ms = 600000;   // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
   int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
   int ddp_w1_wide = 0;
   int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
@@ -254,10 +257,12 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("W4q", Sp * Hp);
   p->add("h3q", Bp * Hp);
   p->add("dP4q", Bp * Sp);        // fp8 image of dP4: the fp8 fc4 backward's operand (RV_OPT_FP8 = 1)
+  p->add("dP1q", Bp * Hp);        // fp8 image of dP1: left operand of fc1's fp8 weight gradient (RV_OPT_FP8 = 1)
   p->add("fp8_state", (32 + 2 * 1024) * 4);   // 16 state floats (+16 pad), then 2 x 1024 max|W| slots
   // per-wave (fused latent forward: 8 per 16 batch rows) or per-tile max|h3| of the fc3 forward (zero until it has run)
   p->n_amax_cap = (int)(Bp / 2 > 4096 ? Bp / 2 : 4096);
-  p->add("h3_amax", (long)p->n_amax_cap * 4);
+  p->n_amax_dp1 = Bp % 512 == 0 ? (int)(8 * (Bp / 512) * (Hp / 64)) : 0;   // one maximum per wave of rv_heads_bwd_ex
+  p->add("h3_amax", ((long)p->n_amax_cap + p->n_amax_dp1) * 4);            // h3's maxima, then dP1's right behind them
   p->add("ddp_flags", 64 * 4);   // data-parallel step: cross-stream sequence flags [0..3], timeout counter [8]
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
@@ -351,6 +356,10 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
     case RV_OPT_DDP_SIGNAL: p->ddp_signal = value ? 1 : 0; return RV_OK;
     case RV_OPT_DDP_W1_WIDE: p->ddp_w1_wide = value ? 1 : 0; return RV_OK;
+    case RV_OPT_DDP_WAIT_MS:
+      RV_REQUIRE(value >= 1, RV_ERR_SHAPE, "rv_plan_set_option: RV_OPT_DDP_WAIT_MS must be at least 1 (got %d)", value);
+      p->ddp_wait_ms = value;
+      return RV_OK;
     case RV_OPT_ROCTX:
       RV_REQUIRE(!value || roctx_load(), RV_ERR_UNSUPPORTED, "rv_plan_set_option: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) could be loaded");
       p->roctx = value ? 1 : 0;
@@ -482,6 +491,15 @@ static bool fp8_bwd(const rv_plan* p) {
 static bool fp8_bwd_possible(const rv_plan* p) {   // (at forward time: which images of dP4 to write)
   return p->fp8 == 1 && rv_dgrad_wgrad_fp8_fits(p->Bp, p->Hp, p->Sp, p->s_w4);
 }
+// fc1's weight gradient on fp8 operands (RV_OPT_FP8 = 1), in the full local step only (the launch that also carries the
+// optimizer riders): the heads' streaming backward writes dP1 as fp8 (its scale follows the maximum it measured in the
+// previous step), the frames' fp8 image is the one fc1's forward read, and neither bf16 copy is written.
+static bool latent_bwd_fused(const rv_plan* p);
+static bool fp8_w1(const rv_plan* p, bool full_local) {
+  return p->fp8 == 1 && full_local && latent_bwd_fused(p) && heads_streaming(p) && p->n_amax_dp1 > 0 &&
+         rv_wgrad_adam_fits(p->Hp, p->Sp, p->Bp, p->s_w1) && (p->Hp / 256) * (p->Sp / 256) * p->s_w1 <= 192 &&
+         p->Bp % (128L * p->s_w1) == 0 && (p->Bp / 128 / p->s_w1) % 2 == 0 && p->Hp % 16 == 0 && p->Sp % 16 == 0;
+}
 static int fc4_backward(rv_plan* p, void* stream) {
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
   if (fp8_bwd(p)) {
@@ -501,7 +519,7 @@ static int fc4_backward(rv_plan* p, void* stream) {
 static bool latent_bwd_fused(const rv_plan* p) { return p->latent_fused && p->Lp == 64 && p->Hp % 512 == 0 && p->Hp <= 2048; }
 
 static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, const float* dmu_ext, const float* dlv_ext,
-                            void* stream) {
+                            void* stream, bool f8_w1 = false) {
   const long Bp = p->Bp, Hp = p->Hp, Lp = p->Lp, L2p = 2 * p->Lp, B = p->B, L = p->L, S = p->S;
   void* dP3 = p->ws("dP3"); void* z = p->ws("z"); void* h1 = p->ws("h1"); void* dP1 = p->ws("dP1"); void* dmulv = p->ws("dmulv");
   float* mulv = (float*)p->ws("mulv"); float* dz_slabs = (float*)p->ws("dz_slabs");
@@ -516,6 +534,11 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
       if (rc) return rc;
     }
     if (!do_heads) return RV_OK;
+    if (f8_w1) {   // dP1 as fp8 only, its maxima behind h3's (fp8_w1)
+      float* f8 = (float*)p->ws("fp8_state");
+      return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, nullptr, 0, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
+                             p->ws("dP1q"), Hp, f8 + 13, (float*)p->ws("h3_amax") + p->n_amax_h3, stream);
+    }
     if (heads_streaming(p))
       return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
                           stream);
@@ -550,6 +573,9 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   int rc;
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
 #define RV_K(k, call) do { if (!(p->skip >> (k) & 1)) RV_TRY(call); } while (0)   /* launch k of the step (rv_plan_diag_skip) */
+  const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
+                              (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
+                          !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
   if (phases & RV_PHASE_FWD) {
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step: x is null");
     Range range_fwd(p->roctx, "rv:fwd");
@@ -557,6 +583,9 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // fp8 backward of fc4: the forward writes dP4 as fp8 (dP4q) INSTEAD of bf16 (a caller that then supplies its own
     // gradients gets its bf16 dP4 from rv_tanh_bwd_pack)
     const bool f8_bwd = fp8_bwd_possible(p);
+    const bool f8_w1 = fp8_w1(p, full_local);     // then nothing reads the frames' bf16 copy: it is not written
+    void* xb_out = f8_w1 ? nullptr : xb;
+    const int n_amax2 = f8_w1 ? p->n_amax_dp1 : 0;
     int n_amax = 0;
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
     const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048;
@@ -569,6 +598,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       n_amax = (int)((Bp / bm3) * (Hp / bn3));
       RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_SHAPE, "rv_plan_step: fp8 path supports up to %d fc3 output tiles (got %d)", p->n_amax_cap, n_amax);
     }
+    p->n_amax_h3 = n_amax;
     // in place only when the padded frame length IS the frame length: with S < Sp the loader's columns S..Sp would be
     // the samples that follow the frame instead of zeros (harmless to fc1, whose weight columns there are zero, but
     // they would reach the framed copy and with it fc1's weight gradient and the exponents of its fp16 slabs)
@@ -579,9 +609,9 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                   Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, xb, Sp, p->b.step_counter, stream));
     } else if (p->fr_hop) {
       // frames come straight from the resident waveform: waveform -> bf16 (and fp8) operand in one kernel
-      RV_K(0, rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb, Bp, Sp, Sp,
+      RV_K(0, rv_gather_cast_frames(x, p->fr_nsamples, p->fr_idx, p->fr_first, B, S, p->fr_hop, xb_out, Bp, Sp, Sp,
                                    p->fp8 ? p->ws("xq") : nullptr, Sp, p->fp8 ? f8 : nullptr, (float*)p->ws("h3_amax"), n_amax,
-                                   p->b.step_counter, stream));
+                                   n_amax2, p->b.step_counter, stream));
       if (p->fp8)
         RV_K(1, rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
                                  h1, Hp, stream));
@@ -589,8 +619,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
         RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     } else if (p->fp8) {
-      RV_K(0, rv_cast_pad_bf16_q8(x, B, S, S, xb, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
-                                 p->b.step_counter, stream));
+      RV_K(0, rv_cast_pad_bf16_q8(x, B, S, S, xb_out, Bp, Sp, Sp, p->ws("xq"), Sp, f8, (float*)p->ws("h3_amax"), n_amax,
+                                 n_amax2, p->b.step_counter, stream));
       RV_K(1, rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
                                h1, Hp, stream));
     } else {
@@ -633,9 +663,6 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     }
   }
-  const bool full_local = (phases & (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM)) ==
-                              (RV_PHASE_BWD_A | RV_PHASE_BWD_B | RV_PHASE_ADAM) &&
-                          !(phases & (RV_PHASE_FINALIZE_A | RV_PHASE_FINALIZE_B)) && !adam_from_flat;
   // The latent layer's backward (dz + dW3, both read dP3) and the heads' backward (dP1 + dWh, both read
   // dmulv and h1) each go out as ONE launch (rv_linear_dgrad_wgrad_f32 / rv_linear_dgrad_wgrad).
   auto latent_bwd = [&](void* st) {
@@ -667,12 +694,18 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     }
     {
       Range r(p->roctx, "rv:rest-bwd");
-      RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
+      const bool f8_w1 = fp8_w1(p, true);
+      RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream, f8_w1));
       // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
       // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
-      RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
-                                   8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
-                                   p->b.step_counter, 256 - n_gemm, stream));
+      if (f8_w1)
+        RV_K(7, rv_linear_wgrad_adam_fp8(p->ws("dP1q"), Hp, p->ws("xq"), Sp, (float*)p->ws("fp8_state") + 15, Hp, Sp, Bp, p->s_w1,
+                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2, 8, p->b.param, p->b.exp_avg,
+                                         p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter, 256 - n_gemm, stream));
+      else
+        RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
+                                     8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+                                     p->b.step_counter, 256 - n_gemm, stream));
     }
     Range r(p->roctx, "rv:adam");
     RV_K(8, rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
@@ -979,6 +1012,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   const bool flags = p->ddp_signal && cap == hipStreamCaptureStatusNone;
   int* fl = (int*)p->ws("ddp_flags");
   const int seq = flags ? ++p->ddp_seq : 0;
+  constexpr long LOCAL_WAIT_MS = 5000;
   auto signal = [&](int edge, hipStream_t from, hipStream_t to) -> int {
     // Edge 0 is an event even with flags on: its waiter would sit on the collective stream from the end of the previous
     // step, spinning on one wave slot of one CU all through the forward and the paired fc4 backward -- and that kernel
@@ -986,7 +1020,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     // (measured: 34 -> 60 us).  The other waiters start spinning late in the backward, beside kernels that leave room.
     if (flags && edge != 0) {
       RV_TRY(rv_flag_set(fl + edge, seq, (void*)from));
-      return rv_flag_wait(fl + edge, seq, fl + 8, (void*)to);
+      return rv_flag_wait(fl + edge, seq, fl + 8, LOCAL_WAIT_MS, (void*)to);   // edges 0, 1: set behind this device's own kernels
     }
     hipEvent_t e = edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2];
     RV_HIP(hipEventRecord(e, from));
@@ -1001,7 +1035,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     return RV_OK;
   };
   auto await = [&](int edge, hipStream_t on) -> int {
-    if (flags) return rv_flag_wait(fl + edge, seq, fl + 8, (void*)on);
+    if (flags) return rv_flag_wait(fl + edge, seq, fl + 8, p->ddp_wait_ms, (void*)on);   // edges 2, 3: set behind a collective
     RV_HIP(hipStreamWaitEvent(on, edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2], 0));
     return RV_OK;
   };

@@ -192,11 +192,12 @@ class TrainEngine:
         (`rv_plan_set_option`, RV_OPT_ROCTX); raises when no roctx library can be loaded."""
         lib().rv_plan_set_option(self._plan, _lib.OPT_ROCTX, int(bool(enable)))
 
-    def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None):
+    def set_fp8_scales(self, x=None, w1=None, w4=None, h3=None, freeze_h3=None, dp1=None):
         """Write entries of the fp8 state block (include/rawvae_hip.h, RV_OPT_FP8).  Weight scales are
-        normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scale (parity runs)."""
+        normally chosen by refresh_shadows (224 / max|W|); `freeze_h3` pins the activation scales -- h3's and dP1's
+        (parity runs)."""
         st = self.buffer("fp8_state", torch.float32, (-1,))[:16]
-        for i, v in ((0, x), (1, w1), (2, w4), (3, h3)):
+        for i, v in ((0, x), (1, w1), (2, w4), (3, h3), (13, dp1)):
             if v is not None:
                 st[i] = float(v)
         if freeze_h3 is not None:
@@ -235,6 +236,10 @@ class TrainEngine:
                     st[3] = self.fp8_h3_scale
                 # scale of dP4's fp8 image (the fp8 backward of fc4): |dP4| <= 2 * 2 / (B S) lands within +-224
                 st[12] = 56.0 * self.B * self.S
+                # first guess for dP1's image (fc1's fp8 weight gradient), of dP4's order; from the second step on it
+                # follows the maximum the heads' backward measured in the step before (delayed scaling, as h3's)
+                if cur[13] == 0.0:
+                    st[13] = 56.0 * self.B * self.S
                 st[8:10] = 0.0   # max|W| of the last update: none yet for these weights
                 self.buffer("fp8_state", torch.float32, (-1,))[32:] = 0.0
         self._await_init(stream)      # (the parameters may have been written on another stream)
@@ -353,6 +358,9 @@ class TrainEngine:
         self._comm = comm   # keep the communicator alive as long as the plan can use it
         # cross-stream edges of the all-reduce schedule: device-side flags (default) or HIP events (RV_DDP_SIGNAL=event)
         lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 0 if os.environ.get("RV_DDP_SIGNAL") == "event" else 1)
+        # how long a flag wait behind a collective -- i.e. behind the slowest peer -- may last (default: ten minutes)
+        if os.environ.get("RV_DDP_WAIT_MS"):
+            lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_WAIT_MS, int(os.environ["RV_DDP_WAIT_MS"]))
         # RV_DDP_W1_WIDE=1 / set_ddp_w1_wide(True): fc1's weight gradient on all CUs in the all-reduce schedule (twice the
         # local step's K splits) -- faster only beside a collective whose workgroups leave room on their CUs
         self.set_ddp_w1_wide(os.environ.get("RV_DDP_W1_WIDE", "0") == "1")
@@ -467,8 +475,8 @@ class TrainEngine:
         return n
 
     def check_ddp_signals(self):
-        """The data-parallel step's device-side flag waits are bounded (100 ms); one that ran out left its consumer
-        running on incomplete data.  Raises if any did since the engine was created (include/rawvae_hip.h,
+        """The data-parallel step's device-side flag waits are bounded (5 s behind local kernels, RV_DDP_WAIT_MS -- ten
+        minutes by default -- behind a collective); one that ran out left its consumer running on incomplete data.  Raises if any did since the engine was created (include/rawvae_hip.h,
         RV_OPT_DDP_SIGNAL).  Called wherever the host reads results back anyway."""
         if getattr(self, "_comm", None) is None:
             return

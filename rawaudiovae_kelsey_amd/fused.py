@@ -86,16 +86,19 @@ class _Holder:
 
 
 def fusable(module, x2):
+    """The parameter tuple when `module(x2)` can run as one node on a step plan, else None."""
     if not getattr(module, "fused_training", True) or not torch.is_grad_enabled():
-        return False
+        return None
     if not x2.is_cuda or x2.requires_grad or x2.dtype != torch.float32 or x2.shape[0] == 0:
-        return False
+        return None
     if module.latent_dim > 256:
-        return False
-    for p in _params(module):
-        if not p.requires_grad or p.dtype != torch.float32 or p.device != x2.device:
-            return False
-    return True
+        return None
+    params = _params(module)
+    dev = x2.device
+    for p in params:
+        if not p.requires_grad or p.dtype != torch.float32 or p.device != dev:
+            return None
+    return params
 
 
 class VaeFn(torch.autograd.Function):
@@ -139,17 +142,20 @@ class VaeFn(torch.autograd.Function):
             L_.rv_plan_set_external_grads(eng._plan, None, None, None, None, None)
         out = [None, None, None]
         need = ctx.needs_input_grad
+        # (weights are 2-D views of their piece; a bias IS its piece: five view calls, not ten)
         for i, (piece, shape) in enumerate(zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)):
-            out.append(piece.view(shape) if need[3 + i] else None)
+            out.append((piece.view(shape) if len(shape) > 1 else piece) if need[3 + i] else None)
         return tuple(out)
 
 
-def forward(module, x2, eps=None):
-    """`VAE.forward` body for a fusable call: x2 is [B, S] fp32 on the module's device."""
+def forward(module, x2, eps=None, params=None):
+    """`VAE.forward` body for a fusable call: x2 is [B, S] fp32 on the module's device (`params`: what `fusable`
+    returned)."""
     holder = _HOLDERS.get(module)
     if holder is None:
         holder = _HOLDERS[module] = _Holder()
-    params = _params(module)
+    if params is None:
+        params = _params(module)
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
     if eps is not None:
         eps = eps.reshape(x2.shape[0], module.latent_dim)

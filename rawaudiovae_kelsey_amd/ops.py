@@ -317,14 +317,15 @@ class LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = _f32c(g).view(1)
-        outs = []
-        st = stream_ptr()
-        for t in ctx.grads:
+        g = _f32c(g)
+        outs, args = [], []
+        for t in ctx.grads:   # all three in ONE launch
             if t is None:
                 outs.append(None)
-                continue
-            o = torch.empty_like(t)
-            lib().rv_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), st)
-            outs.append(o)
+                args += [None, None, 0]
+            else:
+                o = torch.empty_like(t)
+                outs.append(o)
+                args += [t.data_ptr(), o.data_ptr(), t.numel()]
+        lib().rv_scale_by3(*args, g.data_ptr(), stream_ptr())
         return outs[0], None, outs[1], outs[2], None

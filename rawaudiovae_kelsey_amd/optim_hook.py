@@ -10,10 +10,10 @@ This module lets the UNCHANGED loop use it: a global optimizer step pre-hook (to
 register_optimizer_step_pre_hook) recognises a param group of a plain `torch.optim.Adam` that holds all ten parameters
 of a `rawvae.model.VAE` whose forward ran through the one-node path (fused.py: the Parameters are views of one fp32
 arena), with hyper-parameters `rv_adam_multi` implements (betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad /
-maximize / capturable / differentiable -- the reference's construction), performs the update with ONE launch, and hides
-those parameters' gradients from the stock step for the duration of the call (a parameter without a gradient is
-skipped by torch.optim), restoring them in the post-hook.  Everything else -- other optimizers, other parameter
-groups, other hyper-parameters, closures -- is left to PyTorch untouched.
+maximize / capturable / differentiable -- the reference's construction), performs the update with ONE launch, and takes
+those parameters out of the group's list for the duration of the stock step (which then finds nothing to do for
+them), putting the list back in the post-hook.  Everything else -- other optimizers, other parameter groups, other
+parameters of the same group, other hyper-parameters, closures -- is left to PyTorch untouched.
 
 What stays PyTorch's: `optimizer.state[p]` keeps torch's layout (`step`, `exp_avg`, `exp_avg_sq`), so
 `optimizer.state_dict()` / `load_state_dict()` and the reference's checkpoints (train.py:208-212) are unchanged; the
@@ -34,7 +34,7 @@ enabled = os.environ.get("RV_OPTIM_HOOK", "1") != "0"
 stats = {"fused_steps": 0, "declined": {}}   # how often the hook took a step over / why it left one to PyTorch
 _installed = False
 _OWNER = {}            # id(Parameter) -> (weakref(Parameter), weakref(module))
-_STASH = weakref.WeakKeyDictionary()   # optimizer -> [(param, grad), ...] hidden from the stock step
+_STASH = weakref.WeakKeyDictionary()   # optimizer -> [(group, its full parameter list), ...] while the stock step runs
 _T_RING = {}           # device -> int64 tensor [1, 2, 3, ...]: the step number is passed as a pointer into it
 
 
@@ -85,12 +85,14 @@ _PLANS = weakref.WeakKeyDictionary()   # optimizer -> (signature of its groups, 
 
 def _discover(opt):
     """Which (param group, VAE module) pairs of this optimizer the hook may take over: the group holds ALL ten
-    parameters of a module whose Parameters live in an engine's arena.  Re-derived when the groups change."""
+    parameters of a module whose Parameters live in an engine's arena.  Re-derived when the groups change.
+    -> [(group index, weakref(module), the group's OTHER parameters), ...]"""
     from . import fused
     found = []
     for gi, group in enumerate(opt.param_groups):
         ids = {id(q) for q in group["params"]}
-        seen = set()
+        seen, taken = set(), set()
+        mods = []
         for p in group["params"]:
             own = _OWNER.get(id(p))
             if own is None or own[0]() is not p:
@@ -99,24 +101,40 @@ def _discover(opt):
             if module is None or id(module) in seen:
                 continue
             seen.add(id(module))
-            if any(id(q) not in ids for q in fused._params(module)):
+            mine = fused._params(module)
+            if any(id(q) not in ids for q in mine):
                 _decline("group holds only part of the model")   # PyTorch's step
                 continue
-            found.append((gi, weakref.ref(module)))
+            mods.append(module)
+            taken.update(id(q) for q in mine)
+        if len(mods) == 1:     # (two fused models in one group: left to PyTorch -- the list swap below is per group)
+            found.append((gi, weakref.ref(mods[0]), [q for q in group["params"] if id(q) not in taken]))
+        elif mods:
+            _decline("several fused models in one group")
     return found
+
+
+def _restore(opt):
+    stash = _STASH.pop(opt, None)
+    if stash:
+        for group, full in stash:
+            group["params"] = full
 
 
 def _pre_step(opt, args, kwargs):
     # (`args` is the step call's positional arguments INCLUDING the optimizer itself)
-    if not enabled or len(args) > 1 or kwargs.get("closure") is not None or not _OWNER:
+    if not enabled or not _OWNER:
+        return None
+    _restore(opt)     # (a stock step that raised never reached the post-hook)
+    if len(args) > 1 or kwargs.get("closure") is not None:
         return None
     from . import fused, ops
     groups = opt.param_groups
-    sig = (len(_OWNER),) + tuple(len(g["params"]) for g in groups)
+    sig = (len(_OWNER),) + tuple([len(g["params"]) for g in groups])
     plans = _PLANS.get(opt)
     if plans is None or plans[0] != sig:
         plans = _PLANS[opt] = (sig, _discover(opt))
-    for gi, mref in plans[1]:
+    for gi, mref, others in plans[1]:
         group, module = groups[gi], mref()
         if module is None:
             continue
@@ -131,8 +149,9 @@ def _pre_step(opt, args, kwargs):
         eng = holder.last_engine
         grads = [q.grad for q in params]
         ok = True
+        f32 = torch.float32
         for g in grads:
-            if g is None or g.dtype is not torch.float32 or not g.is_cuda or g.is_sparse or not g.is_contiguous():
+            if g is None or g.dtype is not f32 or not g.is_cuda or g.is_sparse or not g.is_contiguous():
                 ok = False
                 break
         if not ok:
@@ -140,22 +159,22 @@ def _pre_step(opt, args, kwargs):
             continue
         _fused_adam(opt, group, holder, eng, params, grads)
         stats["fused_steps"] += 1
-        _STASH.setdefault(opt, []).extend(zip(params, grads))
-        for q in params:
-            q.grad = None     # the stock step skips parameters without a gradient
+        # the stock step that follows must not touch these parameters: they leave the group's list until the post-hook
+        # (two dictionary writes instead of hiding and restoring ten .grad fields)
+        _STASH.setdefault(opt, []).append((group, group["params"]))
+        group["params"] = others
         # the kernel refreshed this engine's operand shadows; the per-layer Functions' caches (ops.py) are stale
         ops.invalidate_shadows()
         eng._shared["version"] += 1
         eng._shadow_version = eng._shared["version"]
+        # an in-place update as far as autograd is concerned (what torch.optim's own kernels do to the version counters)
+        torch.autograd.graph.increment_version(params)
         holder.versions = tuple([q._version for q in params]) + (ops._EPOCH[0],)
     return None
 
 
 def _post_step(opt, args, kwargs):
-    stash = _STASH.pop(opt, None)
-    if stash:
-        for p, g in stash:
-            p.grad = g
+    _restore(opt)
 
 
 def _fused_adam(opt, group, holder, eng, params, grads):
@@ -164,7 +183,7 @@ def _fused_adam(opt, group, holder, eng, params, grads):
     cache = holder.adam_cache
     if cache is None or cache["arena"] is not eng.exp_avg:
         # moments: views of the engine's arenas (every engine of a holder shares them), in torch's state layout
-        cache = holder.adam_cache = {"arena": eng.exp_avg, "descs": {},
+        cache = holder.adam_cache = {"arena": eng.exp_avg, "descs": {}, "steps": None,
                                      "m": [eng.view(eng.exp_avg, k) for k in PARAM_NAMES],
                                      "v": [eng.view(eng.exp_avg_sq, k) for k in PARAM_NAMES]}
     st0 = state[params[0]]
@@ -182,11 +201,15 @@ def _fused_adam(opt, group, holder, eng, params, grads):
                 if st["exp_avg_sq"] is not cache["v"][i]:
                     cache["v"][i].copy_(st["exp_avg_sq"])
             st["exp_avg"], st["exp_avg_sq"] = cache["m"][i], cache["v"][i]
-        steps = [float(state[p]["step"]) for p in params]
+        cache["steps"] = [state[p]["step"] for p in params]
+        steps = [float(v) for v in cache["steps"]]
         if min(steps) != max(steps):
             raise _lib.RvError("optimizer state: the VAE's parameters are at different step counts (%r)" % (steps,))
         st0 = state[params[0]]
-    t = int(float(st0["step"])) + 1
+    step_tensors = cache["steps"]
+    if step_tensors is None or st0["step"] is not step_tensors[0]:      # (state replaced behind the moments' back)
+        step_tensors = cache["steps"] = [state[p]["step"] for p in params]
+    t = int(float(step_tensors[0])) + 1
     descs = cache["descs"].get(eng.B)
     if descs is None:
         descs = (_lib.ParamDesc * 10)(*eng.plan_descs())
@@ -200,4 +223,4 @@ def _fused_adam(opt, group, holder, eng, params, grads):
     lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
     lib().rv_adam_multi(descs, 10, ptr(eng.param), ptr(eng.exp_avg), ptr(eng.exp_avg_sq), None, None, lr, 1.0,
                         _t_ptr(eng.device, t), stream_ptr())
-    torch._foreach_add_([state[p]["step"] for p in params], 1)
+    torch._foreach_add_(step_tensors, 1)

@@ -150,3 +150,53 @@ def test_fp8_trajectory_vs_reference_golden(case):
     w4 = e.view(e.param, "fc4.weight").cpu().numpy()
     np.testing.assert_array_equal(w4q[:S, :H], O.fp8_e4m3_round(w4 * np.float32(st2[2])))
     assert 200.0 < np.abs(w4q).max() <= 448.0
+
+
+def test_fp8_full_step_weight_gradient_of_fc1_on_fp8_operands():
+    """The full local step of the fp8 weight path at C2 also runs fc1's weight gradient on e4m3 operands: dP1 leaves the
+    heads' backward as fp8 (no bf16 copy, nor one of the frames), the GEMM beside the optimizer riders multiplies it with
+    the frames' fp8 image.  One step from zero moments leaves exp_avg = 0.1 g: all ten gradients against the oracle with
+    the same rounding points (3e-2 rel-L2, as the phase-split test), fc1.weight's also against the bf16 backward (what
+    the two fp8 operands cost), the image of dP1 itself, and the delayed scale: measured in step 1, used in step 2."""
+    S, H, L, B = 1024, 2048, 64, 4096
+    e = _engine(S, H, L, B, fp8="full")
+    s_dp1 = 56.0 * B * S / 4.0
+    e.set_fp8_scales(h3=32.0, freeze_h3=True, dp1=s_dp1)
+    st = e.fp8_state()
+    scales = {"x": st[0], "w1": st[1], "w4": st[2], "h3": 32.0, "dp4": st[12], "dp1": s_dp1}
+    x, eps = make_frames(B, S, 1234), make_eps(B, L, 4321)
+    e.step(torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda())
+    torch.cuda.synchronize()
+    p = O.cast_params(make_params(S, H, L, 0), np.float32)
+    c = O.forward(p, x, eps, quant="fp8", fp8_scales=scales)
+    g = O.backward(p, c, KL, quant="fp8", fp8_scales=scales)
+    gb = O.backward(p, c, KL, quant="bf16")
+    for k in PARAM_NAMES:
+        got = e.view(e.exp_avg, k).cpu().numpy().astype(np.float64) / 0.1
+        assert _rel_l2(got, g[k]) < 3e-2, (k, _rel_l2(got, g[k]))
+    got = e.view(e.exp_avg, "fc1.weight").cpu().numpy().astype(np.float64) / 0.1
+    assert _rel_l2(got, gb["fc1.weight"]) < 6e-2, _rel_l2(got, gb["fc1.weight"])
+    # the image of dP1: the oracle's fp32 dP1 through the same scale (elements on the other side of an e4m3 rounding
+    # boundary because dmu / dlv carry the fp8 forward's noise: a few per cent)
+    Bp, Sp, Hp, Lp = e.padded()
+    dp1q = e.buffer("dP1q", torch.uint8, (Bp, Hp)).view(torch.float8_e4m3fn).float().cpu().numpy()[:B, :H]
+    q = lambda a: O.bf16_round(a)  # noqa: E731
+    W21, W22 = q(p["fc21.weight"]), q(p["fc22.weight"])
+    n_k = B * L
+    dP4 = O._q8((2.0 / (B * S)) * (c["recon"] - x) * (1.0 - c["recon"] * c["recon"]), st[12])
+    dP3 = q((dP4 @ O._q8(p["fc4.weight"], st[2])) * (c["h3"] > 0))
+    dz = dP3 @ q(p["fc3.weight"])
+    dmu = q(dz + KL * c["mu"] / n_k)
+    dlv = q(dz * c["eps"] * 0.5 * c["std"] + KL * 0.5 * (np.exp(c["logvar"]) - 1.0) / n_k)
+    dP1f = (dmu @ W21 + dlv @ W22) * (c["h1"] > 0)
+    want = O.fp8_e4m3_round((dP1f * s_dp1).astype(np.float32))
+    assert 8.0 < np.abs(want).max() <= 448.0, np.abs(want).max()          # the scale under test uses the format's range
+    assert _rel_l2(dp1q, want) < 3e-2 and float((dp1q != want).mean()) < 0.2, (_rel_l2(dp1q, want), (dp1q != want).mean())
+    # delayed scaling: unfreeze; the next step's first kernel turns the maximum measured above into dP1's scale
+    e.set_fp8_scales(freeze_h3=False)
+    e.step(torch.from_numpy(make_frames(B, S, 77)).cuda(), torch.from_numpy(make_eps(B, L, 78)).cuda())
+    st2 = e.fp8_state()
+    amax = float(np.abs(dP1f).max())
+    assert abs(st2[14] / amax - 1.0) < 0.05, (st2[14], amax)
+    assert abs(st2[13] * st2[14] / 224.0 - 1.0) < 1e-5 and abs(st2[15] * st2[13] * st2[0] - 1.0) < 1e-5
+    assert np.isfinite(e.last_loss()[0])

@@ -428,5 +428,24 @@ def test_stock_adam_step_runs_as_one_fused_launch_and_keeps_torch_state():
         # the next forward sees the stock step's in-place writes (version counters moved): shadows are rebuilt
         r2, _, _ = me(x)
         assert not torch.equal(r2, recon)
+        # a group holding the ten parameters AND one more: the hook updates the ten, the stock step the other one; the
+        # group's list is whole again afterwards, and the ten count as modified in place (version counters)
+        mg = _model(S, H, L)
+        extra = torch.nn.Parameter(torch.ones(7, device="cuda"))
+        og = torch.optim.Adam(list(mg.parameters()) + [extra], lr=1e-3)
+        recon, mu, logvar = mg(x)
+        (loss_function(recon, x, mu, logvar, 1e-2, S) + extra.sum()).backward()
+        v0 = mg.fc4.weight._version
+        w0 = mg.fc4.weight.detach().clone()
+        n0 = optim_hook.stats["fused_steps"]
+        og.step()
+        assert optim_hook.stats["fused_steps"] == n0 + 1
+        assert len(og.param_groups[0]["params"]) == 11 and og.param_groups[0]["params"][-1] is extra
+        assert mg.fc4.weight._version > v0 and not torch.equal(mg.fc4.weight, w0)
+        assert og.state[mg.fc4.weight]["exp_avg"].data_ptr() != 0 and float(og.state[mg.fc4.weight]["step"]) == 1.0
+        np.testing.assert_allclose(extra.detach().cpu().numpy(), 1.0 - 1e-3, rtol=1e-5)      # stock Adam's first step: -lr * sign(g)
+        assert float(og.state[extra]["step"]) == 1.0
+        og.zero_grad()
+        assert mg.fc1.weight.grad is None and extra.grad is None
     finally:
         optim_hook.enabled = True
