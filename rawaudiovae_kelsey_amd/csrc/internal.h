@@ -82,6 +82,11 @@ RV_INTERNAL int rv_linear_wgrad_adam_fp8(const void* dy_fp8, long lddy, const vo
 RV_INTERNAL int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp,
                                 long Hp, long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw,
                                 void* dp1_fp8, long ldq, const float* q_scale, float* amax_part, void* stream);
+// One-shot: the next paired dgrad + wgrad launch (bf16 or fp8) signals `hip_event` when it completes -- the event is the
+// launch's own completion signal (hipExtLaunchKernelGGL), cheaper on both streams than a hipEventRecord behind it.
+// Not under stream capture.  Returns 1 when an event armed earlier was still pending, i.e. no paired launch took it
+// (other tile forms): call with NULL behind the backward to disarm and to learn which.
+RV_INTERNAL int rv_pair_stop_event(void* hip_event);
 // The paired fc4 backward on fp8 operands (gemm_launch.hip) and whether the extents allow it.
 RV_INTERNAL int rv_dgrad_wgrad_fp8_fits(long Mp, long Np, long Kp, int splits);
 RV_INTERNAL int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,

@@ -507,6 +507,7 @@ __device__ __forceinline__ void wait_vm_exact(int n) {
   }
 }
 
+template <bool Q8>   // Q8: the fp8 weight path's outputs (a second instantiation: the bf16 step's kernel stays as it was)
 __global__ void __launch_bounds__(512)
 k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, const long ldw,
             const bf16_t* __restrict__ h1, const long ldh, bf16_t* __restrict__ dP1, const long ldp,
@@ -519,8 +520,8 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
   // fp8 weight path (RV_OPT_FP8 = 1): dP1 also -- or only, when dP1 is NULL -- as fp8(dP1 * *q_scale), the MN-major
   // operand of fc1's fp8 weight gradient; max|dP1| of every wave's outputs for next step's scale (delayed scaling)
-  const float qs = dP1q ? *q_scale : 0.f;
-  float amax = 0.f;
+  float qs = 0.f, amax = 0.f;
+  if constexpr (Q8) qs = dP1q ? *q_scale : 0.f;
   const int q = lane >> 4, j = lane & 15;
   const int nstrips = (int)(Hp / 64);
   const int g = (int)blockIdx.x / nstrips, cs_ = (int)blockIdx.x - g * nstrips;
@@ -644,12 +645,12 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
       }
       const long orow = r_base + (long)HB_TR * t + r;
       const int ocol = (2 * cp + (q & 1)) * 16 + (q >> 1) * 8;
-      if (dP1) {
+      if (!Q8 || dP1) {
         const bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
                           (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
         store_out16((bf16x8*)(dP1 + orow * ldp + c0 + ocol), o, wt);
       }
-      if (dP1q || amax_part) {
+      if constexpr (Q8) {
         float q8[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -689,10 +690,12 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (db1_partial && tid < 64) db1_partial[(long)g * Hp + c0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
-  if (amax_part) {
+  if constexpr (Q8) {
+    if (amax_part) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0) amax_part[blockIdx.x * 8 + wave] = amax;
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      if (lane == 0) amax_part[blockIdx.x * 8 + wave] = amax;
+    }
   }
 }
 
@@ -806,12 +809,14 @@ int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const
   RV_REQUIRE((((uintptr_t)dmulv_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)h1_bf16 | (uintptr_t)dp1_bf16 | (uintptr_t)dwh_slabs) & 15) == 0,
              RV_ERR_SHAPE, "rv_heads_bwd: operands must be 16-byte aligned");
   RV_REQUIRE(!dp1_bf16 || (ldp >= Hp && ldp % 8 == 0), RV_ERR_SHAPE, "rv_heads_bwd: bad leading dimension of dP1");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_heads_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
-    attr_done = true;
+  const bool q8 = dp1_fp8 || amax_part;
+  auto kern = q8 ? k_heads_bwd<true> : k_heads_bwd<false>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[q8]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
+    attr_done[q8] = true;
   }
-  hipLaunchKernelGGL(k_heads_bwd, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
+  hipLaunchKernelGGL(kern, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
                      db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part);
   RV_CHECK_LAUNCH();

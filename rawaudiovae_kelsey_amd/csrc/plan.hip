@@ -997,9 +997,15 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  RV_HIP(hipStreamIsCapturing(s0, &cap));
+  bool edge0_armed = false;   // the paired launch itself signals ev_ready[0] (see `signal`, edge 0)
   {
     Range r(p->roctx, "rv:fc4-bwd");
-    RV_TRY(fc4_backward(p, stream));
+    if (cap == hipStreamCaptureStatusNone) rv_pair_stop_event(p->ev_ready[0]);
+    rc = fc4_backward(p, stream);
+    edge0_armed = cap == hipStreamCaptureStatusNone && !rv_pair_stop_event(nullptr);   // taken by a paired launch
+    if (rc) return rc;
   }
   Range range_rest(p->roctx, "rv:rest-bwd+exchange+adam");
   // Cross-stream edges: device-side flags (elementwise.hip, k_flag_set / k_flag_wait; ~1.8 us per crossing) when
@@ -1007,8 +1013,6 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   // capture -- a captured graph needs the event edges to know the collective stream belongs to it -- or when
   // RV_OPT_DDP_SIGNAL is 0.  Edge 0: fc4's slabs complete (s0 -> sc); 1: second payload complete (s0 -> sc);
   // 2: fc4's exchange done (sc -> s0); 3: second exchange done (sc -> s0).  Edges 1 and 3 are on the critical path.
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  RV_HIP(hipStreamIsCapturing(s0, &cap));
   const bool flags = p->ddp_signal && cap == hipStreamCaptureStatusNone;
   int* fl = (int*)p->ws("ddp_flags");
   const int seq = flags ? ++p->ddp_seq : 0;
@@ -1023,7 +1027,9 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
       return rv_flag_wait(fl + edge, seq, fl + 8, LOCAL_WAIT_MS, (void*)to);   // edges 0, 1: set behind this device's own kernels
     }
     hipEvent_t e = edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2];
-    RV_HIP(hipEventRecord(e, from));
+    // (edge 0 outside a capture: the event IS the completion signal of the paired launch -- rv_pair_stop_event -- which
+    // leaves 3.7 us of bubble behind that kernel instead of the 5.7 of a record behind it)
+    if (!(edge == 0 && edge0_armed)) RV_HIP(hipEventRecord(e, from));
     RV_HIP(hipStreamWaitEvent(to, e, 0));
     return RV_OK;
   };
@@ -1039,6 +1045,9 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     RV_HIP(hipStreamWaitEvent(on, edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2], 0));
     return RV_OK;
   };
+  // (Tried: the second bucket's payload kernel publishing edge 1's flag from its last workgroup instead of a k_flag_set
+  // launch behind it.  Every workgroup then needs an agent-scope release of its own before it counts itself done -- an L2
+  // write-back each, 1000 of them: +27 us per step.  The kernel boundary does that once.)
   RV_TRY(signal(0, s0, sc));                               // fork 1: fc4 (8.4 MB of gradient at C2) is summed over its
   RV_TRY(payload(8, 10, sc));                              // slabs and travels behind ALL the rest of the backward
   RV_TRY(reduce(0, 8, 10, sc));

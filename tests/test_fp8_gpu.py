@@ -200,3 +200,22 @@ def test_fp8_full_step_weight_gradient_of_fc1_on_fp8_operands():
     assert abs(st2[14] / amax - 1.0) < 0.05, (st2[14], amax)
     assert abs(st2[13] * st2[14] / 224.0 - 1.0) < 1e-5 and abs(st2[15] * st2[13] * st2[0] - 1.0) < 1e-5
     assert np.isfinite(e.last_loss()[0])
+
+
+def test_fp8_full_step_on_resident_waveform_equals_step_on_gathered_frames_at_c2():
+    """The fp8 weight path at C2 (fc1's weight gradient on fp8 operands: neither bf16 copy of the frames nor of dP1 is
+    written) fed from a resident waveform -- the gather-and-quantise cast kernel -- against gather -> `step`: the same
+    bits, two steps (the second one runs on latched scales)."""
+    from rawaudiovae_kelsey_amd import data as D
+    S, H, L, B, hop = 1024, 2048, 64, 4096, 128
+    wave = np.random.default_rng(5).uniform(-1, 1, (B + 40) * hop + S).astype(np.float32)
+    d = D.DeviceAudio(wave, S, hop)
+    idx = torch.randperm(len(d), generator=torch.Generator().manual_seed(1))[:B].contiguous().cuda()
+    a, b = _engine(S, H, L, B, fp8="full", seed=2), _engine(S, H, L, B, fp8="full", seed=2)
+    eps = torch.from_numpy(make_eps(B, L, 9)).cuda()
+    for _ in range(2):
+        a.step(d.gather(idx), eps)
+        b.step_frames(d, idx, eps=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(a.param, b.param) and a.losses(2) == b.losses(2)
+    assert a.fp8_state()[13] == b.fp8_state()[13] != 56.0 * B * S       # dP1's scale has been latched from a measurement
