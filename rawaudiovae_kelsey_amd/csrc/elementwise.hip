@@ -990,7 +990,7 @@ int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* 
 // ---- device-side cross-stream signalling (plan.hip: the data-parallel step) ----
 // A hand-over between two streams through HIP events costs ~9 us per crossing on this runtime (record -> dependent
 // kernel on the other stream; 4.6 us of bubble on the recording stream alone); through a flag in device memory it
-// costs ~1.8 (measured: tools/scratch microbenchmark).  k_flag_set runs BEHIND the producing kernel
+// costs ~1.8 (measured: tools/probe_cross_stream.hip).  k_flag_set runs BEHIND the producing kernel
 // in its stream (the kernel boundary in front of it is the agent-scope release of the producer's data) and publishes
 // a sequence number; k_flag_wait sits in the consumer stream IN FRONT of the consuming kernel and returns when the
 // number has arrived.  Deadlock-free by construction whatever the runtime's stream -> hardware-queue mapping is: every

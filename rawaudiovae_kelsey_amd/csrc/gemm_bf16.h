@@ -213,7 +213,7 @@ __device__ __forceinline__ bf16x8 load_frag(const lds_char* lds, int row0, int k
 
 // v_permlane16_swap_b32: lanes 16-31 / 48-63 of `a` trade places with lanes 0-15 / 32-47 of `b`.  Inline asm
 // on scalars: hipcc (ROCm 7.2) miscompiles __builtin_amdgcn_permlane16_swap when its results are inserted into
-// vector elements (tools/scratch/probe.hip: elements 1..3 come back as copies of other lanes' element 0).  The
+// vector elements (tools/probe_vector_elements.hip: elements 1..3 come back as copies of other lanes' element 0).  The
 // s_nop covers the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside an asm.
 __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));

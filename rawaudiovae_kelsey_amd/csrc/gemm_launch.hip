@@ -205,7 +205,7 @@ int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   if (g_pair_stop_event) {
     // the launch's own completion signal as a HIP event: 3.7 us of bubble behind this kernel on its stream instead of the
     // 5.7 a hipEventRecord behind it costs, and 7 us instead of 11 to the dependent kernel on the other stream
-    // (tools/scratch/extlaunch.hip)
+    // (tools/probe_extlaunch.hip)
     hipExtLaunchKernelGGL(kern, dim3((unsigned)(n_d + n_w)), dim3(64 * WGM * WGN), smem, st, nullptr, g_pair_stop_event, 0, d, g, n_d);
     g_pair_stop_event = nullptr;
   } else {
