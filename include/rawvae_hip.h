@@ -432,8 +432,8 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     ds_read_b64_tr_b8), the wgrad with the fp8 image of h3 the fc3 forward wrote; K tiles are 128 deep, half the LDS
  *     fill per flop of the bf16 pair.  Where the extents do not tile (256 x 256 tiles, an even number of 128-deep K
  *     tiles per block) and for gradients from outside (rv_plan_set_external_grads) the backward stays bf16.  In the full
- *     local step (all phases in one call) fc1's weight gradient -- the launch that also carries the optimizer riders --
- *     runs on fp8 operands as well, under the same tiling conditions: the heads' backward writes dP1 as fp8(dP1 * [13])
+ *     local step (all phases in one call) and in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the
+ *     launch that also carries rider blocks -- runs on fp8 operands as well, under the same tiling conditions: the heads' backward writes dP1 as fp8(dP1 * [13])
  *     only, the GEMM multiplies it with the fp8 image of the frames fc1's forward read (both MN-major), and neither
  *     bf16 copy is written; [13] follows the maximum of |dP1| measured in the previous step, like h3's scale.
  *     The workspace buffer "fp8_state" holds 16 floats (then 2 x 1024 slots) the caller initialises before rv_plan_refresh_shadows:

@@ -553,6 +553,17 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
   return RV_OK;
 }
 
+// ... and on fp8 operands (as rv_linear_wgrad_adam_fp8 below: bytes, both MN-major, dq = 1 / (scale_dy * scale_x)).
+extern "C" int rv_linear_wgrad_finalize_fp8(const void* dy_fp8, long lddy, const void* x_fp8, long ldx, const float* dq, long Mp,
+                                 long Np, long Kp, int splits, void* dw, long lddw, int slab_dtype, float* slab_unscale,
+                                 const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, int n_rider_blocks,
+                                 void* stream) {
+  RV_REQUIRE(dy_fp8 && x_fp8 && dq && dw && grad_out, RV_ERR_NULL, "rv_linear_wgrad_finalize_fp8: null pointer");
+  return wgrad_riders("rv_linear_wgrad_finalize_fp8", dy_fp8, lddy, x_fp8, ldx, Mp, Np, Kp, splits, dw, lddw, slab_dtype, slab_unscale,
+                      descs, n_desc, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr, out_bf16 ? nullptr : (float*)grad_out,
+                      out_bf16 ? (bf16_t*)grad_out : nullptr, n_rider_blocks, stream, dq);
+}
+
 // rv_linear_wgrad_adam on fp8 (e4m3) operands (RV_OPT_FP8 = 1; plan.hip): dy_fp8 [Kp(batch), Mp] and x_fp8 [Kp, Np], one
 // byte per element, both read MN-major through ds_read_b64_tr_b8 (the contraction index is the row of both matrices);
 // dq: device scalar 1 / (scale_dy * scale_x).  Same slabs, riders and launch shape.  Not in the public header.

@@ -79,6 +79,10 @@ RV_INTERNAL int rv_linear_wgrad_adam_fp8(const void* dy_fp8, long lddy, const vo
                                          const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
                                          float* exp_avg_sq, float lr, float grad_scale, const long long* step_counter,
                                          int n_adam_blocks, void* stream);
+RV_INTERNAL int rv_linear_wgrad_finalize_fp8(const void* dy_fp8, long lddy, const void* x_fp8, long ldx, const float* dq, long Mp,
+                                             long Np, long Kp, int splits, void* dw, long lddw, int slab_dtype,
+                                             float* slab_unscale, const rv_param_desc* descs, int n_desc, void* grad_out,
+                                             int out_bf16, int n_rider_blocks, void* stream);
 RV_INTERNAL int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp,
                                 long Hp, long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw,
                                 void* dp1_fp8, long ldq, const float* q_scale, float* amax_part, void* stream);

@@ -116,6 +116,7 @@ struct rv_plan {
   int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax" for h3's maxima
   int n_amax_dp1 = 0;          // ... and for dP1's behind them (fp8 weight gradient of fc1)
   int n_amax_h3 = 0;           // how many of h3's the forward in use writes (set by the forward phase)
+  bool fwd_for_fp8_w1 = false; // set by rv_plan_step_ddp around its forward call (fp8_w1)
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
   long ddp_wait_ms = 600000;   // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
@@ -491,12 +492,14 @@ static bool fp8_bwd(const rv_plan* p) {
 static bool fp8_bwd_possible(const rv_plan* p) {   // (at forward time: which images of dP4 to write)
   return p->fp8 == 1 && rv_dgrad_wgrad_fp8_fits(p->Bp, p->Hp, p->Sp, p->s_w4);
 }
-// fc1's weight gradient on fp8 operands (RV_OPT_FP8 = 1), in the full local step only (the launch that also carries the
-// optimizer riders): the heads' streaming backward writes dP1 as fp8 (its scale follows the maximum it measured in the
-// previous step), the frames' fp8 image is the one fc1's forward read, and neither bf16 copy is written.
+// fc1's weight gradient on fp8 operands (RV_OPT_FP8 = 1), in the schedules whose dW1 launch has an fp8 form -- the one
+// with rider blocks: the full local step (riders = optimizer) and the data-parallel all-reduce step (riders = slab sums;
+// it announces itself to its forward call through `fwd_for_fp8_w1`): the heads' streaming backward writes dP1 as fp8 (its
+// scale follows the maximum it measured in the previous step), the frames' fp8 image is the one fc1's forward read, and
+// neither bf16 copy is written.
 static bool latent_bwd_fused(const rv_plan* p);
 static bool fp8_w1(const rv_plan* p, bool full_local) {
-  return p->fp8 == 1 && full_local && latent_bwd_fused(p) && heads_streaming(p) && p->n_amax_dp1 > 0 &&
+  return p->fp8 == 1 && (full_local || p->fwd_for_fp8_w1) && latent_bwd_fused(p) && heads_streaming(p) && p->n_amax_dp1 > 0 &&
          rv_wgrad_adam_fits(p->Hp, p->Sp, p->Bp, p->s_w1) && (p->Hp / 256) * (p->Sp / 256) * p->s_w1 <= 192 &&
          p->Bp % (128L * p->s_w1) == 0 && (p->Bp / 128 / p->s_w1) % 2 == 0 && p->Hp % 16 == 0 && p->Sp % 16 == 0;
 }
@@ -964,10 +967,13 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   const float scale = 1.0f / (float)p->world;
   int rc;
 #define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
+  // fc1's weight gradient with its finalize riders has an fp8 form (the wide form and the other tiles have none)
+  const int s_w1 = (p->ddp_w1_wide && w1_tile(p) == RV_TILE_256x256) ? p->s_w1_ddp : p->s_w1;
+  const int n_gemm = (int)((Hp / 256) * (Sp / 256) * s_w1);
+  const bool riders = w1_tile(p) == RV_TILE_256x256 && n_gemm <= 192;
   // Bucket = tensors [t0, t1) of the flat arena: slabs -> flat payload (caller's stream), then the SUM over ranks
   // on stream `on`
   // fc1's weight gradient on all CUs (see rv_plan_create): its descriptor for the payload kernel carries the split count
-  const int s_w1 = (p->ddp_w1_wide && w1_tile(p) == RV_TILE_256x256) ? p->s_w1_ddp : p->s_w1;
   rv_param_desc dd[10];
   for (int i = 0; i < 10; ++i) dd[i] = p->d_slab[i];
   dd[0].grad_splits = s_w1;
@@ -996,7 +1002,11 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
                          p->b.step_counter, stream);
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
-  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
+  p->fwd_for_fp8_w1 = riders && s_w1 == p->s_w1;
+  const bool f8_w1 = fp8_w1(p, false);
+  rc = rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream);
+  p->fwd_for_fp8_w1 = false;
+  if (rc) return rc;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   RV_HIP(hipStreamIsCapturing(s0, &cap));
   bool edge0_armed = false;   // the paired launch itself signals ev_ready[0] (see `signal`, edge 0)
@@ -1052,17 +1062,22 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(payload(8, 10, sc));                              // slabs and travels behind ALL the rest of the backward
   RV_TRY(reduce(0, 8, 10, sc));
   RV_TRY(post(2, sc));
-  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
+  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream, f8_w1));
   // dW1 runs WITHOUT optimizer riders here: at several ranks fc4's sum has not arrived when this launch starts (an 8.4 MB
   // bucket needs 40-65 us on the links; the latent-sized backward in front of this launch lasts 25).  It keeps the local
   // step's 128 workgroups by default: this launch runs beside fc4's exchange, whose workgroups hold CUs, and a GEMM that
   // needs every CU whole then runs in two rounds (RV_OPT_DDP_W1_WIDE; modelled both ways in tools/ddp_model.py).
-  const int n_gemm = (int)((Hp / 256) * (Sp / 256) * s_w1);
-  if (w1_tile(p) == RV_TILE_256x256 && n_gemm <= 192) {
+  if (riders) {
     // the GEMM leaves CUs idle: rider blocks sum the slabs of everything else in the second bucket (fc1.bias, heads, fc3:
     // complete since the heads' backward) into the payload meanwhile, and only fc1.weight's own slabs are left to sum
-    RV_TRY(rv_linear_wgrad_finalize(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, dd + 1, 7,
-                                    p->payload_bf16 ? p->grad_bf16 : (void*)p->b.grad, p->payload_bf16, 256 - n_gemm, stream));
+    void* pay = p->payload_bf16 ? p->grad_bf16 : (void*)p->b.grad;
+    if (f8_w1)
+      RV_TRY(rv_linear_wgrad_finalize_fp8(p->ws("dP1q"), Hp, p->ws("xq"), Sp, (float*)p->ws("fp8_state") + 15, Hp, Sp, Bp, s_w1,
+                                          p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, dd + 1, 7, pay, p->payload_bf16, 256 - n_gemm,
+                                          stream));
+    else
+      RV_TRY(rv_linear_wgrad_finalize(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, dd + 1, 7,
+                                      pay, p->payload_bf16, 256 - n_gemm, stream));
     RV_TRY(payload(0, 1, s0));
   } else {
     RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));

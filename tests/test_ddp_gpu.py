@@ -112,6 +112,25 @@ with torch.cuda.stream(st):
 st.synchronize()
 assert torch.equal(gr.param, ref.param), "graph-replayed native step differs"
 assert gr.steps_done() == 4
+# the fp8 weight path at C2 (all four large GEMM launches on e4m3 operands, fc1's weight gradient with its finalize riders
+# included): the same bits as the local fp8 step, delayed scales and all
+S8, H8, L8, B8 = 1024, 2048, 64, 4096
+def fresh8():
+    e = TrainEngine(S8, H8, L8, B8, kl_beta=1e-4, lr=1e-4, seed=3, fp8=True)
+    e.load_params(make_params(S8, H8, L8, 0))
+    return e
+x8 = torch.from_numpy(make_frames(B8, S8, 1)).cuda()
+r8, d8 = fresh8(), fresh8()
+d8.attach_comm(comm, payload="fp32"); d8.set_ddp_w1_wide(False)
+with torch.cuda.stream(st):
+    for _ in range(4):
+        r8.step(x8, stream=st)
+        d8.step_ddp(x8, stream=st)
+st.synchronize()
+assert torch.equal(d8.param, r8.param) and d8.losses(4) == r8.losses(4), "fp8 native step differs"
+assert d8.fp8_state()[13] == r8.fp8_state()[13] != 56.0 * B8 * S8      # dP1's scale: latched from a measurement, in both
+assert not d8.buffer("dP1", torch.bfloat16, (-1,)).any()                  # and its bf16 copy was never written
+del r8, d8
 # bf16 payload: the summed gradient is rounded to bf16 before the exchange; Adam's first steps move every
 # weight by ~lr whatever the gradient's magnitude, so the parameters stay within a fraction of lr of the
 # fp32-payload run (sign flips of near-zero gradients aside) and the loss trajectory within 1e-4
