@@ -117,6 +117,8 @@ def main():
                     ok = bool(torch.equal(ea.exp_avg, eb.exp_avg)) and bool(torch.equal(ea.exp_avg_sq, eb.exp_avg_sq))
             for a, b in zip(ea.losses(3), eb.losses(3)):
                 ok = ok and abs(a - b) <= 1e-4 * abs(b)
+            if os.environ.get("RV_SHM_VERBOSE") == "1" and rank == 0:
+                print("%s: mean |native - torch route| = %.4f lr, max %.2f lr" % (tag, float(d.mean()) / LR, float(d.max()) / LR), flush=True)
             if not agree(ok):
                 per = ", ".join("%s %.2g/%.2g" % (k, float((ea.view(ea.param, k) - eb.view(eb.param, k)).abs().mean()),
                                                    float((ea.view(ea.param, k) - eb.view(eb.param, k)).abs().max()))
