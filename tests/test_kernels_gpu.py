@@ -805,3 +805,27 @@ def test_bf16_gradient_payload_kernels(L):
         outs.append((p.clone(), m.clone(), v.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_scale_by3_one_launch_any_alignment():
+    """rv_scale_by3 (loss_function's backward: three saved gradients times the upstream scalar in one launch): exact
+    products for aligned and unaligned pointers, ragged counts, a skipped tensor and all three skipped."""
+    from rawaudiovae_kelsey_amd._lib import lib, ptr, stream_ptr
+    g = torch.tensor([-1.75], device="cuda")
+    base = torch.randn(3 * 70001 + 64, device="cuda")
+    for off in (0, 1, 3):                       # element offsets: 16-byte aligned, and not
+        a0 = base[off:off + 70001]
+        a1 = base[70001 + off:70001 + off + 4099]
+        a2 = base[2 * 70001 + off:2 * 70001 + off + 8]
+        o0, o1, o2 = torch.zeros(70001 + 8, device="cuda")[off:off + 70001], torch.empty_like(a1), torch.empty_like(a2)
+        lib().rv_scale_by3(ptr(a0), ptr(o0), a0.numel(), ptr(a1), ptr(o1), a1.numel(), ptr(a2), ptr(o2), a2.numel(), ptr(g),
+                           stream_ptr())
+        for a, o in ((a0, o0), (a1, o1), (a2, o2)):
+            assert torch.equal(o, a * g)
+    o1.zero_()
+    lib().rv_scale_by3(None, None, 0, ptr(a1), ptr(o1), a1.numel(), None, None, 0, ptr(g), stream_ptr())
+    assert torch.equal(o1, a1 * g)
+    lib().rv_scale_by3(None, None, 0, None, None, 0, None, None, 0, ptr(g), stream_ptr())
+    with pytest.raises(Exception):
+        lib().rv_scale_by3(ptr(a0), None, 5, None, None, 0, None, None, 0, ptr(g), stream_ptr())
+    torch.cuda.synchronize()
