@@ -460,7 +460,9 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     2 x 33.5 MB of fp32 slabs per step at C2): RV_SLAB_F16 (default: block-floating-point fp16, see above), which
  *     halves what the two weight-gradient GEMMs write and Adam reads back, or RV_SLAB_F32.  Each partial is an fp32
  *     sum over a quarter of the batch; rounding it to fp16 adds ~3e-4 relative noise to those two gradients whatever
- *     their magnitude (the sum over slabs stays fp32).
+ *     their magnitude (the sum over slabs stays fp32).  Where the plan runs the streaming heads' backward (rv_heads_bwd's
+ *     form: padded latent width 64, padded batch a multiple of 512) the row-group partials of fc21.weight / fc22.weight
+ *     follow the same switch (8.4 MB of fp32 slabs per step at C2); rv_plan_descs reports the form in use.
  *   RV_OPT_ROCTX  1: roctx ranges (rocprofv3 --marker-trace) around the host calls that enqueue the step's phases --
  *     "rv:fwd", "rv:fc4-bwd", "rv:rest-bwd", "rv:adam" (local step) / "rv:rest-bwd+exchange+adam" (data-parallel step) --
  *     so that a kernel timeline reads as phases (tracing).  The marker library is loaded at run time

@@ -85,7 +85,8 @@ RV_INTERNAL int rv_linear_wgrad_finalize_fp8(const void* dy_fp8, long lddy, cons
                                              int out_bf16, int n_rider_blocks, void* stream);
 RV_INTERNAL int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp,
                                 long Hp, long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw,
-                                void* dp1_fp8, long ldq, const float* q_scale, float* amax_part, void* stream);
+                                void* dp1_fp8, long ldq, const float* q_scale, float* amax_part, float* dwh_unscale,
+                                void* stream);
 // One-shot: the next paired dgrad + wgrad launch (bf16 or fp8) signals `hip_event` when it completes -- the event is the
 // launch's own completion signal (hipExtLaunchKernelGGL), cheaper on both streams than a hipEventRecord behind it.
 // Not under stream capture.  Returns 1 when an event armed earlier was still pending, i.e. no paired launch took it

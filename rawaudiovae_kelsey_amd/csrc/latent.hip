@@ -507,13 +507,16 @@ __device__ __forceinline__ void wait_vm_exact(int n) {
   }
 }
 
-template <bool Q8>   // Q8: the fp8 weight path's outputs (a second instantiation: the bf16 step's kernel stays as it was)
+// Q8: the fp8 weight path's outputs (instantiations of their own: the bf16 step's kernel stays as it was).  H16: the dWh
+// slabs as block-floating-point fp16 -- value * 2^e with one exponent per 32 x 32 granule and slab, 2^-e in `dwh_unscale`
+// (the weight-gradient GEMMs' slab format, adam.h load_slab4: half the bytes written here and read back by the optimizer).
+template <bool Q8, bool H16>
 __global__ void __launch_bounds__(512)
 k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, const long ldw,
             const bf16_t* __restrict__ h1, const long ldh, bf16_t* __restrict__ dP1, const long ldp,
             float* __restrict__ db1_partial, float* __restrict__ dwh_slabs, const long lddw, const long Hp,
             const int wt, unsigned char* __restrict__ dP1q, const long ldq, const float* __restrict__ q_scale,
-            float* __restrict__ amax_part) {
+            float* __restrict__ amax_part, float* __restrict__ dwh_unscale) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   lds_char* smem = (lds_char*)smem_dyn;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -663,10 +666,44 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
     }
   }
   // ---- dWh slab of this row group
-  float* slab = dwh_slabs + (long)g * 128 * lddw + c0;
+  if constexpr (H16) {
+    // one exponent per 32-row granule = per PAIR of waves (a wave holds 16 rows) and slab, for both 32-column granules of
+    // the strip: the pair's maximum through LDS (the stage of tile NT - 2 is free behind the last tile's barrier)
+    float mx = 0.f;
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
-    store_out16((f32x4*)(slab + (long)(wave * 16 + j) * lddw + cb * 16 + q * 4), acc2[cb], wt);
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(acc2[cb][e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __attribute__((address_space(3))) float* ex = (__attribute__((address_space(3))) float*)stage_at((NT - 2) % HB_NS);
+    if (lane == 0) ex[wave] = mx;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    mx = fmaxf(mx, ex[wave ^ 1]);
+    // exponent and scale as the GEMM epilogue's (gemm_bf16.h): 2^(14 - (e - 127)), both it and its reciprocal normal
+    const int e_ = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    int sb = 268 - e_;
+    sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
+    const float f16s = __uint_as_float((unsigned)sb << 23);
+    const long us_ld = Hp / 32;
+    if ((wave & 1) == 0 && lane < 2)
+      dwh_unscale[(long)g * 4 * us_ld + (wave >> 1) * us_ld + c0 / 32 + lane] = __uint_as_float((unsigned)(254 - sb) << 23);
+    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+    _Float16* slab = (_Float16*)dwh_slabs + (long)g * 128 * lddw + c0;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const f16x4_ h = {(_Float16)(acc2[cb][0] * f16s), (_Float16)(acc2[cb][1] * f16s), (_Float16)(acc2[cb][2] * f16s),
+                        (_Float16)(acc2[cb][3] * f16s)};
+      *(f16x4_*)(slab + (long)(wave * 16 + j) * lddw + cb * 16 + q * 4) = h;
+    }
+  } else {
+    float* slab = dwh_slabs + (long)g * 128 * lddw + c0;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      store_out16((f32x4*)(slab + (long)(wave * 16 + j) * lddw + cb * 16 + q * 4), acc2[cb], wt);
+  }
   // ---- column sums: over the 16 row lanes, then over the 4 row-block waves of a column pair (through the Wh slice's
   // LDS, idle by now)
 #pragma unroll
@@ -789,15 +826,17 @@ int rv_heads_bwd(const void* dmulv_bf16, const void* wh_bf16, long ldw, const vo
                  long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* stream) {
   RV_REQUIRE(dp1_bf16, RV_ERR_NULL, "rv_heads_bwd: null pointer");
   return rv_heads_bwd_ex(dmulv_bf16, wh_bf16, ldw, h1_bf16, ldh, Bp, Hp, Lp, dp1_bf16, ldp, db1_partial, dwh_slabs, lddw, nullptr,
-                         0, nullptr, nullptr, stream);
+                         0, nullptr, nullptr, nullptr, stream);
 }
 
 // rv_heads_bwd with the fp8 weight path's extra outputs (NULL = not wanted): dP1 also as fp8(dP1 * *q_scale) in
 // dp1_fp8 [Bp, ldq bytes] -- then dp1_bf16 may be NULL -- and max|dP1| of every wave's outputs in
-// amax_part[8 * (Bp / 512) * (Hp / 64)].
+// amax_part[8 * (Bp / 512) * (Hp / 64)].  dwh_unscale (NULL = fp32 slabs): the dWh slabs as block-floating-point fp16 --
+// `dwh_slabs` then holds fp16 elements with the same element strides, and dwh_unscale[(Bp / 512) * 4 * (Hp / 32)] takes
+// 2^-e per slab and 32 x 32 granule (rv_param_desc.grad_unscale: us_ld = Hp / 32, us_split_stride = 4 * us_ld).
 int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const void* h1_bf16, long ldh, long Bp, long Hp,
                     long Lp, void* dp1_bf16, long ldp, float* db1_partial, float* dwh_slabs, long lddw, void* dp1_fp8, long ldq,
-                    const float* q_scale, float* amax_part, void* stream) {
+                    const float* q_scale, float* amax_part, float* dwh_unscale, void* stream) {
   RV_REQUIRE(dmulv_bf16 && wh_bf16 && h1_bf16 && (dp1_bf16 || dp1_fp8) && dwh_slabs, RV_ERR_NULL, "rv_heads_bwd: null pointer");
   RV_REQUIRE(!dp1_fp8 || (q_scale && ldq >= Hp && ldq % 16 == 0 && ((uintptr_t)dp1_fp8 & 15) == 0), RV_ERR_SHAPE,
              "rv_heads_bwd: the fp8 output needs a scale and 16-byte aligned rows");
@@ -809,16 +848,18 @@ int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const
   RV_REQUIRE((((uintptr_t)dmulv_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)h1_bf16 | (uintptr_t)dp1_bf16 | (uintptr_t)dwh_slabs) & 15) == 0,
              RV_ERR_SHAPE, "rv_heads_bwd: operands must be 16-byte aligned");
   RV_REQUIRE(!dp1_bf16 || (ldp >= Hp && ldp % 8 == 0), RV_ERR_SHAPE, "rv_heads_bwd: bad leading dimension of dP1");
-  const bool q8 = dp1_fp8 || amax_part;
-  auto kern = q8 ? k_heads_bwd<true> : k_heads_bwd<false>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[q8]) {
+  const bool q8 = dp1_fp8 || amax_part, h16 = dwh_unscale != nullptr;
+  RV_REQUIRE(!h16 || Hp % 32 == 0, RV_ERR_SHAPE, "rv_heads_bwd: fp16 slabs need a padded hidden width that is a multiple of 32");
+  auto kern = q8 ? (h16 ? k_heads_bwd<true, true> : k_heads_bwd<true, false>) : (h16 ? k_heads_bwd<false, true> : k_heads_bwd<false, false>);
+  static bool attr_done[4] = {false, false, false, false};
+  const int which = 2 * q8 + h16;
+  if (!attr_done[which]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
-    attr_done[q8] = true;
+    attr_done[which] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
-                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part);
+                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -116,6 +116,7 @@ struct rv_plan {
   int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax" for h3's maxima
   int n_amax_dp1 = 0;          // ... and for dP1's behind them (fp8 weight gradient of fc1)
   int n_amax_h3 = 0;           // how many of h3's the forward in use writes (set by the forward phase)
+  bool heads_half = false;     // the streaming heads' backward writes fp16 dWh slabs (heads_mode_apply)
   bool fwd_for_fp8_w1 = false; // set by rv_plan_step_ddp around its forward call (fp8_w1)
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
@@ -166,10 +167,30 @@ static void heads_mode_apply(rv_plan* p) {
   p->d_slab[1].grad_splits = p->n_mt1;
   p->d_slab[2].grad_splits = p->s_wh;
   p->d_slab[4].grad_splits = p->s_wh;
+  // The streaming heads' backward writes its dWh slabs in the element type of the large weight gradients' (RV_OPT_SLAB_DTYPE):
+  // block-floating-point fp16 by default (rv_heads_bwd_ex), fp32 in the generic form and in the strict mode
+  const bool half = st && p->slab_dtype == RV_SLAB_F16 && p->Lp == 64 && p->Hp % 32 == 0;
+  p->heads_half = half;
+  float* dWh = (float*)p->ws("dWh");
+  float* us = (float*)p->ws("dWh_us");
+  const long us_ld = p->Hp / 32;
+  for (int i : {2, 4}) {   // fc21.weight = rows [0, Lp) of the stacked slab, fc22.weight = rows [Lp, 2 Lp)
+    rv_param_desc* d = p->d_slab + i;
+    d->grad_half = half;
+    d->grad_unscale = half ? us + (i == 4 ? (p->Lp / 32) * us_ld : 0) : nullptr;
+    d->us_ld = us_ld;
+    d->us_split_stride = (2 * p->Lp / 32) * us_ld;
+    // (grad_slabs is typed float*; with fp16 elements row Lp of the slab sits Lp * Hp HALF-elements behind its start)
+    d->grad_slabs = i == 2 ? dWh : (half ? dWh + p->Lp * p->Hp / 2 : dWh + p->Lp * p->Hp);
+  }
   if (!p->b.grad) {   // without a flat gradient arena d_flat mirrors the slab descriptors
     p->d_flat[1].grad_splits = p->n_mt1;
-    p->d_flat[2].grad_splits = p->s_wh;
-    p->d_flat[4].grad_splits = p->s_wh;
+    for (int i : {2, 4}) {
+      p->d_flat[i].grad_splits = p->s_wh;
+      p->d_flat[i].grad_half = p->d_slab[i].grad_half; p->d_flat[i].grad_unscale = p->d_slab[i].grad_unscale;
+      p->d_flat[i].us_ld = p->d_slab[i].us_ld; p->d_flat[i].us_split_stride = p->d_slab[i].us_split_stride;
+      p->d_flat[i].grad_slabs = p->d_slab[i].grad_slabs;
+    }
   }
 }
 
@@ -245,6 +266,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     p->s_w1_ddp = 2 * p->s_w1;
   p->add("dW1", (long)p->s_w1_ddp * Hp * Sp * 4);
   p->add("dWh", (long)(p->s_wh_gen > p->hb_groups ? p->s_wh_gen : p->hb_groups) * L2p * Hp * 4);
+  p->add("dWh_us", (long)(p->hb_groups > 0 ? p->hb_groups : 1) * 4 * (Hp / 32 + 1) * 4);   // fp16 dWh slabs: 2^-e per slab and granule
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
   p->add("dW1_us", (long)p->s_w1_ddp * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
@@ -346,6 +368,7 @@ static int plan_set_slab_dtype(rv_plan* p, int slab_dtype) {
       p->d_flat[i].grad_half = p->d_slab[i].grad_half; p->d_flat[i].grad_unscale = p->d_slab[i].grad_unscale;
       p->d_flat[i].us_ld = p->d_slab[i].us_ld; p->d_flat[i].us_split_stride = p->d_slab[i].us_split_stride;
     }
+  heads_mode_apply(p);   // the heads' slabs follow
   return RV_OK;
 }
 
@@ -540,11 +563,12 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
     if (f8_w1) {   // dP1 as fp8 only, its maxima behind h3's (fp8_w1)
       float* f8 = (float*)p->ws("fp8_state");
       return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, nullptr, 0, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
-                             p->ws("dP1q"), Hp, f8 + 13, (float*)p->ws("h3_amax") + p->n_amax_h3, stream);
+                             p->ws("dP1q"), Hp, f8 + 13, (float*)p->ws("h3_amax") + p->n_amax_h3,
+                             p->heads_half ? (float*)p->ws("dWh_us") : nullptr, stream);
     }
     if (heads_streaming(p))
-      return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
-                          stream);
+      return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
+                             nullptr, 0, nullptr, nullptr, p->heads_half ? (float*)p->ws("dWh_us") : nullptr, stream);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream);
   }
@@ -674,7 +698,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
   };
   auto heads_bwd = [&](void* st) {
     if (heads_streaming(p))
-      return rv_heads_bwd(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp, st);
+      return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
+                             nullptr, 0, nullptr, nullptr, p->heads_half ? (float*)p->ws("dWh_us") : nullptr, st);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
                                  (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, st);
   };
