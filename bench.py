@@ -22,7 +22,9 @@ rank exits non-zero instead of going on to a collective its peers will never joi
 Rank 0 prints ONE JSON line.  `roofline` is for the LONGEST launch of the step, found in this run: every launch of the
 step is timed IN the step with HIP events (a hipGraph of steps minus the same graph without that launch; `kernels` holds
 all nine rows).  `cpu_baseline` is the stock-PyTorch CPU port of the same step (oracle/torch_port.py) timed on this node's
-host cores (N=1 only).
+host cores (N=1 only).  Side lines at N=1 (never the headline; `--no-alts` skips them): `alt_fp8` / `alt_fp8_forward_only`
+(the fp8 weight path), `alt_fp32_slabs`, `alt_deep_c4` (BASELINE configs[3]) and `alt_api_loop` (the reference's loop
+unchanged through `rawvae.model` + `torch.optim.Adam`; host-bound).
 """
 import argparse
 import json
@@ -61,7 +63,7 @@ def parse():
                          "no per-kernel differential timing (its graphs leave launches out), no side lines; `roofline` is "
                          "then null and the profile's own per-kernel durations are the figures")
     ap.add_argument("--no-alts", action="store_true",
-                    help="skip the side lines `alt_fp8`, `alt_deep_c4` and `alt_fp32_slabs`; they are timed after the "
+                    help="skip the side lines `alt_fp8`, `alt_deep_c4`, `alt_fp32_slabs` and `alt_api_loop`; they are timed after the "
                          "headline at N=1 and never replace it")
     ap.add_argument("--slab-dtype", default=None, choices=["fp32", "fp16"],
                     help="element type of the fc1 / fc4 weight-gradient split-K slabs (default: the engine's)")
@@ -175,6 +177,59 @@ def time_launches_in_step(eng, x, steps=10, reps=7):
     ev[0].record(ts); full.launch(); ev[1].record(ts); full.launch(); ev[2].record(ts)
     ev[2].synchronize()
     return out, abs(ev[0].elapsed_time(ev[1]) - ev[1].elapsed_time(ev[2])) / steps * 1e3
+
+
+def time_api_loop(dev, pool, steps):
+    """Side line `alt_api_loop` (never the headline): the reference's training loop UNCHANGED (train.py:184-193) through
+    the drop-in surface -- `rawvae.model.VAE`, `loss_function`, `torch.optim.Adam(model.parameters())` -- on the headline's
+    shape and frames.  Host-bound (two autograd nodes and the stock optimizer wrapper per step), so the figure is the
+    host's as much as the GPU's; the same loop with the optimizer hook off (stock foreach Adam) is timed beside it."""
+    import torch
+    from rawaudiovae_kelsey_amd import optim_hook
+    from rawaudiovae_kelsey_amd.synth import make_params
+    from rawvae.model import VAE, loss_function
+    out = {"what": "the reference loop unchanged (zero_grad / model(x) / loss_function / backward / torch.optim.Adam.step) "
+                   "through rawvae.model at C2; host-bound"}
+    try:
+        def run(hook):
+            optim_hook.enabled = hook
+            torch.manual_seed(0)
+            m = VAE(S, H, L)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(S, H, L, 0).items()})
+            m = m.to(dev)
+            opt = torch.optim.Adam(m.parameters(), lr=LR)
+
+            def step(x):
+                opt.zero_grad()
+                recon, mu, logvar = m(x)
+                loss = loss_function(recon, x, mu, logvar, KL_BETA, S)
+                loss.backward()
+                opt.step()
+                return loss
+            for i in range(10):
+                step(pool[i % len(pool)])
+            torch.cuda.synchronize()
+            reps = []
+            for r in range(5):
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    loss = step(pool[i % len(pool)])
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - t0) / steps)
+            reps.sort()
+            return reps[len(reps) // 2], float(loss.item())
+        n0 = optim_hook.stats["fused_steps"]
+        t_on, loss_on = run(True)
+        took = optim_hook.stats["fused_steps"] - n0
+        t_off, _ = run(False)
+        out.update({"ms_per_step": t_on * 1e3, "value": float(B) / t_on, "unit": "frames/s", "final_loss": loss_on,
+                    "optimizer_steps_taken_by_the_fused_kernel": took, "repeats": 5,
+                    "ms_per_step_stock_optimizer_step": t_off * 1e3})
+    except Exception as exc:   # the headline is already measured: report, do not lose it
+        out["error"] = str(exc)[:200]
+    finally:
+        optim_hook.enabled = True
+    return out
 
 
 def time_deep_c4(dev, comp, steps, warmup):
@@ -610,8 +665,9 @@ def main():
             except Exception as exc:
                 alts["alt_deep_c4"] = {"what": "deep variant (BASELINE configs[3])", "error": str(exc)[:200]}
             alts["alt_fp32_slabs"] = time_alt(
-                "split-K partial sums of dW1 / dW4 stored as fp32 instead of block-floating-point fp16 (round 2's "
-                "default); everything else as the headline", slab_dtype="fp32")
+                "split-K partial sums of dW1 / dW4 (and of the heads' weight gradients) stored as fp32 instead of "
+                "block-floating-point fp16 (round 2's default); everything else as the headline", slab_dtype="fp32")
+            alts["alt_api_loop"] = time_api_loop(dev, pool, max(50, min(args.steps, 200)))
 
     if not all(map(lambda v: v == v and abs(v) < 1e3, last)):
         print("bench.py: non-finite loss %r" % (last,), file=sys.stderr)
