@@ -349,6 +349,7 @@ def test_flag_wait_behind_a_slow_collective_times_out_loudly_only_when_the_bound
         e = TrainEngine(S, H, L, B, kl_beta=1e-4, lr=1e-4, seed=1)
         e.load_params(make_params(S, H, L, 0))
         e.attach_comm(ddp_model.Comm(fake, 2, 30000.0, 300.0, blocks=4), payload="fp32")
+        lib().rv_plan_set_option(e._plan, _lib.OPT_DDP_SIGNAL, 1)     # device-side flags, whatever RV_DDP_SIGNAL says
         if wait_ms:
             lib().rv_plan_set_option(e._plan, _lib.OPT_DDP_WAIT_MS, wait_ms)
         with torch.cuda.stream(st):
