@@ -128,28 +128,36 @@ __device__ __forceinline__ void fp8_latch_block(float* st, const float* amax_par
   }
 }
 
-// max|W| of the two fp8 weight shadows as the optimizer left them, for next step's scales: 1024 blocks, each a slice of
+// max|W| of the two fp8 weight shadows as the optimizer left them, for next step's scales: 2 x 128 blocks, each a slice of
 // one shadow (first half of the grid: W1q, second half: W4q), max|q| / scale of the slice into the block's slot.  An
 // extra pass over 4 MB (~2 us with its launch) instead of a reduction inside the optimizer kernels, where one atomic per
 // wave on 64 cache lines cost 6 us and the loads to avoid them more.
+constexpr int WMAX_BLOCKS = 128;   // per tensor: 4 independent 16-byte loads per thread at C2 (2 MB shadows)
 __global__ void __launch_bounds__(256) k_fp8_wmax(const unsigned char* __restrict__ w1q, const long n1,
                                                   const unsigned char* __restrict__ w4q, const long n4, float* __restrict__ st) {
   __shared__ float red[4];
-  const int half = FP8_WSLOTS / 2;
-  const bool second = (int)blockIdx.x >= half;
+  const bool second = (int)blockIdx.x >= WMAX_BLOCKS;
   const unsigned char* q = second ? w4q : w1q;
   const long n = second ? n4 : n1;
-  const int b = (int)blockIdx.x - (second ? half : 0);
+  const int b = (int)blockIdx.x - (second ? WMAX_BLOCKS : 0);
+  const float inv_scale = 1.f / st[second ? 2 : 1];   // (requested with the data, not behind the reduction)
   float m = 0.f;
-  for (long i = ((long)b * 256 + threadIdx.x) * 16; i + 16 <= n; i += (long)half * 256 * 16) {
-    const uint4 v = *reinterpret_cast<const uint4*>(q + i);
-    const unsigned w[4] = {v.x & 0x7F7F7F7Fu, v.y & 0x7F7F7F7Fu, v.z & 0x7F7F7F7Fu, v.w & 0x7F7F7F7Fu};
+  constexpr long STRIDE = (long)WMAX_BLOCKS * 256 * 16;
+  for (long i = ((long)b * 256 + threadIdx.x) * 16; i + 16 <= n; i += 4 * STRIDE) {
+    uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 0));
-      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 1));
-      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 2));
-      m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 3));
+    for (int u = 0; u < 4; ++u)   // four loads in flight (a slice past the end reads the first one again: same maximum)
+      v[u] = *reinterpret_cast<const uint4*>(q + (i + u * STRIDE + 16 <= n ? i + u * STRIDE : i));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned w[4] = {v[u].x & 0x7F7F7F7Fu, v[u].y & 0x7F7F7F7Fu, v[u].z & 0x7F7F7F7Fu, v[u].w & 0x7F7F7F7Fu};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 0));
+        m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 1));
+        m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 2));
+        m = fmaxf(m, __builtin_amdgcn_cvt_f32_fp8((int)w[k], 3));
+      }
     }
   }
 #pragma unroll
@@ -158,8 +166,8 @@ __global__ void __launch_bounds__(256) k_fp8_wmax(const unsigned char* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    // two slot halves per tensor: block b of a tensor owns slot b of that tensor's 1024 (the upper 512 stay zero)
-    st[32 + (second ? FP8_WSLOTS : 0) + b] = m / st[second ? 2 : 1];
+    // block b of a tensor owns slot b of that tensor's 1024 (the rest stay zero)
+    st[32 + (second ? FP8_WSLOTS : 0) + b] = m * inv_scale;
   }
 }
 
@@ -844,7 +852,7 @@ int rv_fp8_wmax(const void* w1q, long n1, const void* w4q, long n4, float* fp8_s
   RV_REQUIRE(w1q && w4q && fp8_state, RV_ERR_NULL, "rv_fp8_wmax: null pointer");
   RV_REQUIRE(n1 > 0 && n4 > 0 && n1 % 16 == 0 && n4 % 16 == 0 && (((uintptr_t)w1q | (uintptr_t)w4q) & 15) == 0, RV_ERR_SHAPE,
              "rv_fp8_wmax: shadows must be 16-byte aligned multiples of 16 bytes");
-  hipLaunchKernelGGL(k_fp8_wmax, dim3(FP8_WSLOTS), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)w1q, n1,
+  hipLaunchKernelGGL(k_fp8_wmax, dim3(2 * WMAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)w1q, n1,
                      (const unsigned char*)w4q, n4, fp8_state);
   RV_CHECK_LAUNCH();
   return RV_OK;
