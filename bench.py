@@ -13,7 +13,8 @@ its 9 kernels back to back on one stream, eagerly (`--graph` replays them from a
 fast, consecutive replays are a few us apart).
 
 N > 1: one process per GPU; each step is one `rv_plan_step_ddp` call that also issues the RCCL collectives (all-reduce
-schedule, two buckets, bf16 gradient payload -- one default, fixed before anything is measured: DESIGN.md section 5;
+schedule, two buckets; the bf16 gradient payload by explicit choice of this bench -- named in `config.ddp_payload`, with
+the library's default, the exact fp32 mean, timed beside it as `alt_fp32_payload`: DESIGN.md section 5;
 `RV_DDP_MODE=sharded` / `RV_DDP_PAYLOAD=fp32` select the alternatives).  Weak scaling: per-GPU batch fixed.  Before it is
 timed the library-driven step is checked on scratch engines against the torch.distributed route; after every section
 that can fail on one rank alone the ranks AGREE on success (a MIN all-reduce) -- if any rank failed inside a step, every
@@ -269,7 +270,7 @@ def time_deep_c4(dev, comp, steps, warmup):
         def launch():
             Lb.rv_linear_dgrad_wgrad(ptr(eng.d_dec[depth - 1]), Hp, ptr(eng.shadow[wname]), Hp, ptr(eng.dec_act[depth - 2]), Hp,
                                      Bp, Hp, Hp, ptr(eng.d_dec[depth - 2]), Hp, ptr(eng.bias_part["dec.%d.bias" % (depth - 2)]),
-                                     ptr(eng.slabs[wname]), Hp, eng.splits[wname], 0, None, st)
+                                     ptr(eng.slabs[wname]), Hp, eng.splits[wname], *eng._slab_args(wname), st)
         for _ in range(5):
             launch()
         e0.record(comp)
@@ -283,7 +284,7 @@ def time_deep_c4(dev, comp, steps, warmup):
     kern_flops = 4.0 * Bd * Hd * Hd
     ach = kern_flops / (kern_us * 1e-6) / 1e12
     return {"what": "deep variant (BASELINE configs[3]): S=2048 H=2048 L=256, 3 H x H layers per side, B=4096, bf16, "
-                    "fp32 split-K slabs, eager launches",
+                    "%s split-K slabs for the large weight gradients, eager launches" % eng.slab_dtype,
             "ms_per_step": med / steps * 1e3, "value": float(Bd) * steps / med, "unit": "frames/s",
             "step_tflops": float(Bd) * steps / med * fpf / 1e12,
             "step_mfma_frac": float(Bd) * steps / med * fpf / 1e12 / PEAK_BF16_TFLOPS,
@@ -392,7 +393,9 @@ def main():
     runner, ddp_mode, comm = None, None, None
     native_fallback_reason, startup_check = None, None
     sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
-    payload = os.environ.get("RV_DDP_PAYLOAD", ddp.DEFAULT_PAYLOAD)
+    # the bench's exchange is an explicit choice, named in the line (config.ddp_payload): bf16 gradient payload -- what the
+    # 8-GPU target is sized against -- with the library's default (fp32, the exact mean) timed beside it (alt_fp32_payload)
+    payload = os.environ.get("RV_DDP_PAYLOAD", ddp.BENCH_PAYLOAD)
     if use_ddp:
         want_native = multi and backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch"
         ok = False
@@ -731,7 +734,7 @@ def main():
             **ddp_alts, **alts,
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "startup_check": startup_check,
-                "rccl_version": getattr(comm, "version", None),
+                "rccl_version": getattr(comm, "version", None), "rccl_ranks": getattr(comm, "rccl_count", None),
                 "comm_stream_pick": [{"us_per_round_trip": u, "candidates_tried": n} for u, n in ddp.comm_stream_report()]}
                if use_ddp else {}),
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,

@@ -475,9 +475,13 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     it follows a collective -- and timeouts are counted in ddp_flags[8], which must stay 0) -- or 0: HIP events (~9 us
  *     per crossing).  Steps enqueued under stream capture always use events (a graph needs the edges).
  *   RV_OPT_DDP_WAIT_MS  bound, in milliseconds, of a flag wait whose setter sits behind a collective, i.e. behind the
- *     slowest peer rank (default 600000 = ten minutes, the order of a collective library's own watchdog: ranks reach a
- *     step seconds apart around a checkpoint or an evaluation pass as a matter of course).  A wait that runs out is
- *     counted in ddp_flags[8]; the step's results are then invalid and the host side must raise.
+ *     slowest peer rank (default 30000 = thirty seconds: a spinning wave cannot be cancelled from the host, so the bound
+ *     is what a dead peer costs; ranks reach a step seconds apart around a checkpoint or an evaluation pass as a matter
+ *     of course -- a caller whose ranks drift further apart than that raises it, or synchronises the ranks first).  A
+ *     wait that runs out is counted in ddp_flags[8] and POISONS the plan on the device: the optimizer launches of
+ *     rv_plan_step_ddp read the count and apply no update while it is non-zero, so a partial all-reduce never reaches
+ *     the parameters; the host side must read the count (it is never cleared on the device), agree on it across ranks
+ *     and stop every rank.
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider

@@ -1057,9 +1057,10 @@ int rv_scale_by3(const float* a0, float* out0, long n0, const float* a1, float* 
   return RV_OK;
 }
 
-int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
-                  float* exp_avg_sq, float* grad_out, const void* grad_bf16, float lr, float grad_scale,
-                  const long long* step_counter, void* stream) {
+// rv_adam_multi whose update is withheld when `*poison` is non-zero (internal.h; plan.hip's data-parallel step).
+int rv_adam_multi_guarded(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
+                          float* grad_out, const void* grad_bf16, float lr, float grad_scale,
+                          const long long* step_counter, const int* poison, void* stream) {
   RV_REQUIRE(param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_adam_multi: null pointer");
   RV_REQUIRE(!(grad_bf16 && grad_out), RV_ERR_UNSUPPORTED, "rv_adam_multi: grad_out is the sum of the slabs; not with grad_bf16");
   DescTable tab;
@@ -1067,9 +1068,16 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
-                     step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16);
+                     step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16, poison);
   RV_CHECK_LAUNCH();
   return RV_OK;
+}
+
+int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg,
+                  float* exp_avg_sq, float* grad_out, const void* grad_bf16, float lr, float grad_scale,
+                  const long long* step_counter, void* stream) {
+  return rv_adam_multi_guarded(descs, n_desc, param, exp_avg, exp_avg_sq, grad_out, grad_bf16, lr, grad_scale, step_counter,
+                               nullptr, stream);
 }
 
 int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
@@ -1187,7 +1195,7 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                      out_bf16 ? (float*)nullptr : (float*)grad_out, 0.f, 1.f, (const long long*)nullptr,
-                     out_bf16 ? (bf16_t*)grad_out : (bf16_t*)nullptr, (const bf16_t*)nullptr);
+                     out_bf16 ? (bf16_t*)grad_out : (bf16_t*)nullptr, (const bf16_t*)nullptr, (const int*)nullptr);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -66,6 +66,11 @@ RV_INTERNAL int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf
 // stream until the flag has reached `value` (bounded; timeouts are counted in *timeouts).
 RV_INTERNAL int rv_flag_set(int* flag, int value, void* stream);
 RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, long max_ms, void* stream);
+// rv_adam_multi that withholds the update when `*poison` is non-zero (poison may be NULL): the data-parallel step passes
+// its count of flag waits that ran out, so that a step whose exchange did not complete in time changes no parameter.
+RV_INTERNAL int rv_adam_multi_guarded(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
+                                      float* grad_out, const void* grad_bf16, float lr, float grad_scale,
+                                      const long long* step_counter, const int* poison, void* stream);
 // rv_linear_wgrad_adam's launch shape (256 x 256 weight-gradient GEMM + rider blocks on the idle CUs) whose riders sum
 // the gradient slabs of `descs` into a flat payload arena instead of updating them (gemm_launch.hip).
 RV_INTERNAL int rv_linear_wgrad_finalize(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,

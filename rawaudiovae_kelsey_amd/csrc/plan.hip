@@ -118,9 +118,10 @@ struct rv_plan {
   int n_amax_h3 = 0;           // how many of h3's the forward in use writes (set by the forward phase)
   bool heads_half = false;     // the streaming heads' backward writes fp16 dWh slabs (heads_mode_apply)
   bool fwd_for_fp8_w1 = false; // set by rv_plan_step_ddp around its forward call (fp8_w1)
+  bool last_fwd_f8_w1 = false; // what the most recent forward phase decided (fp8_w1): the backward follows IT, not its own phase mask
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
-  long ddp_wait_ms = 600000;   // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
+  long ddp_wait_ms = 30000;    // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
   int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
   int ddp_w1_wide = 0;
   int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
@@ -611,6 +612,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // gradients gets its bf16 dP4 from rv_tanh_bwd_pack)
     const bool f8_bwd = fp8_bwd_possible(p);
     const bool f8_w1 = fp8_w1(p, full_local);     // then nothing reads the frames' bf16 copy: it is not written
+    p->last_fwd_f8_w1 = f8_w1;
     void* xb_out = f8_w1 ? nullptr : xb;
     const int n_amax2 = f8_w1 ? p->n_amax_dp1 : 0;
     int n_amax = 0;
@@ -722,7 +724,10 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     }
     {
       Range r(p->roctx, "rv:rest-bwd");
-      const bool f8_w1 = fp8_w1(p, true);
+      // fc1's weight gradient on fp8 operands only when the FORWARD of this step prepared it (no bf16 copy of the frames,
+      // dP1's delayed scale latched from the previous step's maxima): a forward enqueued by a call of its own
+      // (RV_PHASE_FWD alone is not a full local step) wrote the bf16 copies, and this backward reads those
+      const bool f8_w1 = p->last_fwd_f8_w1 && fp8_w1(p, true);
       RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream, f8_w1));
       // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
       // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
@@ -1019,12 +1024,13 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-reduce of gradient bucket %d failed (collective library code %d)", b, nrc);
     return RV_OK;
   };
+  // (guarded: a flag wait in front of an update that ran out has left a non-zero count in ddp_flags[8]; from then on no
+  // update is applied -- the parameters stay what the last complete exchange made them -- until the host has seen the
+  // count and raised: a partial all-reduce never reaches the weights)
+  const int* poison = (const int*)p->ws("ddp_flags") + 8;
   auto adam_bucket = [&](int t0, int n) -> int {
-    if (p->payload_bf16)
-      return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, p->grad_bf16, lr,
-                                    scale, p->b.step_counter, stream);
-    return rv_adam_multi(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, scale,
-                         p->b.step_counter, stream);
+    return rv_adam_multi_guarded(p->d_flat + t0, n, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr,
+                                 p->payload_bf16 ? p->grad_bf16 : nullptr, lr, scale, p->b.step_counter, poison, stream);
   };
   // forward + loss and the paired fc4 backward (as rv_plan_step)
   p->fwd_for_fp8_w1 = riders && s_w1 == p->s_w1;

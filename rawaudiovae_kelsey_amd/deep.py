@@ -16,7 +16,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import ACT_RELU, ParamDesc, dgrad_wgrad_pick, gemm_pick, gemm_tile, lib, pad_dims, ptr, stream_ptr
+from ._lib import (ACT_RELU, SLAB_F16, SLAB_F32, ParamDesc, dgrad_wgrad_pick, gemm_pick, gemm_tile, lib, pad_dims, ptr,
+                   stream_ptr)
 
 
 def param_names(depth):
@@ -42,9 +43,10 @@ class DeepVAE(nn.Module):
         self.dec = nn.ModuleList([nn.Linear(latent_dim if i == 0 else n_units, n_units) for i in range(depth)])
         self.fc4 = nn.Linear(n_units, segment_length)
 
-    def engine(self, batch_size, kl_beta, lr, seed=0, ring=256):
+    def engine(self, batch_size, kl_beta, lr, seed=0, ring=256, slab_dtype="fp16"):
         eng = DeepTrainEngine(self.segment_length, self.n_units, self.latent_dim, self.depth, batch_size,
-                              device=self.fc4.weight.device, kl_beta=kl_beta, lr=lr, seed=seed, ring=ring)
+                              device=self.fc4.weight.device, kl_beta=kl_beta, lr=lr, seed=seed, ring=ring,
+                              slab_dtype=slab_dtype)
         eng.adopt(self)
         return eng
 
@@ -52,8 +54,17 @@ class DeepVAE(nn.Module):
 class DeepTrainEngine:
     """Whole-step engine for `DeepVAE`, sequenced in Python over the C ABI."""
 
-    def __init__(self, S, H, L, depth, batch_size, device="cuda", kl_beta=1e-4, lr=1e-4, seed=0, ring=256):
+    def __init__(self, S, H, L, depth, batch_size, device="cuda", kl_beta=1e-4, lr=1e-4, seed=0, ring=256,
+                 slab_dtype="fp16"):
+        """slab_dtype: element type of the split-K slabs of the LARGE weight gradients (every layer whose padded extents
+        are multiples of 32 and 8: the H x H layers, the first and the last) -- "fp16" (default, as TrainEngine's):
+        block-floating-point fp16 with one power-of-two scale per 32 x 32 granule and slab (half the bytes the
+        weight-gradient GEMMs write and the optimizer reads back: 200 of the step's ~900 MB of optimizer-side traffic at
+        the C4 shape); "fp32".  The latent-sized gradients (heads, dec.0) keep fp32 slabs."""
         self.S, self.H, self.L, self.depth, self.B = int(S), int(H), int(L), int(depth), int(batch_size)
+        if slab_dtype not in ("fp16", "fp32"):
+            raise _lib.RvError("slab_dtype %r (expected 'fp16' or 'fp32')" % (slab_dtype,))
+        self.slab_dtype = slab_dtype
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.RvError("DeepTrainEngine needs a GPU device; there is no CPU path")
@@ -109,6 +120,7 @@ class DeepTrainEngine:
         self.dz_slabs = z_(self.s_dz, Bp, Lp, **f32)
         # per-tensor shadows, gradient slabs and bias-gradient partials
         self.shadow, self.slabs, self.splits, self.bias_part = {}, {}, {}, {}
+        self.unscale = {}      # name -> [splits, rows_p / 32, cols_p / 32] fp32: 2^-e per granule of an fp16 slab
 
         def weight(name, rows_p, cols_p):
             self.shadow[name] = z_(rows_p, cols_p, **bf)
@@ -129,15 +141,19 @@ class DeepTrainEngine:
         self.plan_hh = dgrad_wgrad_pick(Bp, Hp, Hp)             # H x H layers
         self.plan_heads = dgrad_wgrad_pick(Bp, Hp, 2 * Lp)       # heads: dy [Bp,2Lp], W [2Lp,Hp]
 
-        def slab(name, splits, rows_p, cols_p):
+        def slab(name, splits, rows_p, cols_p, half_ok=False):
             self.splits[name] = splits
-            self.slabs[name] = z_(splits, rows_p, cols_p, **f32)
-        slab("fc4.weight", self.plan_out[2], Sp, Hp)
+            if half_ok and self.slab_dtype == "fp16" and rows_p % 32 == 0 and cols_p % 32 == 0:
+                self.slabs[name] = z_(splits, rows_p, cols_p, dtype=torch.float16, device=dev)
+                self.unscale[name] = z_(splits, rows_p // 32, cols_p // 32, **f32)
+            else:
+                self.slabs[name] = z_(splits, rows_p, cols_p, **f32)
+        slab("fc4.weight", self.plan_out[2], Sp, Hp, True)
         for i in range(1, d):
-            slab("dec.%d.weight" % i, self.plan_hh[2], Hp, Hp)
-            slab("enc.%d.weight" % i, self.plan_hh[2], Hp, Hp)
+            slab("dec.%d.weight" % i, self.plan_hh[2], Hp, Hp, True)
+            slab("enc.%d.weight" % i, self.plan_hh[2], Hp, Hp, True)
         slab("dec.0.weight", gemm_pick(Hp, Lp, Bp)[2], Hp, Lp)
-        slab("enc.0.weight", gemm_pick(Hp, Sp, Bp)[2], Hp, Sp)
+        slab("enc.0.weight", gemm_pick(Hp, Sp, Bp)[2], Hp, Sp, True)
         slab("heads.weight", self.plan_heads[2], 2 * Lp, Hp)
         # bias-gradient partial rows: produced by the kernel that creates the layer's dY
         self.bias_part["fc4.bias"] = z_(Bp // bm_o, Sp, **f32)
@@ -235,7 +251,16 @@ class DeepTrainEngine:
                 bp = self.bias_part[k]
                 g = (bp.data_ptr(), bp.shape[1], bp.shape[1], bp.shape[0])
             descs[i] = ParamDesc(self.offsets[k], rows, cols, g[0], g[1], g[2], g[3], sb, sf, ld)
+            us = self.unscale.get(k)
+            if us is not None:     # fp16 slabs: the optimizer multiplies each slab value by its granule's 2^-e
+                descs[i].grad_half, descs[i].grad_unscale = 1, us.data_ptr()
+                descs[i].us_ld, descs[i].us_split_stride = us.shape[2], us.shape[1] * us.shape[2]
         return descs
+
+    def _slab_args(self, name):
+        """(slab_dtype, unscale table) of a weight's gradient slabs, as rv_linear_dgrad_wgrad / rv_linear_wgrad take them."""
+        us = self.unscale.get(name)
+        return (SLAB_F16, us.data_ptr()) if us is not None else (SLAB_F32, None)
 
     # ---- one training step ---------------------------------------------
     def step(self, x, eps=None, recon_out=None, adam=True, stream=None):
@@ -270,7 +295,7 @@ class DeepTrainEngine:
             # dy [Bp,kd] is the gradient at the output of layer `wname`, whose input is dec_act[i]
             L_.rv_linear_dgrad_wgrad(ptr(dy), kd, W(wname), Hp, ptr(self.dec_act[i]), Hp, Bp, Hp, kd,
                                      ptr(self.d_dec[i]), Hp, ptr(self.bias_part["dec.%d.bias" % i]),
-                                     ptr(self.slabs[wname]), Hp, self.splits[wname], 0, None, st)
+                                     ptr(self.slabs[wname]), Hp, self.splits[wname], *self._slab_args(wname), st)
             dy, kd, wname = self.d_dec[i], Hp, "dec.%d.weight" % i
         # dec.0: input is z (no ReLU): dz as fp32 slabs, weight gradient separately
         L_.rv_linear_dgrad_wgrad_f32(ptr(dy), Hp, W("dec.0.weight"), Lp, ptr(self.z), Lp, Bp, Lp, Hp,
@@ -285,11 +310,11 @@ class DeepTrainEngine:
         for i in range(d - 1, -1, -1):
             L_.rv_linear_dgrad_wgrad(ptr(dy), kd, wptr, Hp, ptr(self.enc_act[i]), Hp, Bp, Hp, kd,
                                      ptr(self.d_enc[i]), Hp, ptr(self.bias_part["enc.%d.bias" % i]),
-                                     ptr(self.slabs[wname]), Hp, self.splits[wname], 0, None, st)
+                                     ptr(self.slabs[wname]), Hp, self.splits[wname], *self._slab_args(wname), st)
             dy, kd, wname = self.d_enc[i], Hp, "enc.%d.weight" % i
             wptr = W(wname)
         L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"], -1,
-                           ptr(self.slabs["enc.0.weight"]), Sp, 0, None, st)
+                           ptr(self.slabs["enc.0.weight"]), Sp, *self._slab_args("enc.0.weight"), st)
         if adam:
             for chunk in self._chunks:
                 L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, None,

@@ -212,6 +212,8 @@ class TrainEngine:
         owner rank only: they are gathered first (a collective -- every rank reaches this point together, because
         the engines of all ranks step in the same order), or this engine would compute with stale weights for
         (world - 1) / world of the arena."""
+        self._await_init(stream)      # first: the parameters may have been written on another stream, and everything
+                                      # below (the masters' gather, the fp8 maxima, the shadow rebuild) reads them on `stream`
         owner = self._shared.get("bf16_gather_engine")
         if owner is not None:
             # the gather is torch.distributed collectives plus arena copies: they must run ON `stream`, behind the
@@ -242,7 +244,6 @@ class TrainEngine:
                     st[13] = 56.0 * self.B * self.S
                 st[8:10] = 0.0   # max|W| of the last update: none yet for these weights
                 self.buffer("fp8_state", torch.float32, (-1,))[32:] = 0.0
-        self._await_init(stream)      # (the parameters may have been written on another stream)
         lib().rv_plan_refresh_shadows(self._plan, stream_ptr(stream))
         self._shadow_version = self._shared["version"]
 
@@ -322,8 +323,8 @@ class TrainEngine:
         the fp8 forward) all-gathers a 16-bit message -- bf16 of the updated weights plus the biases in fp32,
         half the bytes; every rank's operand shadows and biases are bit-identical to the "fp32" route, but fp32
         weight masters are then current on their owner rank only (`ddp.gather_sharded_params` before a
-        checkpoint); "fp32" all-gathers the fp32 parameters.  payload (all-reduce schedule only): "bf16" (the
-        default, `ddp.DEFAULT_PAYLOAD`: half the bytes on the links) or "fp32" (the exact mean) -- `set_ddp_payload`."""
+        checkpoint); "fp32" all-gathers the fp32 parameters.  payload (all-reduce schedule only): "fp32" (the
+        default, `ddp.DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in: half the bytes on the links) -- `set_ddp_payload`."""
         if sharded:
             from .ddp import ShardPlan
             self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
@@ -358,7 +359,7 @@ class TrainEngine:
         self._comm = comm   # keep the communicator alive as long as the plan can use it
         # cross-stream edges of the all-reduce schedule: device-side flags (default) or HIP events (RV_DDP_SIGNAL=event)
         lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 0 if os.environ.get("RV_DDP_SIGNAL") == "event" else 1)
-        # how long a flag wait behind a collective -- i.e. behind the slowest peer -- may last (default: ten minutes)
+        # how long a flag wait behind a collective -- i.e. behind the slowest peer -- may last (default: thirty seconds)
         if os.environ.get("RV_DDP_WAIT_MS"):
             lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_WAIT_MS, int(os.environ["RV_DDP_WAIT_MS"]))
         # RV_DDP_W1_WIDE=1 / set_ddp_w1_wide(True): fc1's weight gradient on all CUs in the all-reduce schedule (twice the
@@ -475,9 +476,12 @@ class TrainEngine:
         return n
 
     def check_ddp_signals(self):
-        """The data-parallel step's device-side flag waits are bounded (5 s behind local kernels, RV_DDP_WAIT_MS -- ten
-        minutes by default -- behind a collective); one that ran out left its consumer running on incomplete data.  Raises if any did since the engine was created (include/rawvae_hip.h,
-        RV_OPT_DDP_SIGNAL).  Called wherever the host reads results back anyway."""
+        """The data-parallel step's device-side flag waits are bounded (5 s behind local kernels, RV_DDP_WAIT_MS --
+        thirty seconds by default -- behind a collective).  One that ran out has poisoned the plan on the device: no
+        optimizer update has been applied since (include/rawvae_hip.h, RV_OPT_DDP_WAIT_MS), so the parameters are those
+        of the last complete step -- but the steps since are lost and this rank's peers are still exchanging.  Raises if
+        any did since the engine was created.  Called wherever the host reads results back anyway; a multi-rank caller
+        agrees on `ddp_timeouts()` across ranks and stops them together (train.py DataParallel.check)."""
         if getattr(self, "_comm", None) is None:
             return
         fl = getattr(self, "_ddp_flags", None)
@@ -485,8 +489,19 @@ class TrainEngine:
             fl = self._ddp_flags = self.buffer("ddp_flags", torch.int32, (-1,))
         n = int(fl[8].item())
         if n:
-            raise _lib.RvError("data-parallel step: %d cross-stream flag wait(s) timed out -- the steps since the last check "
-                               "ran on incomplete gradients; their results are invalid (RV_DDP_SIGNAL=event selects HIP events)" % n)
+            raise _lib.RvError("data-parallel step: %d cross-stream flag wait(s) timed out -- no optimizer update has been "
+                               "applied since the first one (the parameters are those of the last complete step); a peer rank "
+                               "is more than RV_DDP_WAIT_MS behind or gone (RV_DDP_SIGNAL=event selects HIP events)" % n)
+
+    def ddp_timeouts(self):
+        """Count of flag waits that ran out (0 = healthy; synchronises).  Does not raise: for callers that must first
+        agree with their peer ranks on what to do."""
+        if getattr(self, "_comm", None) is None:
+            return 0
+        fl = getattr(self, "_ddp_flags", None)
+        if fl is None:
+            fl = self._ddp_flags = self.buffer("ddp_flags", torch.int32, (-1,))
+        return int(fl[8].item())
 
     def last_loss(self):
         """(total, mse, kld) of the most recent step; synchronises."""

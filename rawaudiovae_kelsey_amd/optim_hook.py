@@ -10,10 +10,18 @@ This module lets the UNCHANGED loop use it: a global optimizer step pre-hook (to
 register_optimizer_step_pre_hook) recognises a param group of a plain `torch.optim.Adam` that holds all ten parameters
 of a `rawvae.model.VAE` whose forward ran through the one-node path (fused.py: the Parameters are views of one fp32
 arena), with hyper-parameters `rv_adam_multi` implements (betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad /
-maximize / capturable / differentiable -- the reference's construction), performs the update with ONE launch, and takes
-those parameters out of the group's list for the duration of the stock step (which then finds nothing to do for
-them), putting the list back in the post-hook.  Everything else -- other optimizers, other parameter groups, other
-parameters of the same group, other hyper-parameters, closures -- is left to PyTorch untouched.
+maximize / capturable / differentiable -- the reference's construction), performs the update with ONE launch, and hides
+those parameters' `.grad` for the duration of the stock step (which skips parameters without a gradient, as it always
+does), putting the gradients back in the post-hook.  The group's parameter list is never touched: if the stock step
+raises, `zero_grad()` / `state_dict()` / `add_param_group()` see the optimizer whole (round-4 advisor; round 4 swapped
+the list and restored it in the post-hook, which a raising step never reaches).  Everything else -- other optimizers,
+other parameter groups, other parameters of the same group, other hyper-parameters, closures -- is left to PyTorch
+untouched.
+
+torch entry points this module leans on beyond the documented optimizer-hook API are feature-tested at import
+(`_probe`): `torch.autograd.graph.increment_version` (public since 2.2; without it the hook is OFF and every step is
+PyTorch's own -- the public path) and `torch._foreach_add_` (private name; without it the ten step counters are bumped
+one by one with `Tensor.add_`).  `missing` says what was not found.
 
 What stays PyTorch's: `optimizer.state[p]` keeps torch's layout (`step`, `exp_avg`, `exp_avg_sq`), so
 `optimizer.state_dict()` / `load_state_dict()` and the reference's checkpoints (train.py:208-212) are unchanged; the
@@ -34,8 +42,31 @@ enabled = os.environ.get("RV_OPTIM_HOOK", "1") != "0"
 stats = {"fused_steps": 0, "declined": {}}   # how often the hook took a step over / why it left one to PyTorch
 _installed = False
 _OWNER = {}            # id(Parameter) -> (weakref(Parameter), weakref(module))
-_STASH = weakref.WeakKeyDictionary()   # optimizer -> [(group, its full parameter list), ...] while the stock step runs
+_STASH = weakref.WeakKeyDictionary()   # optimizer -> [(parameters, their gradients), ...] while the stock step runs
 _T_RING = {}           # device -> int64 tensor [1, 2, 3, ...]: the step number is passed as a pointer into it
+
+
+def _probe(t=torch):
+    """Which of the torch entry points beyond the documented hook API exist in this torch: -> (bump_versions or None,
+    add_one_to_each, [names not found]).  `bump_versions(params)` marks tensors as modified in place for autograd;
+    without it the hook cannot tell autograd about its update and stays off."""
+    missing = []
+    bump = getattr(getattr(getattr(t, "autograd", None), "graph", None), "increment_version", None)
+    if bump is None:
+        missing.append("torch.autograd.graph.increment_version")
+    foreach_add = getattr(t, "_foreach_add_", None)
+    if foreach_add is None:
+        missing.append("torch._foreach_add_")
+
+        def add_one(tensors, value=1):       # the public spelling, one host call per counter
+            for x in tensors:
+                x.add_(value)
+    else:
+        add_one = foreach_add
+    return bump, add_one, missing
+
+
+_bump_versions, _add_to_each, missing = _probe()
 
 
 def register(module, params):
@@ -117,15 +148,21 @@ def _discover(opt):
 def _restore(opt):
     stash = _STASH.pop(opt, None)
     if stash:
-        for group, full in stash:
-            group["params"] = full
+        for params, grads in stash:
+            for q, g in zip(params, grads):
+                q.grad = g
 
 
 def _pre_step(opt, args, kwargs):
     # (`args` is the step call's positional arguments INCLUDING the optimizer itself)
     if not enabled or not _OWNER:
         return None
-    _restore(opt)     # (a stock step that raised never reached the post-hook)
+    # a stock step that raised never reached the post-hook: the gradients it left hidden were consumed by the fused
+    # update of THAT step and must not come back under a later one
+    _STASH.pop(opt, None)
+    if _bump_versions is None:
+        _decline("this torch lacks " + missing[0])
+        return None
     if len(args) > 1 or kwargs.get("closure") is not None:
         return None
     from . import fused, ops
@@ -157,18 +194,20 @@ def _pre_step(opt, args, kwargs):
         if not ok:
             _decline("gradients missing / not dense fp32 on the device")
             continue
-        _fused_adam(opt, group, holder, eng, params, grads)
+        if not _fused_adam(opt, group, holder, eng, params, grads):
+            continue
         stats["fused_steps"] += 1
-        # the stock step that follows must not touch these parameters: they leave the group's list until the post-hook
-        # (two dictionary writes instead of hiding and restoring ten .grad fields)
-        _STASH.setdefault(opt, []).append((group, group["params"]))
-        group["params"] = others
+        # the stock step that follows must not touch these parameters: it skips parameters without a gradient, so their
+        # gradients are hidden until the post-hook.  The group's list stays whole whatever the stock step does.
+        _STASH.setdefault(opt, []).append((params, grads))
+        for q in params:
+            q.grad = None
         # the kernel refreshed this engine's operand shadows; the per-layer Functions' caches (ops.py) are stale
         ops.invalidate_shadows()
         eng._shared["version"] += 1
         eng._shadow_version = eng._shared["version"]
         # an in-place update as far as autograd is concerned (what torch.optim's own kernels do to the version counters)
-        torch.autograd.graph.increment_version(params)
+        _bump_versions(params)
         holder.versions = tuple([q._version for q in params]) + (ops._EPOCH[0],)
     return None
 
@@ -202,14 +241,18 @@ def _fused_adam(opt, group, holder, eng, params, grads):
                     cache["v"][i].copy_(st["exp_avg_sq"])
             st["exp_avg"], st["exp_avg_sq"] = cache["m"][i], cache["v"][i]
         cache["steps"] = [state[p]["step"] for p in params]
-        steps = [float(v) for v in cache["steps"]]
-        if min(steps) != max(steps):
-            raise _lib.RvError("optimizer state: the VAE's parameters are at different step counts (%r)" % (steps,))
         st0 = state[params[0]]
     step_tensors = cache["steps"]
     if step_tensors is None or st0["step"] is not step_tensors[0]:      # (state replaced behind the moments' back)
         step_tensors = cache["steps"] = [state[p]["step"] for p in params]
-    t = int(float(step_tensors[0])) + 1
+    # The kernel applies ONE bias correction to all ten tensors.  A stock step in between that skipped some of them
+    # (gradient None: the reference's loop never does that, a frozen layer would) leaves their counters behind; checked
+    # on every call (ten host scalars), and such a step is PyTorch's.
+    steps = [float(v) for v in step_tensors]
+    if min(steps) != max(steps):
+        _decline("parameters at different step counts")
+        return False
+    t = int(steps[0]) + 1
     descs = cache["descs"].get(eng.B)
     if descs is None:
         descs = (_lib.ParamDesc * 10)(*eng.plan_descs())
@@ -223,4 +266,5 @@ def _fused_adam(opt, group, holder, eng, params, grads):
     lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
     lib().rv_adam_multi(descs, 10, ptr(eng.param), ptr(eng.exp_avg), ptr(eng.exp_avg_sq), None, None, lr, 1.0,
                         _t_ptr(eng.device, t), stream_ptr())
-    torch._foreach_add_(step_tensors, 1)
+    _add_to_each(step_tensors, 1)
+    return True

@@ -90,8 +90,9 @@ def main():
         torch.cuda.synchronize()
         if not agree(same_on_all_ranks(eb.param)):
             failures.append("%r torch.distributed route: replicas differ" % ((S, H, L, B),))
-        # (mode, payload, gather, wide): `wide` = fc1's weight gradient with twice the local step's K splits (the default
-        # of the all-reduce schedule); with the local split count and the fp32 payload the arithmetic is the reference's
+        # (mode, payload, gather, wide): `wide` = fc1's weight gradient with twice the local step's K splits on all CUs
+        # (opt-in: RV_OPT_DDP_W1_WIDE, off by default); with the local split count and the fp32 payload the arithmetic
+        # is the reference's
         modes = (("allreduce", "fp32", None, False), ("allreduce", "fp32", None, True), ("allreduce", "bf16", None, True),
                  ("sharded", None, "fp32", True), ("sharded", None, "bf16", True))
         for mode, payload, gather, wide in modes:
@@ -126,6 +127,54 @@ def main():
                 failures.append(tag + ": differs from the torch.distributed route (rank %d: mean %.3g max %.3g, lr %.1g; per tensor "
                                 "mean/max: %s; losses %r vs %r)" % (rank, float(d.mean()), float(d.max()), LR, per, ea.losses(3), eb.losses(3)))
             del ra, ea
+        # ---- HIP against the ORACLE (not HIP against HIP): ONE step of the library-driven all-reduce schedule (fp32
+        # payload, the default) on per-rank batches with per-rank eps, against oracle.train_step on the CONCATENATED
+        # batch -- SURVEY 8e's exactness argument (equal per-rank batches: the mean of the ranks' gradients is the
+        # gradient of the global-batch mean loss).  After one Adam step from zero moments exp_avg = 0.1 g and
+        # exp_avg_sq = 0.001 g^2, so the moments ARE the averaged gradient: rel-L2 per tensor against the
+        # bf16-quantised oracle as tests/test_golden_gpu.py does for the local step (5e-3), parameters within Adam's first-step
+        # bound of it (every element moves by ~lr; sign flips of near-zero gradients aside), loss = mean of the ranks'.
+        import numpy as np
+        from oracle import vae_oracle as O
+        from oracle.inputs import PARAM_NAMES, make_eps
+        eo = fresh()
+        ro = ddp.NativeDdpRunner(eo, comm, st, payload="fp32")
+        eo.set_ddp_w1_wide(False)
+        xr = [make_frames(B, S, 900 + r) for r in range(world)]
+        er = [make_eps(B, L, 700 + r) for r in range(world)]
+        with torch.cuda.stream(st):
+            eo.step_ddp(torch.from_numpy(xr[rank]).to(dev), eps=torch.from_numpy(er[rank]).to(dev), stream=st)
+        torch.cuda.synchronize()
+        p64 = O.cast_params(make_params(S, H, L, 0), np.float64)
+        state = O.adam_init(p64)
+        xc, ec = np.concatenate(xr).astype(np.float64), np.concatenate(er).astype(np.float64)
+        loss_o, _, g_o = O.train_step(p64, state, xc, ec, 1e-4, LR, quant="bf16")
+        lt = torch.tensor([eo.last_loss()[0]], dtype=torch.float64)
+        dist.all_reduce(lt)
+        bad = []
+        if abs(float(lt.item()) / world - loss_o) > 2e-5 * abs(loss_o):
+            bad.append("loss: mean over ranks %.9g, oracle on the concatenated batch %.9g" % (float(lt.item()) / world, loss_o))
+        for k in PARAM_NAMES:
+            g_hip = eo.view(eo.exp_avg, k).double().cpu().numpy() / 0.1
+            rel = float(np.linalg.norm(g_hip - g_o[k]) / (np.linalg.norm(g_o[k]) + 1e-300))
+            tol = 5e-3
+            if rel > tol:
+                bad.append("%s: averaged gradient rel-L2 %.3g vs the oracle (tol %.0e)" % (k, rel, tol))
+            v_hip = eo.view(eo.exp_avg_sq, k).double().cpu().numpy() / 0.001
+            relv = float(np.linalg.norm(v_hip - g_o[k] ** 2) / (np.linalg.norm(g_o[k] ** 2) + 1e-300))
+            if relv > 4 * tol:
+                bad.append("%s: second moment rel-L2 %.3g vs the oracle" % (k, relv))
+            dp_ = np.abs(eo.view(eo.param, k).double().cpu().numpy() - p64[k])
+            if dp_.max() > 2.1 * LR or dp_.mean() > 0.05 * LR:
+                bad.append("%s: parameters after the step differ from oracle.train_step by max %.2f lr, mean %.3f lr"
+                           % (k, dp_.max() / LR, dp_.mean() / LR))
+        if not agree(same_on_all_ranks(eo.param)):
+            bad.append("replicas differ")
+        if not agree(not bad):
+            failures.append("%r native step vs oracle.train_step on the concatenated batch: %s" % ((S, H, L, B), "; ".join(bad) or "failed on another rank"))
+        elif rank == 0:
+            print("DDP_VS_ORACLE_OK %r" % ((S, H, L, B),), flush=True)
+        del ro, eo
         dist.barrier()
         comm.destroy()
     dist.barrier()
@@ -135,9 +184,17 @@ def main():
         print("DDP_SHM_FAILED rank %d:\n  " % rank + "\n  ".join(failures), flush=True)
     elif rank == 0:
         print("DDP_SHM_OK", flush=True)
-    # leave without running interpreter teardown: what is being tested has been decided above, and the order in which
-    # torch, the HIP runtime and ctypes-loaded libraries unload at exit is not this test's subject
-    os._exit(1 if failures else 0)
+    # Teardown in dependency order before the interpreter's own (engines hold plans whose events / streams belong to the
+    # HIP runtime, the stand-in communicator holds shared memory, the process group holds gloo's sockets): everything
+    # this test created is gone by here -- `del ra, ea` / `del ro, eo` per mode, comm.destroy(), destroy_process_group()
+    # above -- so a normal exit has nothing left to order.  RV_WORKER_HARD_EXIT=1 skips interpreter teardown altogether.
+    code = 1 if failures else 0
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    if os.environ.get("RV_WORKER_HARD_EXIT", "1") == "1":
+        os._exit(code)
+    sys.exit(code)
 
 
 if __name__ == "__main__":

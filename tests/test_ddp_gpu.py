@@ -14,10 +14,18 @@ pytestmark = pytest.mark.gpu
 from conftest import REPO  # noqa: E402
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (the rendezvous of a torch.distributed.run child)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_two_rank_bench_flow_keeps_replicas_identical():
     env = dict(os.environ, RV_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(REPO, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(REPO, "bench.py"),
            "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -39,7 +47,7 @@ def test_native_ddp_step_two_processes_one_gpu():
     assert os.path.exists(so), "tools/libfakecoll.so missing: __graft_entry__.build() compiles it"
     env = dict(os.environ, RV_COMM_STREAM_ALLOW_SLOW="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(REPO, "tests", "ddp_shm_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(REPO, "tests", "ddp_shm_worker.py")]
     # (Two processes time-share ONE GPU here, which exposed an ordering bug the one-process tests never showed: an engine
     # initialised on one stream and stepped on another without an edge between the two -- engine._note_init /
     # _await_init.  About one run in fifteen failed before that fix; 45 consecutive runs passed after it.)
@@ -54,6 +62,9 @@ def test_native_ddp_step_two_processes_one_gpu():
         except OSError:
             pass
     assert r.returncode == 0 and "DDP_SHM_OK" in r.stdout
+    # HIP against the oracle (the worker's last section): the two-process native step on per-rank batches equals
+    # oracle.train_step on the concatenated batch, at both shapes
+    assert r.stdout.count("DDP_VS_ORACLE_OK") == 2, r.stdout[-2000:]
 
 
 def test_native_rccl_step_one_rank_equals_local_step():
@@ -64,7 +75,7 @@ def test_native_rccl_step_one_rank_equals_local_step():
 import os, sys
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
-os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29578"
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", %r
 dist.init_process_group("gloo", rank=0, world_size=1)
 from oracle.inputs import make_frames, make_params
 from rawaudiovae_kelsey_amd import ddp
@@ -84,7 +95,7 @@ st.synchronize()
 comm = ddp.RcclComm()
 comm.self_test(torch.device("cuda", 0))
 eager = fresh(); eager.attach_comm(comm, payload="fp32"); eager.set_ddp_w1_wide(False)   # the local step's arithmetic
-assert ddp.DEFAULT_PAYLOAD == "bf16" and TrainEngine.ddp_payload_default() == "bf16"
+assert ddp.DEFAULT_PAYLOAD == "fp32" and TrainEngine.ddp_payload_default() == "fp32" and comm.rccl_count == 1
 with torch.cuda.stream(st):
     for _ in range(4):
         eager.step_ddp(x, stream=st)
@@ -134,7 +145,10 @@ del r8, d8
 # bf16 payload: the summed gradient is rounded to bf16 before the exchange; Adam's first steps move every
 # weight by ~lr whatever the gradient's magnitude, so the parameters stay within a fraction of lr of the
 # fp32-payload run (sign flips of near-zero gradients aside) and the loss trajectory within 1e-4
-bf = fresh(); bf.attach_comm(comm)      # the defaults: bf16 payload, fc1's weight gradient on all CUs
+df = fresh(); df.attach_comm(comm)      # the default: the exact fp32 mean
+assert df.ddp_payload == "fp32"
+del df
+bf = fresh(); bf.attach_comm(comm, payload="bf16")      # opt-in
 assert bf.ddp_payload == "bf16"
 with torch.cuda.stream(st):
     for _ in range(4):
@@ -177,7 +191,7 @@ assert torch.equal(shg.param, ref.param), "graph-replayed sharded step differs"
 comm.destroy()
 dist.destroy_process_group()
 print("NATIVE_OK")
-''' % REPO
+''' % (REPO, _free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0 and "NATIVE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
@@ -357,8 +371,15 @@ def test_flag_wait_behind_a_slow_collective_times_out_loudly_only_when_the_bound
                 e.step_ddp(x, stream=st)
         st.synchronize()
         return e
-    e = run(0)                      # default bound: the 30 ms collectives are simply waited for
-    assert e.steps_done() == 2
+    e = run(0)                      # default bound (30 s): the 30 ms collectives are simply waited for
+    assert e.steps_done() == 2 and e.ddp_timeouts() == 0
+    start = torch.from_numpy(__import__("numpy").concatenate([v.ravel() for v in make_params(S, H, L, 0).values()])).cuda()
+    assert not torch.equal(e.param, start)          # (it trained)
     e = run(5)                      # 5 ms: every wait behind a collective runs out
+    assert e.ddp_timeouts() > 0
     with pytest.raises(_lib.RvError, match="timed out"):
         e.steps_done()
+    # ... and the plan is poisoned on the device: the updates behind the waits that ran out were NOT applied (a partial
+    # all-reduce never reaches the weights), nor the moments touched
+    assert torch.equal(e.param, start)
+    assert not e.exp_avg.any() and not e.exp_avg_sq.any()

@@ -219,3 +219,32 @@ def test_fp8_full_step_on_resident_waveform_equals_step_on_gathered_frames_at_c2
     torch.cuda.synchronize()
     assert torch.equal(a.param, b.param) and a.losses(2) == b.losses(2)
     assert a.fp8_state()[13] == b.fp8_state()[13] != 56.0 * B * S       # dP1's scale has been latched from a measurement
+
+
+def test_fp8_split_phase_calls_follow_the_forwards_decision():
+    """A forward enqueued by a call of its own (RV_PHASE_FWD) is not a full local step: it writes the bf16 copy of the
+    frames and latches no scale for dP1.  A later backward + Adam call -- which, taken alone, looks like a full local
+    step -- must then run fc1's weight gradient on those bf16 operands, not on an fp8 image of dP1 whose scale was never
+    prepared (round-4 advisor).  Checked at C2 against the single-call step from the same weights: the same loss bit
+    for bit (the forward is the same), dP1's scale untouched and its fp8 image never written, every averaged gradient
+    (exp_avg / 0.1) within the fp8 path's tolerance of the single-call step's, fc1.weight's equal to the oracle's with
+    the bf16 backward's rounding points."""
+    from rawaudiovae_kelsey_amd import engine as E
+    S, H, L, B = 1024, 2048, 64, 4096
+    x = torch.from_numpy(make_frames(B, S, 1234)).cuda()
+    eps = torch.from_numpy(make_eps(B, L, 4321)).cuda()
+    one = _engine(S, H, L, B, fp8="full")
+    two = _engine(S, H, L, B, fp8="full")
+    guess = 56.0 * B * S
+    one.step(x, eps)
+    two.step(x, eps, phases=E.PHASE_FWD)
+    two.step(x, eps, phases=E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_ADAM)
+    torch.cuda.synchronize()
+    assert one.last_loss() == two.last_loss()
+    assert two.fp8_state()[13] == guess                                   # never latched, never used
+    assert not two.buffer("dP1q", torch.uint8, (-1,)).any()               # ... and its image never written
+    assert two.buffer("dP1", torch.bfloat16, (-1,)).any()                 # the bf16 dP1 was
+    for k in PARAM_NAMES:
+        a = two.view(two.exp_avg, k).cpu().numpy().astype(np.float64)
+        b = one.view(one.exp_avg, k).cpu().numpy().astype(np.float64)
+        assert _rel_l2(a, b) < (6e-2 if k == "fc1.weight" else 1e-3), (k, _rel_l2(a, b))

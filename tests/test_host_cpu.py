@@ -222,3 +222,47 @@ def test_plan_descriptors_follow_the_heads_backward_in_use():
         assert generic[1] == B // bm and generic[2] == generic[4] == sp
         assert [v for i, v in enumerate(fused) if i not in (1, 2, 4)] == [v for i, v in enumerate(generic) if i not in (1, 2, 4)]
         L.rv_plan_destroy(plan)
+
+
+def test_private_torch_entry_points_are_feature_tested_with_public_fallbacks(monkeypatch):
+    """The drop-in loop's host path leans on three torch entry points outside the documented API
+    (`torch.autograd.graph.increment_version`, `torch._foreach_add_`, `torch._C._cuda_getCurrentRawStream`).  Each is
+    looked up once and has a public fall-back; their absence is simulated here (no GPU needed):
+      * no raw-stream accessor -> `_lib.stream_ptr()` reads `torch.cuda.current_stream().cuda_stream`;
+      * no `_foreach_add_` -> the ten step counters are bumped with `Tensor.add_`;
+      * no `increment_version` -> the optimizer hook declines every step (PyTorch's own optimizer step runs: the public
+        path) and says why."""
+    import types
+
+    from rawaudiovae_kelsey_amd import _lib, optim_hook
+    # this torch has all three
+    bump, add, missing = optim_hook._probe()
+    assert bump is not None and missing == [] and optim_hook.missing == []
+    # a torch with neither of the optimizer hook's two
+    bare = types.SimpleNamespace(autograd=types.SimpleNamespace(graph=types.SimpleNamespace()))
+    bump, add, missing = optim_hook._probe(bare)
+    assert bump is None and missing == ["torch.autograd.graph.increment_version", "torch._foreach_add_"]
+    counters = [torch.tensor(0.0), torch.tensor(4.0)]
+    add(counters, 1)
+    assert [float(c) for c in counters] == [1.0, 5.0]
+    # the hook, with the version bump missing, leaves the step to PyTorch and records the reason
+    monkeypatch.setattr(optim_hook, "_bump_versions", None)
+    monkeypatch.setattr(optim_hook, "missing", ["torch.autograd.graph.increment_version"])
+    monkeypatch.setattr(optim_hook, "enabled", True)
+    monkeypatch.setitem(optim_hook._OWNER, -1, (lambda: None, lambda: None))     # "some model is registered"
+    before = dict(optim_hook.stats["declined"])
+    w = torch.nn.Parameter(torch.ones(3))
+    opt = torch.optim.Adam([w], lr=0.5)
+    w.grad = torch.ones(3)
+    assert optim_hook._pre_step(opt, (opt,), {}) is None
+    why = "this torch lacks torch.autograd.graph.increment_version"
+    assert optim_hook.stats["declined"].get(why, 0) == before.get(why, 0) + 1
+    opt.step()                                    # the stock step did the work
+    assert torch.allclose(w.detach(), torch.full((3,), 0.5))
+    # the stream accessor: private fast path when present, the public Stream object otherwise
+    monkeypatch.setattr(_lib, "_raw_stream", None)
+    monkeypatch.delattr(torch._C, "_cuda_getCurrentRawStream", raising=False)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: types.SimpleNamespace(cuda_stream=0x1234))
+    assert _lib.stream_ptr() == 0x1234
+    assert _lib.stream_ptr(types.SimpleNamespace(cuda_stream=0x77)) == 0x77
+    monkeypatch.setattr(_lib, "_raw_stream", None)     # (the next caller looks the accessor up again)

@@ -205,8 +205,12 @@ def test_train_py_data_parallel_two_ranks(tmp_path):
     ds = _dataset(tmp_path)
     ini = _ini(ds, training__batch_size="32")
     env = dict(os.environ, RV_DIST_BACKEND="gloo")
+    import socket
+    with socket.socket() as so:      # a port nobody listens on right now
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(REPO, "train.py"), "--config", str(ini)]
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(REPO, "train.py"), "--config", str(ini)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     out = r.stdout

@@ -27,10 +27,11 @@ def main():
     for k, v in (("S", 2048), ("H", 2048), ("L", 256), ("depth", 3), ("B", 4096), ("steps", 200), ("warmup", 20)):
         ap.add_argument("--" + k, type=int, default=v)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--slab-dtype", default="fp16", choices=["fp16", "fp32"])
     a = ap.parse_args()
     torch.manual_seed(0)
     m = DeepVAE(a.S, a.H, a.L, a.depth).cuda()
-    eng = m.engine(a.B, kl_beta=1e-4, lr=1e-4, seed=0)
+    eng = m.engine(a.B, kl_beta=1e-4, lr=1e-4, seed=0, slab_dtype=a.slab_dtype)
     x = torch.rand(a.B, a.S, device="cuda") * 2 - 1
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
@@ -54,7 +55,7 @@ def main():
     F = flops_per_frame(a.S, a.H, a.L, a.depth)
     print(json.dumps({"workload": "deep S=%d H=%d L=%d depth=%d B=%d" % (a.S, a.H, a.L, a.depth, a.B),
                       "frames_per_s": a.B / dt, "us_per_step": dt * 1e6, "model_tflops": F * a.B / dt / 1e12,
-                      "graph": not a.no_graph, "loss_first": eng.losses(a.steps)[0], "loss_last": eng.last_loss()[0]}))
+                      "graph": not a.no_graph, "slab_dtype": a.slab_dtype, "loss_first": eng.losses(a.steps)[0], "loss_last": eng.last_loss()[0]}))
 
 
 if __name__ == "__main__":

@@ -93,6 +93,7 @@ class DataParallel:
         self.device = device
         self.comm = None
         self.sharded = False
+        self.engines = []      # every engine the exchange is attached to (the full-batch one and the ragged tail's)
         if self.active:
             backend = os.environ.get("RV_DIST_BACKEND", "nccl")
             if backend == "nccl":
@@ -133,10 +134,27 @@ class DataParallel:
         self.dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def check(self):
+        """Health of the library-driven step, before results are read back (every rank calls it at the same points).
+        A flag wait that ran out on ANY engine of ANY rank (engine.ddp_timeouts: a peer more than RV_DDP_WAIT_MS behind,
+        or gone) has poisoned that plan -- its updates are withheld on the device -- while the other ranks went on.
+        Nothing after that can be trusted and a rank that raised alone would leave its peers inside the next collective,
+        so the ranks agree on the worst count and ALL leave, non-zero."""
+        if not self.active or self.comm is None:
+            return
+        n = sum(e.ddp_timeouts() for e in self.engines)
+        t = torch.tensor([n], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        if int(t.item()):
+            print("rank %d: data-parallel step: %d flag wait(s) timed out here, %d on the worst rank -- no update has been "
+                  "applied there since; stopping every rank" % (self.rank, n, int(t.item())), file=sys.stderr, flush=True)
+            os._exit(5)
+
     def prepare(self, engine):
         """Attach the exchange to an engine; returns its step function."""
         if not self.active:
             return engine.step
+        self.engines.append(engine)
         if self.comm is not None:
             # RV_DDP_MODE=allreduce (default): all-reduce and the full update on every rank;
             # RV_DDP_MODE=sharded: reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
@@ -147,7 +165,7 @@ class DataParallel:
             # masters gathered at checkpoints by sync_optimizer_state)
             engine.attach_comm(self.comm, sharded=self.sharded,
                                gather=os.environ.get("RV_SHARD_GATHER", "fp32") if self.sharded else None,
-                               payload=os.environ.get("RV_DDP_PAYLOAD"))   # all-reduce: bf16 by default, fp32 = exact mean
+                               payload=os.environ.get("RV_DDP_PAYLOAD"))   # all-reduce: fp32 (the exact mean) by default, bf16 opt-in
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
         sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
@@ -377,6 +395,7 @@ def main(argv=None):
 
         def drain():
             nonlocal train_loss, seen
+            dp.check()      # (every attached engine, agreed across ranks, before anything is read back)
             for v in engine.drain_losses():
                 writer.add_scalar('Loss/Batch', v, epoch * n_batches + seen)
                 writer.add_scalar('Learning Rate', learning_rate, epoch * n_batches + seen)
