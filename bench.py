@@ -184,7 +184,8 @@ def time_api_loop(dev, pool, steps):
     """Side line `alt_api_loop` (never the headline): the reference's training loop UNCHANGED (train.py:184-193) through
     the drop-in surface -- `rawvae.model.VAE`, `loss_function`, `torch.optim.Adam(model.parameters())` -- on the headline's
     shape and frames.  Host-bound (two autograd nodes and the stock optimizer wrapper per step), so the figure is the
-    host's as much as the GPU's; the same loop with the optimizer hook off (stock foreach Adam) is timed beside it."""
+    host's as much as the GPU's; the same loop with the optimizer hook off (stock foreach Adam) and with loss_function on
+    the general autograd route (`fused_loss = False`: round 4's loop, two autograd nodes) are timed beside it."""
     import torch
     from rawaudiovae_kelsey_amd import optim_hook
     from rawaudiovae_kelsey_amd.synth import make_params
@@ -192,12 +193,13 @@ def time_api_loop(dev, pool, steps):
     out = {"what": "the reference loop unchanged (zero_grad / model(x) / loss_function / backward / torch.optim.Adam.step) "
                    "through rawvae.model at C2; host-bound"}
     try:
-        def run(hook):
+        def run(hook, fused_loss=True):
             optim_hook.enabled = hook
             torch.manual_seed(0)
             m = VAE(S, H, L)
             m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(S, H, L, 0).items()})
             m = m.to(dev)
+            m.fused_loss = fused_loss
             opt = torch.optim.Adam(m.parameters(), lr=LR)
 
             def step(x):
@@ -223,9 +225,11 @@ def time_api_loop(dev, pool, steps):
         t_on, loss_on = run(True)
         took = optim_hook.stats["fused_steps"] - n0
         t_off, _ = run(False)
+        t_two, _ = run(True, fused_loss=False)
         out.update({"ms_per_step": t_on * 1e3, "value": float(B) / t_on, "unit": "frames/s", "final_loss": loss_on,
                     "optimizer_steps_taken_by_the_fused_kernel": took, "repeats": 5,
-                    "ms_per_step_stock_optimizer_step": t_off * 1e3})
+                    "ms_per_step_stock_optimizer_step": t_off * 1e3,
+                    "ms_per_step_loss_on_the_general_autograd_route": t_two * 1e3})
     except Exception as exc:   # the headline is already measured: report, do not lose it
         out["error"] = str(exc)[:200]
     finally:

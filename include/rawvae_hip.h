@@ -502,6 +502,16 @@ int rv_plan_set_option(rv_plan*, int option, int value);
  * phase.  Not honoured by the full-step schedules (phases == RV_PHASE_ALL_LOCAL). */
 int rv_plan_set_external_grads(rv_plan*, const float* d_recon, const float* recon, const float* dmu,
                                const float* dlogvar, float* grad_out);
+/* The plan's OWN loss across the autograd boundary (loss_function of rawvae/model.py:38-47 called on the untouched
+ * outputs of the fused forward: the drop-in loop of train.py:184-193).  rv_plan_loss: (total, mse, kld) of the forward
+ * phase that ran last into out3[3] (device), one small launch, the value -- and summation order -- the backward later
+ * writes to the loss ring.  rv_plan_set_loss_grad: the following BWD / FINALIZE phases use the forward's fused loss
+ * gradient (nothing from outside) and leave (*d_loss_dev) x gradient in grad_out (flat fp32 [n_params]; NULL = the
+ * bound grad arena); d_loss_dev is the upstream gradient of the scalar loss, a DEVICE pointer read at finalize time (the
+ * host never synchronises on it).  d_loss_dev = NULL and grad_out = NULL switch it off.  RV_ERR_STATE while gradients
+ * from outside are set. */
+int rv_plan_loss(rv_plan*, float kl_beta, float* out3, void* stream);
+int rv_plan_set_loss_grad(rv_plan*, const float* d_loss_dev, float* grad_out);
 /* The plan's ten parameter descriptors (PARAM order): gradient slabs of its own workspace (from_flat = 0) or the
  * bound flat gradient arena (1), and the operand shadows Adam must refresh.  For callers that drive
  * rv_adam_multi / rv_params_from_flat themselves. */

@@ -42,6 +42,7 @@ class CommDesc(C.Structure):
 OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE, OPT_DDP_WAIT_MS = 0, 1, 2, 3, 4, 5, 6
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
+TILE_256x256 = 7     # RV_TILE_256x256 (include/rawvae_hip.h)
 PHASE_FWD, PHASE_BWD_A, PHASE_BWD_B = 1, 2, 4
 PHASE_FINALIZE_A, PHASE_ADAM, PHASE_FINALIZE_B = 8, 16, 32
 PHASE_ADAM_A, PHASE_ADAM_B = 64, 128
@@ -113,6 +114,8 @@ _SIGS = {
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
+    "rv_plan_loss": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    "rv_plan_set_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                    c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -606,11 +606,13 @@ __global__ void __launch_bounds__(256)
 k_adam(const DescTable tab, float* __restrict__ param, float* __restrict__ m_arena,
        float* __restrict__ v_arena, float* __restrict__ grad_out, float lr, float grad_scale,
        const long long* __restrict__ step_counter, bf16_t* __restrict__ grad_out_bf16,
-       const bf16_t* __restrict__ grad_in_bf16, const int* __restrict__ poison) {
+       const bf16_t* __restrict__ grad_in_bf16, const int* __restrict__ poison,
+       const float* __restrict__ grad_scale_dev) {
   // `poison` (the data-parallel step: its count of cross-stream flag waits that ran out, plan.hip): a wait in front of
   // this launch gave up, so the gradient it guards is incomplete -- the update is NOT applied, on any tensor, from then
   // on (the count is never cleared on the device; the host raises when it reads it).  One scalar load per block.
   if (poison && *poison != 0) return;
+  if (grad_scale_dev) grad_scale *= *grad_scale_dev;   // a scale that lives on the device (an upstream gradient: plan.hip)
   adam_block<UPDATE>(tab, (long)blockIdx.x, (int)threadIdx.x, param, m_arena, v_arena, grad_out, lr, grad_scale,
                      step_counter, grad_out_bf16, grad_in_bf16);
 }

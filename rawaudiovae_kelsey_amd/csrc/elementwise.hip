@@ -913,6 +913,36 @@ int rv_reparam_bwd(const float* dz_slabs, int splits, long Bp, long Lp, long B, 
   return RV_OK;
 }
 
+// The loss scalar from the partial sums a forward phase left (mse_partial of the fc4 forward's epilogue, kl_partial of the
+// reparameterisation): what the extra block of k_reparam_bwd / k_latent_bwd computes during the backward, in the same
+// summation order, as a launch of its own -- for a caller that wants the value before (or without) a backward.
+__global__ void __launch_bounds__(256)
+k_loss_from_partials(const float* __restrict__ mse_partial, int n_mse, const float* __restrict__ kl_partial, int n_kl,
+                     long B, long S, long L, float kl_beta, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int tid = threadIdx.x;
+  float m = 0.f, k = 0.f;
+  for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+  for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+  m = block_sum_256(m, sh);
+  k = block_sum_256(k, sh);
+  if (tid == 0) {
+    const float mse = m / ((float)B * (float)S);
+    const float kld = -0.5f * k * (1.0f / ((float)B * (float)L));
+    out[0] = mse + kl_beta * kld;
+    out[1] = mse;
+    out[2] = kld;
+  }
+}
+int rv_loss_from_partials(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, long B, long S, long L,
+                          float kl_beta, float* out3, void* stream) {
+  RV_REQUIRE(mse_partial && kl_partial && out3 && n_mse > 0 && n_kl > 0, RV_ERR_NULL, "rv_loss_from_partials: null pointer");
+  hipLaunchKernelGGL(k_loss_from_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_partial, n_mse, kl_partial, n_kl,
+                     B, S, L, kl_beta, out3);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
 long rv_loss_fused_workspace_bytes(void) { return 256 + 2 * LOSS_MAX_BLOCKS * (long)sizeof(float); }
 
 int rv_loss_fused(const float* recon, const float* x, const float* mu, const float* logvar, long B,
@@ -1068,7 +1098,7 @@ int rv_adam_multi_guarded(const rv_param_desc* descs, int n_desc, float* param, 
   if (rc) return rc;
   hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, param, exp_avg, exp_avg_sq, grad_out, lr, grad_scale,
-                     step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16, poison);
+                     step_counter, (bf16_t*)nullptr, (const bf16_t*)grad_bf16, poison, (const float*)nullptr);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -1187,7 +1217,10 @@ int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg,
   return RV_OK;
 }
 
-int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, void* stream) {
+// rv_grad_finalize whose sums are multiplied by the device scalar *scale_dev (NULL: 1) -- the upstream gradient of a
+// loss whose backward the plan runs itself (rv_plan_set_loss_grad): the host never reads it.
+int rv_grad_finalize_scaled(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, const float* scale_dev,
+                            void* stream) {
   RV_REQUIRE(grad_out, RV_ERR_NULL, "rv_grad_finalize: null pointer");
   DescTable tab;
   int rc = adam_build_table(descs, n_desc, &tab);
@@ -1195,9 +1228,13 @@ int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int
   hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0,
                      (hipStream_t)stream, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                      out_bf16 ? (float*)nullptr : (float*)grad_out, 0.f, 1.f, (const long long*)nullptr,
-                     out_bf16 ? (bf16_t*)grad_out : (bf16_t*)nullptr, (const bf16_t*)nullptr, (const int*)nullptr);
+                     out_bf16 ? (bf16_t*)grad_out : (bf16_t*)nullptr, (const bf16_t*)nullptr, (const int*)nullptr, scale_dev);
   RV_CHECK_LAUNCH();
   return RV_OK;
+}
+
+int rv_grad_finalize(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16, void* stream) {
+  return rv_grad_finalize_scaled(descs, n_desc, grad_out, out_bf16, nullptr, stream);
 }
 
 }  // extern "C"

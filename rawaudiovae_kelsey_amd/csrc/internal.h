@@ -71,6 +71,12 @@ RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, long max
 RV_INTERNAL int rv_adam_multi_guarded(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
                                       float* grad_out, const void* grad_bf16, float lr, float grad_scale,
                                       const long long* step_counter, const int* poison, void* stream);
+// The loss scalar (total, mse, kld) from a forward's partial sums, and rv_grad_finalize times a device-side scalar
+// (elementwise.hip): the two pieces of rv_plan_loss / rv_plan_set_loss_grad (plan.hip).
+RV_INTERNAL int rv_loss_from_partials(const float* mse_partial, int n_mse, const float* kl_partial, int n_kl, long B, long S,
+                                      long L, float kl_beta, float* out3, void* stream);
+RV_INTERNAL int rv_grad_finalize_scaled(const rv_param_desc* descs, int n_desc, void* grad_out, int out_bf16,
+                                        const float* scale_dev, void* stream);
 // rv_linear_wgrad_adam's launch shape (256 x 256 weight-gradient GEMM + rider blocks on the idle CUs) whose riders sum
 // the gradient slabs of `descs` into a flat payload arena instead of updating them (gemm_launch.hip).
 RV_INTERNAL int rv_linear_wgrad_finalize(const void* dy_bf16, long lddy, const void* x_bf16, long ldx, long Mp, long Np, long Kp,

@@ -93,6 +93,7 @@ struct rv_plan {
   const float* ext_d_recon = nullptr; const float* ext_recon = nullptr;
   const float* ext_dmu = nullptr; const float* ext_dlv = nullptr;
   float* ext_grad_out = nullptr;
+  const float* loss_grad_dev = nullptr;   // rv_plan_set_loss_grad: the FINALIZE launches multiply by this device scalar
   int latent_fused = 1;          // RV_OPT_LATENT_FUSED: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
@@ -340,6 +341,27 @@ int rv_plan_set_external_grads(rv_plan* p, const float* d_recon, const float* re
   RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_external_grads: null plan");
   RV_REQUIRE(!d_recon || recon, RV_ERR_NULL, "rv_plan_set_external_grads: d_recon needs recon (tanh')");
   p->ext_d_recon = d_recon; p->ext_recon = recon; p->ext_dmu = dmu; p->ext_dlv = dlogvar; p->ext_grad_out = grad_out;
+  return RV_OK;
+}
+
+// The plan's own loss as an autograd node (the drop-in loop: loss_function on the untouched outputs of the fused forward).
+// rv_plan_loss: (total, mse, kld) of the forward phase that ran last, into out3 -- one small launch, the summation order of
+// the value the backward later writes to the loss ring.  rv_plan_set_loss_grad: the following backward + FINALIZE phases
+// run on the forward's own fused loss gradient (no gradients from outside) and leave d_loss * gradient in `grad_out`
+// (exact-shape fp32 [n_params]; NULL: the plan's grad arena), d_loss read from the device at finalize time.  Both NULL
+// switches it off again.
+int rv_plan_loss(rv_plan* p, float kl_beta, float* out3, void* stream) {
+  RV_REQUIRE(p && p->bound && out3, RV_ERR_STATE, "rv_plan_loss: plan not bound / null output");
+  return rv_loss_from_partials((const float*)p->ws("mse_part"), p->n_mse, (const float*)p->ws("kl_part"), p->n_kl, p->B, p->S,
+                               p->L, kl_beta, out3, stream);
+}
+
+int rv_plan_set_loss_grad(rv_plan* p, const float* d_loss_dev, float* grad_out) {
+  RV_REQUIRE(p, RV_ERR_NULL, "rv_plan_set_loss_grad: null plan");
+  RV_REQUIRE(!(d_loss_dev && (p->ext_d_recon || p->ext_dmu || p->ext_dlv)), RV_ERR_STATE,
+             "rv_plan_set_loss_grad: gradients from outside are set (rv_plan_set_external_grads)");
+  p->loss_grad_dev = d_loss_dev;
+  p->ext_grad_out = grad_out;
   return RV_OK;
 }
 
@@ -807,7 +829,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     if (!((fin >> i) & 1)) { ++i; continue; }
     int j = i;
     while (j < 10 && ((fin >> j) & 1)) ++j;
-    RV_TRY(rv_grad_finalize(p->d_slab + i, j - i, fin_out, 0, stream));
+    RV_TRY(rv_grad_finalize_scaled(p->d_slab + i, j - i, fin_out, 0, p->loss_grad_dev, stream));
     i = j;
   }
   for (int i = 0; i < 10;) {

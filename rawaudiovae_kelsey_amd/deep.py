@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (ACT_RELU, SLAB_F16, SLAB_F32, ParamDesc, dgrad_wgrad_pick, gemm_pick, gemm_tile, lib, pad_dims, ptr,
+from ._lib import (ACT_RELU, SLAB_F16, SLAB_F32, TILE_256x256, ParamDesc, dgrad_wgrad_pick, gemm_pick, gemm_tile, lib, pad_dims, ptr,
                    stream_ptr)
 
 
@@ -167,7 +167,45 @@ class DeepTrainEngine:
         n = len(self.names)   # rv_adam_multi takes at most 16 tensors per launch
         self._chunks = [(ParamDesc * min(16, n - lo))(*[self._descs[j] for j in range(lo, min(lo + 16, n))])
                         for lo in range(0, n, 16)]
+        self._plan_riders()
         self.host_steps = 0
+
+    def _plan_riders(self):
+        """The last GEMM of the backward -- the first layer's weight gradient dW = dY^T x -- as `rv_linear_wgrad_adam`
+        (TrainEngine's launch 7): where its 256 x 256 tiles x K splits leave CUs idle (64 tiles x 2 splits = 128 blocks
+        at the C4 shape), those CUs run the optimizer update of tensors whose gradients are complete by then, for as
+        many bytes as a rider block streams in the GEMM's time (~23 GB/s per CU).  The step's last launches then update
+        only the rest.  Same update arithmetic whoever runs it (adam.h): results do not depend on the partition."""
+        Bp, Sp, Hp = self.Bp, self.Sp, self.Hp
+        self.riders = None
+        sp = self.splits["enc.0.weight"]
+        n_gemm = (Hp // 256) * (Sp // 256) * sp if (Hp % 256 == 0 and Sp % 256 == 0) else 0
+        if not n_gemm or n_gemm > 192 or (Bp // 64) % sp or ((Bp // 64) // sp) % 2:
+            return
+        us_gemm = 10.3 + (Bp // 64 // sp) * 1.21             # profiles/r04_gemm_decomp.txt: the ping-pong wgrad's fit
+        budget = us_gemm * 23e3 * (256 - n_gemm)              # bytes the rider blocks stream meanwhile
+        picked, spent = [], 0.0
+        for j in range(len(self.names) - 1, -1, -1):          # from the output side: those gradients are complete first
+            k = self.names[j]
+            if k.startswith("enc.0.") or len(picked) == 16:
+                continue
+            numel = 1
+            for v in self.shapes[k]:
+                numel *= v
+            slab = self.slabs.get(k)
+            cost = 26.0 * numel + (slab.numel() * slab.element_size() if slab is not None else 0)
+            if spent + cost > 1.15 * budget and picked:
+                continue
+            picked.append(j)
+            spent += cost
+        if not picked:
+            return
+        picked.sort()
+        rest = [j for j in range(len(self.names)) if j not in picked]
+        self.riders = {"n_blocks": 256 - n_gemm, "names": [self.names[j] for j in picked],
+                       "table": (ParamDesc * len(picked))(*[self._descs[j] for j in picked]),
+                       "rest": [(ParamDesc * min(16, len(rest) - lo))(*[self._descs[j] for j in rest[lo:lo + 16]])
+                                for lo in range(0, len(rest), 16)]}
 
     # ---- parameters -----------------------------------------------------
     def view(self, arena, name):
@@ -313,12 +351,25 @@ class DeepTrainEngine:
                                      ptr(self.slabs[wname]), Hp, self.splits[wname], *self._slab_args(wname), st)
             dy, kd, wname = self.d_enc[i], Hp, "enc.%d.weight" % i
             wptr = W(wname)
-        L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"], -1,
-                           ptr(self.slabs["enc.0.weight"]), Sp, *self._slab_args("enc.0.weight"), st)
-        if adam:
-            for chunk in self._chunks:
+        rd = self.riders
+        if adam and rd is not None:
+            L_.rv_linear_wgrad_adam(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"],
+                                    ptr(self.slabs["enc.0.weight"]), Sp, *self._slab_args("enc.0.weight"), rd["table"],
+                                    len(rd["table"]), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.lr, 1.0,
+                                    ctr, rd["n_blocks"], st)
+            for chunk in rd["rest"]:
                 L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, None,
                                  self.lr, 1.0, ctr, st)
+        else:
+            # (gradients only, or extents the rider launch does not tile: the same 256 x 256 tiles where they apply, so
+            # that the slabs -- and the exponents of fp16 slabs, which follow the tile -- are the same either way)
+            L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"],
+                               TILE_256x256 if rd is not None else -1, ptr(self.slabs["enc.0.weight"]), Sp,
+                               *self._slab_args("enc.0.weight"), st)
+            if adam:
+                for chunk in self._chunks:
+                    L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None,
+                                     None, self.lr, 1.0, ctr, st)
         self.host_steps += 1
 
     def gradients(self):

@@ -101,22 +101,35 @@ def fusable(module, x2):
     return params
 
 
+class _FwdRecord:
+    """What `loss_function` needs to recognise the untouched outputs of one fused forward (FusedLossFn below)."""
+    __slots__ = ("eng", "tick", "eps", "x_ptr", "x_numel", "x_version", "params", "module", "loss_taken", "mu", "logvar")
+
+
 class VaeFn(torch.autograd.Function):
     """(recon, mu, logvar) = VAE.forward(x) -- rawvae/model.py:19-35 -- on a step plan."""
 
     @staticmethod
-    def forward(ctx, x, eps, eng, *params):
+    def forward(ctx, x, eps, eng, rec, *params):
         B = x.shape[0]
         recon = torch.empty((B, eng.S), dtype=torch.float32, device=x.device)
         eng.step(x, eps=eps, recon_out=recon, phases=PHASE_FWD)
         mu, logvar = eng.outputs()
-        ctx.eng, ctx.tick, ctx.eps = eng, eng.host_steps, eps
+        ctx.eng, ctx.tick, ctx.eps, ctx.rec = eng, eng.host_steps, eps, rec
+        rec.eng, rec.tick, rec.eps = eng, eng.host_steps, eps
+        rec.x_ptr, rec.x_numel, rec.x_version = x.data_ptr(), x.numel(), x._version
         ctx.save_for_backward(recon)
         return recon, mu, logvar
 
     @staticmethod
     def backward(ctx, d_recon, d_mu, d_lv):
         eng = ctx.eng
+        if ctx.rec.loss_taken:
+            raise _lib.RvError(
+                "rawvae fused forward: loss_function() took this forward's loss as ONE autograd node on the step plan "
+                "(its backward runs the plan's own fused loss gradient), and now further gradients arrive for recon / mu / "
+                "logvar from another term of the loss.  Set `model.fused_loss = False` to route loss_function through the "
+                "general autograd path (any combination of losses), or add the extra term to the parameters only.")
         if eng.host_steps != ctx.tick:
             raise _lib.RvError(
                 "rawvae fused forward: backward() reached a forward pass whose activations a later forward of the "
@@ -140,12 +153,79 @@ class VaeFn(torch.autograd.Function):
                             ptr(ctx.eps), None, 0.0, 0.0, 1.0, 0, eng.seed, stream_ptr())
         finally:
             L_.rv_plan_set_external_grads(eng._plan, None, None, None, None, None)
-        out = [None, None, None]
+        out = [None, None, None, None]
         need = ctx.needs_input_grad
         # (weights are 2-D views of their piece; a bias IS its piece: five view calls, not ten)
         for i, (piece, shape) in enumerate(zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)):
-            out.append((piece.view(shape) if len(shape) > 1 else piece) if need[3 + i] else None)
+            out.append((piece.view(shape) if len(shape) > 1 else piece) if need[4 + i] else None)
         return tuple(out)
+
+
+class FusedLossFn(torch.autograd.Function):
+    """`loss_function(recon, x, mu, logvar, kl_beta, S)` (rawvae/model.py:38-47) on the UNTOUCHED outputs of a fused
+    forward, as one autograd node over the model's parameters.
+
+    The forward phase of the step plan has already done the loss's work: the fc4 GEMM's epilogue left the squared-error
+    partial sums and dP4 = d(mse)/d(pre-tanh), the reparameterisation its KL partial sums.  So the value is one small
+    launch (`rv_plan_loss`), and the backward is the plan's own backward -- paired fc4 backward on that dP4, latent and
+    heads backward with the KL gradient folded in, fc1's weight gradient, one finalize launch -- exactly the kernels of
+    the fused engine's step, with the upstream gradient of the scalar applied on the device in the finalize launch
+    (`rv_plan_set_loss_grad`).  Against the general route (LossFn + VaeFn.backward over gradients from outside) this is
+    one autograd node instead of two and five kernel launches fewer (the stand-alone loss kernel over recon / x, the
+    scaling of its three gradients, tanh' and the bias column sums of dP4, a memset).  The graph edge from the loss to
+    (recon, mu, logvar) does not exist on this route; VaeFn.backward refuses to run beside it (another loss term on the
+    same outputs needs `model.fused_loss = False`)."""
+
+    @staticmethod
+    def forward(ctx, rec, kl_beta, *params):
+        eng = rec.eng
+        out = torch.empty(4, dtype=torch.float32, device=eng.device)
+        lib().rv_plan_loss(eng._plan, float(kl_beta), ptr(out), stream_ptr())
+        ctx.rec, ctx.kl = rec, float(kl_beta)
+        rec.loss_taken = True
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        rec = ctx.rec
+        eng = rec.eng
+        if eng.host_steps != rec.tick:
+            raise _lib.RvError(
+                "rawvae fused loss: backward() reached a forward pass whose activations a later forward of the same batch "
+                "size has overwritten. Call backward() before the next model(x), or set `model.fused_training = False`.")
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.contiguous().float()
+        grad = torch.empty(eng.n_params, dtype=torch.float32, device=eng.device)
+        L_ = lib()
+        L_.rv_plan_set_loss_grad(eng._plan, ptr(g), ptr(grad))
+        try:
+            L_.rv_plan_step(eng._plan, PHASE_BWD_A | PHASE_BWD_B | PHASE_FINALIZE_A | PHASE_FINALIZE_B, None,
+                            ptr(rec.eps), None, ctx.kl, 0.0, 1.0, 0, eng.seed, stream_ptr())
+        finally:
+            L_.rv_plan_set_loss_grad(eng._plan, None, None)
+        out = [None, None]
+        need = ctx.needs_input_grad
+        for i, (piece, shape) in enumerate(zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)):
+            out.append((piece.view(shape) if len(shape) > 1 else piece) if need[2 + i] else None)
+        return tuple(out)
+
+
+def fused_loss(recon_x, x, mu, logvar, kl_beta, segment_length):
+    """The loss as FusedLossFn when (recon_x, mu, logvar) are the untouched outputs of the most recent fused forward of
+    their model and `x` is the batch that forward read; None otherwise (the caller takes the general path)."""
+    rec = getattr(recon_x, "_rv_fwd", None)
+    if rec is None or rec.loss_taken or rec.mu() is not mu or rec.logvar() is not logvar or not torch.is_grad_enabled():
+        return None
+    if type(kl_beta) not in (float, int) or recon_x._version or mu._version or logvar._version:
+        return None
+    eng = rec.eng
+    if eng.host_steps != rec.tick or segment_length != eng.S or not torch.is_tensor(x):
+        return None
+    if x.data_ptr() != rec.x_ptr or x.numel() != rec.x_numel or x._version != rec.x_version or x.requires_grad:
+        return None
+    module = rec.module()
+    if module is None or not getattr(module, "fused_loss", True):
+        return None
+    return FusedLossFn.apply(rec, kl_beta, *rec.params)
 
 
 def forward(module, x2, eps=None, params=None):
@@ -162,4 +242,12 @@ def forward(module, x2, eps=None, params=None):
         eps = eps if (eps.dtype == torch.float32 and eps.is_contiguous()) else eps.contiguous().float()
     eng = holder.engine(module, x2.shape[0], params)
     eng.seed = module._rng_seed
-    return VaeFn.apply(x2, eps, eng, *params)
+    rec = _FwdRecord()
+    rec.params, rec.module, rec.loss_taken = params, weakref.ref(module), False
+    recon, mu, logvar = VaeFn.apply(x2, eps, eng, rec, *params)
+    # the three tensors the caller receives carry the record: loss_function recognises them by identity (fused_loss)
+    # (weak references: the autograd node behind mu / logvar holds the record, so strong ones would close a cycle that
+    # keeps the node's saved recon -- 16 MB at C2 -- alive until the garbage collector finds it)
+    rec.mu, rec.logvar = weakref.ref(mu), weakref.ref(logvar)
+    recon._rv_fwd = rec
+    return recon, mu, logvar

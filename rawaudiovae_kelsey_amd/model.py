@@ -129,4 +129,10 @@ class Decoder(nn.Module):
 def loss_function(recon_x, x, mu, logvar, kl_beta, segment_length):
     """mean squared reconstruction error + kl_beta * KL(q(z|x) || N(0,1)), both `mean`
     reductions, returned as a 0-dim tensor (model.py:38-47)."""
+    if getattr(recon_x, "_rv_fwd", None) is not None:
+        # the untouched outputs of the one-node training forward: the step plan already holds this loss and its gradient
+        # (fused.FusedLossFn: one autograd node over the parameters, the fused engine's own backward kernels)
+        out = fused.fused_loss(recon_x, x, mu, logvar, kl_beta, segment_length)
+        if out is not None:
+            return out
     return ops.LossFn.apply(recon_x, x.reshape(-1, segment_length), mu, logvar, kl_beta)

@@ -249,6 +249,82 @@ def test_fused_forward_node_takes_any_loss_and_upstream_scale():
     assert float(m.fc1.weight.grad.abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("S,H,L,B", [(64, 96, 8, 16), (512, 256, 24, 300), (1024, 2048, 64, 4096)])
+def test_loss_function_on_fused_outputs_is_one_node_on_the_plan(S, H, L, B):
+    """`loss_function` (model.py:38-47) called on the untouched outputs of the one-node forward -- the reference's loop,
+    train.py:186-191 -- becomes ONE autograd node over the parameters whose backward is the step plan's own (fused
+    engine kernels, the forward's fused MSE gradient; fused.FusedLossFn).  Against the general route (`fused_loss =
+    False`: LossFn + VaeFn.backward on gradients from outside): the same loss to fp32 rounding of another summation order,
+    the same ten gradients to the bf16 rounding of dP4 (computed from the fp32 accumulator on one route, from the fp32
+    reconstruction on the other); against the fused ENGINE, which runs exactly these kernels: the same loss bit for bit.
+    Upstream scale, fall-backs, and the guard against a second loss term on the same outputs."""
+    from rawaudiovae_kelsey_amd import _lib
+    from rawaudiovae_kelsey_amd.engine import TrainEngine
+    from rawvae.model import loss_function
+    x = torch.from_numpy(make_frames(B, S, 50)).cuda()
+    eps = torch.from_numpy(make_eps(B, L, 90)).cuda()
+    KLB = 1e-2
+
+    def run(fused_loss, scale=1.0):
+        m = _model(S, H, L)
+        m.fused_loss = fused_loss
+        recon, mu, logvar = m(x, eps=eps)
+        loss = loss_function(recon, x, mu, logvar, KLB, S)
+        (loss * scale if scale != 1.0 else loss).backward()
+        return m, loss, {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    ma, la, ga = run(True)
+    mb, lb, gb = run(False)
+    assert type(la.grad_fn).__name__ == "FusedLossFnBackward" and type(lb.grad_fn).__name__ == "LossFnBackward"
+    assert la.dim() == 0 and abs(la.item() - lb.item()) <= 5e-6 * abs(lb.item())
+    for k in PARAM_NAMES:
+        assert ga[k].shape == gb[k].shape == ma.state_dict()[k].shape
+        assert _rel_l2(ga[k].cpu().numpy(), gb[k].double().cpu().numpy()) < 2e-3, k
+    # the fused engine on the same weights, batch and eps: the same kernels, so the same loss bits and the same gradients
+    e = TrainEngine(S, H, L, B, kl_beta=KLB, lr=1e-3)
+    e.load_params(make_params(S, H, L, 0))
+    from rawaudiovae_kelsey_amd import engine as E
+    e.step(x, eps, phases=E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B)
+    assert e.last_loss()[0] == la.item()
+    for k in PARAM_NAMES:
+        assert torch.equal(e.grad_views()[k], ga[k]), k
+    # an upstream factor reaches the gradients on the device (no host read of it)
+    _, _, g3 = run(True, scale=2.5)
+    for k in PARAM_NAMES:
+        np.testing.assert_allclose(g3[k].cpu().numpy(), 2.5 * ga[k].cpu().numpy(), rtol=2e-6, atol=0)
+    # not the forward's batch, modified outputs, or a tensor kl_beta: the general route, same numbers
+    m = _model(S, H, L)
+    recon, mu, logvar = m(x, eps=eps)
+    l2 = loss_function(recon, x.clone(), mu, logvar, KLB, S)
+    assert type(l2.grad_fn).__name__ == "LossFnBackward" and abs(l2.item() - lb.item()) <= 5e-6 * abs(lb.item())
+    recon, mu, logvar = m(x, eps=eps)
+    l3 = loss_function(recon * 1.0, x, mu, logvar, KLB, S)
+    assert type(l3.grad_fn).__name__ == "LossFnBackward"
+    # a second loss term on the same outputs cannot be served beside the one-node loss: it says so, and names the switch
+    recon, mu, logvar = m(x, eps=eps)
+    l4 = loss_function(recon, x, mu, logvar, KLB, S) + 1e-3 * mu.pow(2).mean()
+    with pytest.raises(_lib.RvError, match="fused_loss"):
+        l4.backward()
+    m.zero_grad()
+    m.fused_loss = False
+    recon, mu, logvar = m(x, eps=eps)
+    (loss_function(recon, x, mu, logvar, KLB, S) + 1e-3 * mu.pow(2).mean()).backward()
+    assert float(m.fc1.weight.grad.abs().max()) > 0.0
+    # the record on the outputs does not keep the graph alive: nothing of a finished step is reachable from the model
+    import gc
+    import weakref
+    m.fused_loss = True
+    recon, mu, logvar = m(x, eps=eps)
+    wr = weakref.ref(recon)
+    loss = loss_function(recon, x, mu, logvar, KLB, S)
+    loss.backward()
+    del recon, mu, logvar, loss
+    gc.disable()
+    try:
+        assert wr() is None        # freed by reference counting alone (no cycle through the record)
+    finally:
+        gc.enable()
+
+
 def test_fused_forward_node_guards_and_fallbacks():
     from rawaudiovae_kelsey_amd import _lib, fused
     S, H, L, B = 64, 96, 8, 16

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-segment host time of the reference-style loop at C2 (perf_counter around each call of the loop and around the two
 Python backward functions, which run on autograd's worker thread and are invisible to a profiler of the main thread).
-    python tools/api_breakdown.py        -> profiles/r04_api_breakdown.txt"""
+    python tools/api_breakdown.py        -> profiles/r05_api_breakdown.txt"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,6 +23,8 @@ def wrap(cls, name):
         return r
     setattr(cls, name, staticmethod(w))
 wrap(fused.VaeFn, "backward"); wrap(ops.LossFn, "backward"); wrap(fused.VaeFn, "forward"); wrap(ops.LossFn, "forward")
+wrap(fused.FusedLossFn, "forward"); wrap(fused.FusedLossFn, "backward")
+m.fused_loss = os.environ.get("RV_FUSED_LOSS", "1") != "0"     # 0: loss_function through the general autograd route
 def step(x, T):
     t0 = pc(); opt.zero_grad(); t1 = pc()
     recon, mu, logvar = m(x); t2 = pc()

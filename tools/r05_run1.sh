@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-git rev-parse --short HEAD > .evidence_commit 2>/dev/null || true
+
 python -m pytest tests -m gpu -q -x > $O/r05_gpu_tests_1.txt 2>&1; tail -5 $O/r05_gpu_tests_1.txt
 RV_WORKER_HARD_EXIT=0 python -m pytest tests/test_ddp_gpu.py -q -k two_processes > $O/r05_worker_soft_exit.txt 2>&1; tail -3 $O/r05_worker_soft_exit.txt
 python bench.py > $O/r05_bench_1.json 2> $O/r05_bench_1.err; tail -c 600 $O/r05_bench_1.json; echo
