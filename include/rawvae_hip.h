@@ -193,6 +193,20 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                   float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream);
 
+/* rv_latent_fwd on PAIRS of workgroups: workgroups 2i and 2i + 1 share 32 batch rows and split the WEIGHTS -- each
+ * contracts one K half of the heads GEMM and computes one half of fc3's output columns -- exchanging their 32 x 128 fp32
+ * partial head sums through `xchg` inside the launch (write-through stores, a per-workgroup generation counter in `gen`,
+ * sc1 loads; bounded wait, time-outs counted in *err, which must stay 0).  Half the weight bytes pass through every CU's
+ * L2 -> LDS port, which is what bounds rv_latent_fwd (13-14 of its 18 us at C2).  Same outputs as rv_latent_fwd_ex up to
+ * the fp32 summation order of the head sums (h3_fp8 / q_scale / amax_part: the fp8 forward's extras, NULL = not wanted).
+ * xchg: (Bp / 16) x 4096 floats, gen: Bp / 16 ints, err: one int -- the caller's, zeroed once, not shared between
+ * launches that may overlap.  RV_ERR_UNSUPPORTED unless Lp == 64, Hp is 1024 or 2048 and Bp a multiple of 32. */
+int rv_latent_fwd_pair(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
+                       const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
+                       const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
+                       float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
+                       const float* q_scale, float* amax_part, float* xchg, int* gen, int* err, void* stream);
+
 /* The backward mirror of rv_latent_fwd's first two steps in ONE launch (same shape limits): dz = dP3 W3 (autograd of
  * fc3's input, model.py:29) for 16 batch rows per workgroup over the full contraction, then rv_reparam_bwd's
  * arithmetic on that block's dz while it is still in LDS -- no dz slabs, no second launch.  Arguments as
@@ -482,6 +496,10 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     rv_plan_step_ddp read the count and apply no update while it is non-zero, so a partial all-reduce never reaches
  *     the parameters; the host side must read the count (it is never cleared on the device), agree on it across ranks
  *     and stop every rank.
+ *   RV_OPT_LATENT_PAIR  1 (default): where RV_OPT_LATENT_FUSED applies and the extents allow (hidden width 1024 or 2048, a
+ *     padded batch that is a multiple of 32) the fused latent forward runs on pairs of workgroups that split the weights
+ *     (rv_latent_fwd_pair; its exchange buffers are the workspace buffers "lat_xchg" / "lat_gen", whose last int counts
+ *     hand-off time-outs and must stay 0); 0: rv_latent_fwd, 16 rows per workgroup and all weights through every CU.
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider
@@ -492,7 +510,7 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
  *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
 enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5,
-       RV_OPT_DDP_WAIT_MS = 6 };
+       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and

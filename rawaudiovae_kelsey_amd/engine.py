@@ -107,6 +107,8 @@ class TrainEngine:
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
         L_.rv_plan_set_option(self._plan, _lib.OPT_SLAB_DTYPE, _lib.SLAB_F16 if slab_dtype == "fp16" else _lib.SLAB_F32)
+        if os.environ.get("RV_LATENT_PAIR", "1") == "0":
+            L_.rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, 0)
         self._note_init()     # the zero fills above ran on the current stream
 
     # ---- stream hygiene ---------------------------------------------------
@@ -186,6 +188,11 @@ class TrainEngine:
         fused kernel (padded latent width 64, hidden width a multiple of 512 up to 2048, bf16); False: always three
         launches (`rv_plan_set_option`, RV_OPT_LATENT_FUSED)."""
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_FUSED, int(bool(enable)))
+
+    def set_latent_pair(self, enable):
+        """True (default): the fused latent forward on pairs of workgroups that split the weights (`rv_latent_fwd_pair`)
+        where the extents allow; False: `rv_latent_fwd`, every workgroup streams all weights (RV_OPT_LATENT_PAIR)."""
+        lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, int(bool(enable)))
 
     def set_roctx(self, enable):
         """roctx ranges (rocprofv3 --marker-trace) around the phases of every step this engine enqueues
@@ -473,7 +480,20 @@ class TrainEngine:
         """Number of steps started on the device (reads the device counter; synchronises)."""
         n = int(self.step_counter.item())
         self.check_ddp_signals()
+        self.check_latent_pair()
         return n
+
+    def check_latent_pair(self):
+        """The paired latent forward's in-launch hand-off is bounded (100 ms); a wait that ran out left that step's mu /
+        logvar / h3 incomplete.  Raises if any did (include/rawvae_hip.h, RV_OPT_LATENT_PAIR)."""
+        cnt = getattr(self, "_lat_err", None)
+        if cnt is None:
+            gen = self.buffer("lat_gen", torch.int32, (-1,))
+            cnt = self._lat_err = gen[self.padded()[0] // 16:][:1]
+        n = int(cnt.item())
+        if n:
+            raise _lib.RvError("latent forward: %d partner hand-off(s) between paired workgroups timed out -- the results of "
+                               "those steps are invalid (RV_LATENT_PAIR=0 selects the unpaired kernel)" % n)
 
     def check_ddp_signals(self):
         """The data-parallel step's device-side flag waits are bounded (5 s behind local kernels, RV_DDP_WAIT_MS --

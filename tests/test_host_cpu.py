@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     names = _header_symbols()
     diag = _header_symbols("rawvae_hip_diag.h")      # the test hook: exported, not part of the product ABI
-    assert 30 <= len(names) <= 60 and diag == ["rv_gemm_force_tile", "rv_plan_diag_skip"]
+    assert 30 <= len(names) <= 70 and diag == ["rv_gemm_force_tile", "rv_plan_diag_skip"]
     raw = ctypes.CDLL(_lib.LIB_PATH)
     # ... and nothing else: launchers only the step plan calls (csrc/internal.h) are hidden, not a second ABI
     import subprocess

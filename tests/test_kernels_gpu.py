@@ -381,6 +381,87 @@ def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
                         h31.data_ptr(), Hp, sp())
 
 
+@pytest.mark.parametrize("B,Lt,H", [(4096, 64, 2048), (100, 3, 1024), (300, 40, 2000), (4000, 64, 900)])
+def test_latent_fwd_on_workgroup_pairs_equals_the_unpaired_kernel(L, B, Lt, H):
+    """rv_latent_fwd_pair (workgroups 2i / 2i + 1 share 32 rows, split the weights and exchange their partial head sums
+    inside the launch) against rv_latent_fwd on the same bf16 operands and eps, and against float64 numpy: mu / logvar to
+    the fp32 summation order of the head sums (1e-5 of the term scale), z equal except where that crosses a bf16 rounding
+    boundary, KL partials per 16-row block, h3 equal on rows whose z is equal (fc3 is the same 64-term sum in the same
+    order), the same Philox draws; launched four times in a row on one set of exchange buffers (the generation counters
+    advance, nothing is reset), no hand-off time-out."""
+    rng = np.random.default_rng(9)
+    Bp, Lp, Hp = -(-B // 128) * 128, 64, -(-H // 1024) * 1024
+    h = np.zeros((Bp, Hp), np.float32); h[:B, :H] = np.maximum(rand_bf16(rng, (B, H), 0.5), 0)
+    wh = np.zeros((2 * Lp, Hp), np.float32)
+    wh[:Lt, :H] = rand_bf16(rng, (Lt, H), 0.05); wh[Lp:Lp + Lt, :H] = rand_bf16(rng, (Lt, H), 0.05)
+    bh = np.zeros(2 * Lp, np.float32)
+    bh[:Lt] = rng.standard_normal(Lt) * 0.1; bh[Lp:Lp + Lt] = rng.standard_normal(Lt) * 0.1
+    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.2)
+    b3 = np.zeros(Hp, np.float32); b3[:H] = rng.standard_normal(H) * 0.1
+    eps = rng.standard_normal((B, Lt)).astype(np.float32)
+    hd, whd, w3d = dev(h, torch.bfloat16), dev(wh, torch.bfloat16), dev(w3, torch.bfloat16)
+    bhd, b3d, ed = dev(bh), dev(b3), dev(eps)
+    ctr = torch.ones(1, dtype=torch.int64, device="cuda")
+    xchg = torch.zeros(Bp // 16 * 4096, device="cuda")
+    gen = torch.zeros(Bp // 16 + 1, dtype=torch.int32, device="cuda")
+
+    def outs():
+        return (torch.empty(Bp, 2 * Lp, device="cuda"), torch.empty(Bp, Lp, device="cuda", dtype=torch.bfloat16),
+                torch.zeros(Bp * Lp // 1024, device="cuda"), torch.empty(Bp, Hp, device="cuda", dtype=torch.bfloat16))
+
+    def pair(e_in, e_out, seed, o):
+        L.rv_latent_fwd_pair(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
+                             B, Lt, e_in, e_out, seed, ctr.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                             o[3].data_ptr(), Hp, None, 0, None, None, xchg.data_ptr(), gen.data_ptr(),
+                             gen.data_ptr() + 4 * (Bp // 16), sp())
+    o1 = outs()
+    pair(ed.data_ptr(), None, 0, o1)
+    o2 = outs()
+    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
+                    B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
+                    o2[3].data_ptr(), Hp, sp())
+    torch.cuda.synchronize()
+    assert int(gen[-1]) == 0 and bool((gen[:-1] == 1).all())
+    ref = h[:B].astype(np.float64) @ wh.astype(np.float64).T + bh
+    mu, lv = ref[:, :Lt], ref[:, Lp:Lp + Lt]
+    got = o1[0].cpu().numpy()
+    np.testing.assert_allclose(got[:B, :Lt], mu, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got[:B, Lp:Lp + Lt], lv, rtol=1e-5, atol=2e-5)
+    assert not got[B:].any() and not got[:, Lt:Lp].any() and not got[:, Lp + Lt:].any()
+    np.testing.assert_allclose(got, o2[0].cpu().numpy(), rtol=1e-5, atol=2e-5)
+    za, zb = o1[1].float().cpu().numpy(), o2[1].float().cpu().numpy()
+    assert np.mean(za != zb) < 2e-3 and not za[B:].any() and not za[:, Lt:].any()
+    np.testing.assert_allclose(za, zb, rtol=1e-2, atol=1e-6)
+    kl_ref = float(np.sum(1 + lv - mu ** 2 - np.exp(lv)))
+    assert abs(float(o1[2].double().sum()) - kl_ref) <= 1e-5 * abs(kl_ref) + 1e-4
+    np.testing.assert_allclose(o1[2].cpu().numpy(), o2[2].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    h3ref = np.maximum(za[:B].astype(np.float64) @ w3.astype(np.float64).T + b3, 0)
+    np.testing.assert_allclose(o1[3].float().cpu().numpy()[:B], h3ref, rtol=1e-2, atol=1e-3)
+    rows_same = (za == zb).all(axis=1)
+    assert rows_same.mean() > 0.8
+    assert torch.equal(o1[3][torch.from_numpy(rows_same).cuda()], o2[3][torch.from_numpy(rows_same).cuda()])
+    # repeated launches on the same exchange buffers: bit-identical outputs every time, the counters advance
+    for k in range(3):
+        o3 = outs()
+        pair(ed.data_ptr(), None, 0, o3)
+        for a, b in zip(o1, o3):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    assert int(gen[-1]) == 0 and bool((gen[:-1] == 4).all())
+    # generated eps: the same Philox draws as the unpaired kernel
+    e1, e3 = torch.empty(B, Lt, device="cuda"), torch.empty(B, Lt, device="cuda")
+    pair(None, e1.data_ptr(), 77, outs())
+    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
+                    B, Lt, None, e3.data_ptr(), 77, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
+                    o2[3].data_ptr(), Hp, sp())
+    assert torch.equal(e1, e3)
+    from rawaudiovae_kelsey_amd import _lib
+    with pytest.raises(_lib.RvError):      # a hidden width the pairing does not cover
+        L.rv_latent_fwd_pair(hd.data_ptr(), 512, whd.data_ptr(), 512, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, 512, Lp,
+                             B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
+                             o2[3].data_ptr(), 512, None, 0, None, None, xchg.data_ptr(), gen.data_ptr(), gen.data_ptr(), sp())
+
+
 @pytest.mark.parametrize("B,Lt,H,ext", [(100, 3, 512, False), (4096, 64, 2048, False), (300, 40, 900, True), (200, 64, 1536, True)])
 def test_latent_bwd_one_launch_equals_two(L, B, Lt, H, ext):
     """rv_latent_bwd (dz = dP3 W3 over the full contraction + the reparameterisation / KL backward + the loss scalar

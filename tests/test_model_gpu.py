@@ -490,7 +490,7 @@ def test_stock_adam_step_runs_as_one_fused_launch_and_keeps_torch_state():
         for g in od.param_groups:
             g["lr"] = 5e-4
         ld2, _ = loop(md, 3, False, od, first=5)
-        np.testing.assert_allclose(la2, ld2, rtol=5e-6)
+        np.testing.assert_allclose(la2, ld2, rtol=2e-5)      # (two runs 1e-7 apart per update, as above: 2e-5 on the losses)
         # a group with only some of the parameters: PyTorch's own step (state tensors are NOT arena views)
         me = _model(S, H, L)
         optim_hook.enabled = True
