@@ -142,6 +142,16 @@ int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16
                               long lddx, int dgrad_splits, float* dw_slabs, long lddw, int wgrad_splits,
                               void* stream);
 
+/* Store policy of the GEMM / fused kernels' epilogues for the launches this HOST THREAD enqueues from now on; returns the
+ * previous policy.  0 (default for direct callers): plain stores -- outputs stay in the writing XCD's L2, which a chain of
+ * same-shaped layers reads back from there.  Bit 0: every epilogue output is written through to memory as it is
+ * produced (16-byte sc0 sc1 stores): nothing is left dirty for the end-of-kernel release to flush with the chip idle --
+ * what the step plan sets around its own launches (its outputs are 8-34 MB per kernel and the next kernel runs on all
+ * XCDs).  Bit 1: only the split-K slabs of weight gradients (rv_linear_wgrad, the wgrad half of rv_linear_dgrad_wgrad,
+ * rv_linear_wgrad_adam) are written through -- nothing reads them before the optimizer -- while activations and
+ * activation gradients keep plain stores (the deep variant's sequencer, deep.py). */
+int rv_set_store_policy(int policy);
+
 /* dW = dY^T X as `splits` partial slabs [Mp(out), Np(in)] (split over the batch) of element type slab_dtype.
  * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS
  * reads.  Autograd of F.linear w.r.t. weight, train.py:191.  `tile`: RV_TILE_AUTO (the picker's choice) or a named
@@ -496,10 +506,12 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     rv_plan_step_ddp read the count and apply no update while it is non-zero, so a partial all-reduce never reaches
  *     the parameters; the host side must read the count (it is never cleared on the device), agree on it across ranks
  *     and stop every rank.
- *   RV_OPT_LATENT_PAIR  1 (default): where RV_OPT_LATENT_FUSED applies and the extents allow (hidden width 1024 or 2048, a
- *     padded batch that is a multiple of 32) the fused latent forward runs on pairs of workgroups that split the weights
+ *   RV_OPT_LATENT_PAIR  1: where RV_OPT_LATENT_FUSED applies and the extents allow (hidden width 1024 or 2048, a padded
+ *     batch that is a multiple of 32) the fused latent forward runs on pairs of workgroups that split the weights
  *     (rv_latent_fwd_pair; its exchange buffers are the workspace buffers "lat_xchg" / "lat_gen", whose last int counts
- *     hand-off time-outs and must stay 0); 0: rv_latent_fwd, 16 rows per workgroup and all weights through every CU.
+ *     hand-off time-outs and must stay 0); 0 (default): rv_latent_fwd, 16 rows per workgroup and all weights through
+ *     every CU.  Opt-in because it measured SLOWER in the step at C2 (19.7-21.0 against 18.0-18.8 us, three interleaved
+ *     pairs on one box): the in-launch hand-off costs what the halved weight stream saves.
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider

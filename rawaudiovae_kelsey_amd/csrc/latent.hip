@@ -448,7 +448,8 @@ k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* _
     asm volatile("" ::: "memory");
   }
 
-  // ---- exchange with the partner (see the header comment)
+  // ---- exchange with the partner (see the header comment); fc3's second weight slot flies meanwhile (slot 1 is free)
+  if (NU > 1) issue_fc3(1);
   float* mine = xchg + (long)b * (LP_ROWS * 128);
   const float* theirs = xchg + (long)partner * (LP_ROWS * 128);
   store_wt16((f32x4*)(mine + (long)tid * 4), f32x4{pmu[0], pmu[1], pmu[2], pmu[3]});
@@ -529,7 +530,6 @@ k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* _
   }
 
   // ---- fc3: h3[r0 + row][n] = relu(sum_k W3[n][k] z[row][k] + b3[n]) for this wave's columns, 64 per slot, 32 rows
-  if (NU > 1) issue_fc3(1);
   bf16x8 z0[2], z1[2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
@@ -543,9 +543,7 @@ k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* _
   float amax = 0.f;
   for (int u = 0; u < NU; ++u) {
     const lds_char* sl = (u & 1) ? W1 : W0;
-    // slot 0 and the bias landed before the exchange's vmcnt(0); slot 1's pieces have landed once only the stores of
-    // iteration 0 (4, with the fp8 outputs 8) are younger
-    if (u == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // both slots and the bias landed before the exchange's vmcnt(0)
     bf16x8 w[4][2];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
@@ -1095,7 +1093,7 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
   hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt & 1, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -1131,7 +1129,7 @@ int rv_latent_fwd_pair(const void* h_bf16, long ldh, const void* wh_bf16, long l
   hipLaunchKernelGGL(k_latent_fwd_pair, dim3((unsigned)(Bp / 16)), dim3(512), LP_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part, xchg, gen, err);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt & 1, (unsigned char*)h3_fp8, ldq, q_scale, amax_part, xchg, gen, err);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -1159,7 +1157,7 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.k_tiles = (int)(Bp / 64 / dw3_splits); g.M_valid = (int)Hp; g.N_valid = (int)Lp;
     g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
     g.tiles_m = (int)(Hp / 64); g.tiles_n = 1; g.splits = dw3_splits;
-    g.wt = rv_store_wt;
+    g.wt = rv_store_wt & 1;
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
   static bool attr_done = false;
@@ -1213,7 +1211,7 @@ int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
-                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
+                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt & 1, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

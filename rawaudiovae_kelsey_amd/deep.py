@@ -65,6 +65,8 @@ class DeepTrainEngine:
         if slab_dtype not in ("fp16", "fp32"):
             raise _lib.RvError("slab_dtype %r (expected 'fp16' or 'fp32')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
+        import os
+        self.slab_wt = os.environ.get("RV_DEEP_SLAB_WT", "1") != "0"     # write-through stores for the split-K slabs
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.RvError("DeepTrainEngine needs a GPU device; there is no CPU path")
@@ -153,7 +155,18 @@ class DeepTrainEngine:
             slab("dec.%d.weight" % i, self.plan_hh[2], Hp, Hp, True)
             slab("enc.%d.weight" % i, self.plan_hh[2], Hp, Hp, True)
         slab("dec.0.weight", gemm_pick(Hp, Lp, Bp)[2], Hp, Lp)
-        slab("enc.0.weight", gemm_pick(Hp, Sp, Bp)[2], Hp, Sp, True)
+        # The first layer's weight gradient dW = dY^T x is the last GEMM of the backward and has no dgrad to share a launch
+        # with: on 256 x 256 tiles with the ping-pong loop (the wgrad half of the paired launches, alone) and as many K
+        # splits as fill the chip -- 64 tiles x 4 at the C4 shape, 31 us -- where the extents tile; the picker's
+        # 256 x 128 tiles with two transposed operands took 55 us there (profiles/r05_deep_kernel_stats.txt).
+        sp0, self.tile_enc0 = gemm_pick(Hp, Sp, Bp)[2], -1
+        if Hp % 256 == 0 and Sp % 256 == 0:
+            tiles, kt = (Hp // 256) * (Sp // 256), Bp // 64
+            while tiles * sp0 < 256 and kt % (2 * sp0) == 0 and kt // (2 * sp0) >= 2 and sp0 < 8:
+                sp0 *= 2
+            if kt % sp0 == 0:
+                self.tile_enc0 = TILE_256x256
+        slab("enc.0.weight", sp0, Hp, Sp, True)
         slab("heads.weight", self.plan_heads[2], 2 * Lp, Hp)
         # bias-gradient partial rows: produced by the kernel that creates the layer's dY
         self.bias_part["fc4.bias"] = z_(Bp // bm_o, Sp, **f32)
@@ -167,45 +180,7 @@ class DeepTrainEngine:
         n = len(self.names)   # rv_adam_multi takes at most 16 tensors per launch
         self._chunks = [(ParamDesc * min(16, n - lo))(*[self._descs[j] for j in range(lo, min(lo + 16, n))])
                         for lo in range(0, n, 16)]
-        self._plan_riders()
         self.host_steps = 0
-
-    def _plan_riders(self):
-        """The last GEMM of the backward -- the first layer's weight gradient dW = dY^T x -- as `rv_linear_wgrad_adam`
-        (TrainEngine's launch 7): where its 256 x 256 tiles x K splits leave CUs idle (64 tiles x 2 splits = 128 blocks
-        at the C4 shape), those CUs run the optimizer update of tensors whose gradients are complete by then, for as
-        many bytes as a rider block streams in the GEMM's time (~23 GB/s per CU).  The step's last launches then update
-        only the rest.  Same update arithmetic whoever runs it (adam.h): results do not depend on the partition."""
-        Bp, Sp, Hp = self.Bp, self.Sp, self.Hp
-        self.riders = None
-        sp = self.splits["enc.0.weight"]
-        n_gemm = (Hp // 256) * (Sp // 256) * sp if (Hp % 256 == 0 and Sp % 256 == 0) else 0
-        if not n_gemm or n_gemm > 192 or (Bp // 64) % sp or ((Bp // 64) // sp) % 2:
-            return
-        us_gemm = 10.3 + (Bp // 64 // sp) * 1.21             # profiles/r04_gemm_decomp.txt: the ping-pong wgrad's fit
-        budget = us_gemm * 23e3 * (256 - n_gemm)              # bytes the rider blocks stream meanwhile
-        picked, spent = [], 0.0
-        for j in range(len(self.names) - 1, -1, -1):          # from the output side: those gradients are complete first
-            k = self.names[j]
-            if k.startswith("enc.0.") or len(picked) == 16:
-                continue
-            numel = 1
-            for v in self.shapes[k]:
-                numel *= v
-            slab = self.slabs.get(k)
-            cost = 26.0 * numel + (slab.numel() * slab.element_size() if slab is not None else 0)
-            if spent + cost > 1.15 * budget and picked:
-                continue
-            picked.append(j)
-            spent += cost
-        if not picked:
-            return
-        picked.sort()
-        rest = [j for j in range(len(self.names)) if j not in picked]
-        self.riders = {"n_blocks": 256 - n_gemm, "names": [self.names[j] for j in picked],
-                       "table": (ParamDesc * len(picked))(*[self._descs[j] for j in picked]),
-                       "rest": [(ParamDesc * min(16, len(rest) - lo))(*[self._descs[j] for j in rest[lo:lo + 16]])
-                                for lo in range(0, len(rest), 16)]}
 
     # ---- parameters -----------------------------------------------------
     def view(self, arena, name):
@@ -305,6 +280,17 @@ class DeepTrainEngine:
         if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != self.B * self.S:
             raise _lib.RvError("step: x must be contiguous fp32 [B, S]")
         L_, st = lib(), stream_ptr(stream)
+        # weight-gradient slabs are written through (nothing reads them before the optimizer: left dirty they are flushed
+        # at every kernel boundary with the chip idle), activations keep plain stores -- the next layer's launch finds
+        # its input rows in the L2 that wrote them (write-through everywhere cost this engine 858 -> 951 us in round 3)
+        prev_policy = L_.rv_set_store_policy(2 if self.slab_wt else 0)
+        try:
+            self._enqueue(L_, st, x, eps, recon_out, adam)
+        finally:
+            L_.rv_set_store_policy(prev_policy)
+        self.host_steps += 1
+
+    def _enqueue(self, L_, st, x, eps, recon_out, adam):
         B, S, L, Bp, Sp, Hp, Lp, d = self.B, self.S, self.L, self.Bp, self.Sp, self.Hp, self.Lp, self.depth
         W = lambda k: ptr(self.shadow[k])  # noqa: E731
         ctr = ptr(self.step_counter)
@@ -351,26 +337,12 @@ class DeepTrainEngine:
                                      ptr(self.slabs[wname]), Hp, self.splits[wname], *self._slab_args(wname), st)
             dy, kd, wname = self.d_enc[i], Hp, "enc.%d.weight" % i
             wptr = W(wname)
-        rd = self.riders
-        if adam and rd is not None:
-            L_.rv_linear_wgrad_adam(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"],
-                                    ptr(self.slabs["enc.0.weight"]), Sp, *self._slab_args("enc.0.weight"), rd["table"],
-                                    len(rd["table"]), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.lr, 1.0,
-                                    ctr, rd["n_blocks"], st)
-            for chunk in rd["rest"]:
+        L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"], self.tile_enc0,
+                           ptr(self.slabs["enc.0.weight"]), Sp, *self._slab_args("enc.0.weight"), st)
+        if adam:
+            for chunk in self._chunks:
                 L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None, None,
                                  self.lr, 1.0, ctr, st)
-        else:
-            # (gradients only, or extents the rider launch does not tile: the same 256 x 256 tiles where they apply, so
-            # that the slabs -- and the exponents of fp16 slabs, which follow the tile -- are the same either way)
-            L_.rv_linear_wgrad(ptr(dy), Hp, ptr(self.xb), Sp, Hp, Sp, Bp, self.splits["enc.0.weight"],
-                               TILE_256x256 if rd is not None else -1, ptr(self.slabs["enc.0.weight"]), Sp,
-                               *self._slab_args("enc.0.weight"), st)
-            if adam:
-                for chunk in self._chunks:
-                    L_.rv_adam_multi(chunk, len(chunk), ptr(self.param), ptr(self.exp_avg), ptr(self.exp_avg_sq), None,
-                                     None, self.lr, 1.0, ctr, st)
-        self.host_steps += 1
 
     def gradients(self):
         """Exact-shape fp32 gradients of the last backward (sums the slabs); for tests."""

@@ -107,8 +107,9 @@ class TrainEngine:
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
         L_.rv_plan_set_option(self._plan, _lib.OPT_SLAB_DTYPE, _lib.SLAB_F16 if slab_dtype == "fp16" else _lib.SLAB_F32)
-        if os.environ.get("RV_LATENT_PAIR", "1") == "0":
-            L_.rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, 0)
+        self._latent_pair = False
+        if os.environ.get("RV_LATENT_PAIR", "0") == "1":
+            self.set_latent_pair(True)
         self._note_init()     # the zero fills above ran on the current stream
 
     # ---- stream hygiene ---------------------------------------------------
@@ -190,9 +191,13 @@ class TrainEngine:
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_FUSED, int(bool(enable)))
 
     def set_latent_pair(self, enable):
-        """True (default): the fused latent forward on pairs of workgroups that split the weights (`rv_latent_fwd_pair`)
-        where the extents allow; False: `rv_latent_fwd`, every workgroup streams all weights (RV_OPT_LATENT_PAIR)."""
+        """True: the fused latent forward on pairs of workgroups that split the weights (`rv_latent_fwd_pair`) where the
+        extents allow; False (default): `rv_latent_fwd`, every workgroup streams all weights (RV_OPT_LATENT_PAIR; the paired
+        form measured slower in the step at C2 -- DESIGN.md section 6 -- and stays an option)."""
+        if enable:
+            self.buffer("lat_gen", torch.int32, (-1,)).zero_()     # generation counters and the time-out count start at 0
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, int(bool(enable)))
+        self._latent_pair = bool(enable)
 
     def set_roctx(self, enable):
         """roctx ranges (rocprofv3 --marker-trace) around the phases of every step this engine enqueues
@@ -486,6 +491,8 @@ class TrainEngine:
     def check_latent_pair(self):
         """The paired latent forward's in-launch hand-off is bounded (100 ms); a wait that ran out left that step's mu /
         logvar / h3 incomplete.  Raises if any did (include/rawvae_hip.h, RV_OPT_LATENT_PAIR)."""
+        if not getattr(self, "_latent_pair", False):
+            return
         cnt = getattr(self, "_lat_err", None)
         if cnt is None:
             gen = self.buffer("lat_gen", torch.int32, (-1,))
