@@ -697,7 +697,9 @@ def main():
                     tj = json.load(f)
                 per = tj.get("per_launch_bytes", {})
                 traffic = per.get(str(top["launch"]), tj.get("traffic_bytes") if top["launch"] == 4 else None)
-                traffic_src = "profiles/%s (PMC passes of an earlier builder run, not this run)" % os.path.basename(cand[-1])
+                traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command on the " \
+                              "builder's box, commit %s: counters serialise dispatches, so never the timed run itself)" % (
+                                  os.path.basename(cand[-1]), tj.get("commit", "not recorded"))
             except Exception:
                 pass
             mfma_bound = top.get("mfma_frac", 0.0) >= top["hbm_frac"]

@@ -37,7 +37,12 @@ for k, v in rows.items():
         if pat in k:
             per_launch[str(idx)] = v["traffic_bytes"]
 dom = [k for k in rows if "gemm_dgrad_wgrad_kernel" in k]
-out = {"method": __doc__.strip(), "per_kernel": rows, "per_launch_bytes": per_launch,
+import os
+try:
+    commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".evidence_commit")).read().strip()
+except OSError:
+    commit = "not recorded"
+out = {"method": __doc__.strip(), "commit": commit, "per_kernel": rows, "per_launch_bytes": per_launch,
        "step_total_bytes_one_launch_each": sum(v["traffic_bytes"] for v in rows.values())}
 if dom:
     d = rows[dom[0]]
