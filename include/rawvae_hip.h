@@ -142,16 +142,6 @@ int rv_linear_dgrad_wgrad_f32(const void* dy_bf16, long lddy, const void* w_bf16
                               long lddx, int dgrad_splits, float* dw_slabs, long lddw, int wgrad_splits,
                               void* stream);
 
-/* Store policy of the GEMM / fused kernels' epilogues for the launches this HOST THREAD enqueues from now on; returns the
- * previous policy.  0 (default for direct callers): plain stores -- outputs stay in the writing XCD's L2, which a chain of
- * same-shaped layers reads back from there.  Bit 0: every epilogue output is written through to memory as it is
- * produced (16-byte sc0 sc1 stores): nothing is left dirty for the end-of-kernel release to flush with the chip idle --
- * what the step plan sets around its own launches (its outputs are 8-34 MB per kernel and the next kernel runs on all
- * XCDs).  Bit 1: only the split-K slabs of weight gradients (rv_linear_wgrad, the wgrad half of rv_linear_dgrad_wgrad,
- * rv_linear_wgrad_adam) are written through -- nothing reads them before the optimizer -- while activations and
- * activation gradients keep plain stores (the deep variant's sequencer, deep.py). */
-int rv_set_store_policy(int policy);
-
 /* dW = dY^T X as `splits` partial slabs [Mp(out), Np(in)] (split over the batch) of element type slab_dtype.
  * dy [Kp(batch), Mp] bf16, x [Kp(batch), Np] bf16; both read through transposing LDS
  * reads.  Autograd of F.linear w.r.t. weight, train.py:191.  `tile`: RV_TILE_AUTO (the picker's choice) or a named

@@ -118,7 +118,6 @@ _SIGS = {
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
-    "rv_set_store_policy": (c_int, [c_int]),
     "rv_plan_loss": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rv_plan_set_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rv_reparam_bwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_void_p,
@@ -178,7 +177,7 @@ class _Lib:
             fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-            checked = res is c_int and name not in ("rv_version", "rv_set_store_policy")   # (these return values, not codes)
+            checked = res is c_int and name != "rv_version"
             setattr(self, name, _wrap(fn, name) if checked else fn)
 
 

@@ -8,14 +8,7 @@
 using namespace rv;
 
 namespace rv {
-// Store policy of the epilogues (common.h store_wt16), per host thread: bit 0 = every epilogue output of the following
-// launches is written through (the training plan sets it around its launches), bit 1 = the split-K slabs of
-// weight-gradient GEMMs only (rv_set_store_policy: a caller that sequences layers itself, whose activations the next
-// launch reads back from L2 but whose slabs nothing reads before the optimizer).
-thread_local int rv_store_wt = 0;
-}
-static inline int wt_for(bool weight_gradient_slabs) {
-  return (rv::rv_store_wt & 1) | ((weight_gradient_slabs && (rv::rv_store_wt & 2)) ? 1 : 0);
+thread_local int rv_store_wt = 0;   // see common.h; set by plan.hip around the training step's launches
 }
 
 namespace {
@@ -50,7 +43,7 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
     attr_done = true;
   }
   GemmArgs g = a;
-  g.wt = wt_for(a.wt != 0);   // (a.wt as an INPUT: the caller marks weight-gradient slabs, rv_linear_wgrad)
+  g.wt = rv_store_wt;
   g.tiles_m = (int)(Mp / BM);
   g.tiles_n = (int)(Np / BN);
   g.splits = splits;
@@ -199,8 +192,7 @@ template <int NSTAGE, bool FP8 = false>
 int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4;
   GemmArgs d = d_in, g = g_in;
-  d.wt = wt_for(false);
-  g.wt = wt_for(true);     // the wgrad half's slabs
+  d.wt = g.wt = rv_store_wt;
   const int n_d = d.tiles_m * d.tiles_n, n_w = g.tiles_m * g.tiles_n * g.splits;
   constexpr int smem = 2 * (BM + BN) * 128 + 8 * 4096;  // the ring (the epilogue's reductions reuse its first bytes) + the
                                                          // first ReLU-mask chunk of the dgrad blocks (gemm_bf16.h MASK_LDS)
@@ -240,7 +232,7 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
     attr_done = true;
   }
   GemmArgs g1 = a, g2 = b;
-  g1.wt = g2.wt = wt_for(false);
+  g1.wt = g2.wt = rv_store_wt;
   g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
   g2.tiles_m = (int)(Mp2 / BM); g2.tiles_n = (int)(Np2 / BN); g2.splits = splits2;
   const int n1 = g1.tiles_m * g1.tiles_n * splits1, n2 = g2.tiles_m * g2.tiles_n * splits2;
@@ -495,7 +487,6 @@ int rv_linear_wgrad(const void* dy, long lddy, const void* x, long ldx, long Mp,
   a.k_tiles = (int)(Kp / 64 / splits); a.M_valid = (int)Mp; a.N_valid = (int)Np;
   int rc = set_slabs(a, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
-  a.wt = 1;   // weight-gradient slabs (launch(): the store policy's bit 1 applies)
   if (tile == RV_TILE_AUTO) return launch_auto<false, false, EPI_F32>(a, Mp, Np, Kp, splits, (hipStream_t)stream);
   return launch_tile<false, false, EPI_F32>(tile, a, Mp, Np, Kp, splits, (hipStream_t)stream);
 }
@@ -531,7 +522,7 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
   g.k_tiles = (int)(Kp / kt / splits); g.M_valid = (int)Mp; g.N_valid = (int)Np; g.dq = fp8_dq;
   rc = set_slabs(g, dw, lddw, Mp * lddw, slab_dtype, slab_unscale, Mp, Np);
   if (rc) return rc;
-  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.wt = wt_for(true);
+  g.tiles_m = (int)(Mp / 256); g.tiles_n = (int)(Np / 256); g.splits = splits; g.wt = rv_store_wt;
   const int n_gemm = g.tiles_m * g.tiles_n * splits;
   constexpr int smem = 2 * (256 + 256) * 128;
   static_assert(8 * 2 * AS_SLOT <= smem, "the optimizer waves' LDS rings live in the launch's dynamic LDS");
@@ -583,12 +574,6 @@ extern "C" int rv_linear_wgrad_adam_fp8(const void* dy_fp8, long lddy, const voi
   RV_REQUIRE(dy_fp8 && x_fp8 && dq && dw && param && exp_avg && exp_avg_sq && step_counter, RV_ERR_NULL, "rv_linear_wgrad_adam_fp8: null pointer");
   return wgrad_riders("rv_linear_wgrad_adam_fp8", dy_fp8, lddy, x_fp8, ldx, Mp, Np, Kp, splits, dw, lddw, slab_dtype, slab_unscale, descs,
                       n_desc, param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, nullptr, nullptr, n_adam_blocks, stream, dq);
-}
-
-extern "C" int rv_set_store_policy(int policy) {   // (public header) -> the previous policy of this host thread
-  const int prev = rv::rv_store_wt;
-  rv::rv_store_wt = policy & 3;
-  return prev;
 }
 
 extern "C" int rv_pair_stop_event(void* ev) {   // returns whether an armed event was still pending (no paired launch took it)

@@ -1093,7 +1093,7 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
   hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt & 1, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -1129,7 +1129,7 @@ int rv_latent_fwd_pair(const void* h_bf16, long ldh, const void* wh_bf16, long l
   hipLaunchKernelGGL(k_latent_fwd_pair, dim3((unsigned)(Bp / 16)), dim3(512), LP_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt & 1, (unsigned char*)h3_fp8, ldq, q_scale, amax_part, xchg, gen, err);
+                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part, xchg, gen, err);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -1157,7 +1157,7 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.k_tiles = (int)(Bp / 64 / dw3_splits); g.M_valid = (int)Hp; g.N_valid = (int)Lp;
     g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
     g.tiles_m = (int)(Hp / 64); g.tiles_n = 1; g.splits = dw3_splits;
-    g.wt = rv_store_wt & 1;
+    g.wt = rv_store_wt;
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
   static bool attr_done = false;
@@ -1211,7 +1211,7 @@ int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
-                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt & 1, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
+                     db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

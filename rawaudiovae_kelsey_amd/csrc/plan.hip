@@ -752,7 +752,6 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
     // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    int n_tail = 2;     // tensors [0, n_tail) are updated by the step's last launch, [n_tail, 10) by the riders of launch 7
     {
       Range r(p->roctx, "rv:fc4-bwd");
       RV_K(4, fc4_backward(p, stream));
@@ -766,22 +765,19 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream, f8_w1));
       // (round 3, with 16-byte slab loads in the optimizer blocks: the heads' tensors ride as well -- 192.0 against
       // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
-      // fp8 operands: the GEMM half of this launch is ~24 us, the riders' full table ~33 at their per-CU streaming rate --
-      // so only fc4's update rides (its GEMM blocks still take a share behind their tiles) and the heads' and fc3's go to
-      // the step's last launch, which streams at the whole chip's rate (RV_FP8_RIDERS=all: round 4's table)
-      static const bool riders_all = [] { const char* e = getenv("RV_FP8_RIDERS"); return e && !strcmp(e, "all"); }();
-      n_tail = f8_w1 && !riders_all ? 8 : 2;
+      // (fp8 operands: only fc4's update riding here and the rest in the last launch was tried in round 5 -- 166.2-167.1 us
+      // per step against 164.0-164.2 with the whole table riding and the GEMM blocks taking 15 % of it: profiles/r05_fp8_riders.txt)
       if (f8_w1)
         RV_K(7, rv_linear_wgrad_adam_fp8(p->ws("dP1q"), Hp, p->ws("xq"), Sp, (float*)p->ws("fp8_state") + 15, Hp, Sp, Bp, p->s_w1,
-                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + n_tail, 10 - n_tail, p->b.param,
-                                         p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter, 256 - n_gemm, stream));
+                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2, 8, p->b.param, p->b.exp_avg,
+                                         p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter, 256 - n_gemm, stream));
       else
         RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
                                      8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                      p->b.step_counter, 256 - n_gemm, stream));
     }
     Range r(p->roctx, "rv:adam");
-    RV_K(8, rv_adam_multi(p->d_slab, n_tail, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
+    RV_K(8, rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                           p->b.step_counter, stream));
     return fp8_after_update(p, stream);
   }

@@ -65,8 +65,6 @@ class DeepTrainEngine:
         if slab_dtype not in ("fp16", "fp32"):
             raise _lib.RvError("slab_dtype %r (expected 'fp16' or 'fp32')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
-        import os
-        self.slab_wt = os.environ.get("RV_DEEP_SLAB_WT", "1") != "0"     # write-through stores for the split-K slabs
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.RvError("DeepTrainEngine needs a GPU device; there is no CPU path")
@@ -280,14 +278,10 @@ class DeepTrainEngine:
         if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != self.B * self.S:
             raise _lib.RvError("step: x must be contiguous fp32 [B, S]")
         L_, st = lib(), stream_ptr(stream)
-        # weight-gradient slabs are written through (nothing reads them before the optimizer: left dirty they are flushed
-        # at every kernel boundary with the chip idle), activations keep plain stores -- the next layer's launch finds
-        # its input rows in the L2 that wrote them (write-through everywhere cost this engine 858 -> 951 us in round 3)
-        prev_policy = L_.rv_set_store_policy(2 if self.slab_wt else 0)
-        try:
-            self._enqueue(L_, st, x, eps, recon_out, adam)
-        finally:
-            L_.rv_set_store_policy(prev_policy)
+        # (plain stores throughout: the next layer's launch finds its input rows in the L2 that wrote them -- write-through
+        # everywhere cost this engine 858 -> 951 us in round 3, and write-through for the split-K slabs alone, which
+        # nothing reads before the optimizer, 848 -> 858-864 us in round 5: profiles/r05_deep.txt)
+        self._enqueue(L_, st, x, eps, recon_out, adam)
         self.host_steps += 1
 
     def _enqueue(self, L_, st, x, eps, recon_out, adam):

@@ -186,8 +186,9 @@ class FusedLossFn(torch.autograd.Function):
         return out[0]
 
     @staticmethod
-    def backward(ctx, g):
-        rec = ctx.rec
+    def run_backward(rec, kl_beta, g):
+        """The plan's backward for the forward recorded in `rec`, times the device scalar `g`: the ten gradients as
+        exact-shape views of one fresh flat tensor."""
         eng = rec.eng
         if eng.host_steps != rec.tick:
             raise _lib.RvError(
@@ -199,14 +200,61 @@ class FusedLossFn(torch.autograd.Function):
         L_.rv_plan_set_loss_grad(eng._plan, ptr(g), ptr(grad))
         try:
             L_.rv_plan_step(eng._plan, PHASE_BWD_A | PHASE_BWD_B | PHASE_FINALIZE_A | PHASE_FINALIZE_B, None,
-                            ptr(rec.eps), None, ctx.kl, 0.0, 1.0, 0, eng.seed, stream_ptr())
+                            ptr(rec.eps), None, kl_beta, 0.0, 1.0, 0, eng.seed, stream_ptr())
         finally:
             L_.rv_plan_set_loss_grad(eng._plan, None, None)
-        out = [None, None]
+        # (weights are 2-D views of their piece; a bias IS its piece: five view calls, not ten)
+        return [piece.view(shape) if len(shape) > 1 else piece
+                for piece, shape in zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)]
+
+    @staticmethod
+    def backward(ctx, g):
+        pieces = FusedLossFn.run_backward(ctx.rec, ctx.kl, g)
         need = ctx.needs_input_grad
-        for i, (piece, shape) in enumerate(zip(grad.split_with_sizes(eng.param_sizes), eng.param_shape_list)):
-            out.append((piece.view(shape) if len(shape) > 1 else piece) if need[2 + i] else None)
-        return tuple(out)
+        return (None, None) + tuple(p if need[2 + i] else None for i, p in enumerate(pieces))
+
+
+class FusedLoss(torch.Tensor):
+    """The 0-dim loss tensor `fused_loss` hands back: an ordinary tensor in every respect (value, `.item()`, arithmetic
+    -- results are plain tensors --, and its grad_fn is FusedLossFn's node, so `torch.autograd.backward`, `.grad()` and a
+    `(2 * loss).backward()` all take the autograd engine's route), except that calling `.backward()` ON IT, the way the
+    reference loop does (train.py:191), runs the node's backward right there on the calling thread and accumulates the
+    ten gradients into `.grad` itself.  Same kernels, same gradients; what it skips is the autograd engine's hand-over to
+    its device worker thread and back for a graph of one node (~80 us of the loop's ~140 us backward at C2,
+    profiles/r05_api_breakdown.txt).  Anything the shortcut does not cover -- a `gradient` / `inputs` argument,
+    `create_graph`, hooks on a parameter or on the loss, gradients disabled -- goes to `Tensor.backward` unchanged."""
+    __torch_function__ = torch._C._disabled_torch_function_impl      # ops on it return plain tensors
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        rec = getattr(self, "_rv_rec", None)
+        if (rec is None or gradient is not None or inputs is not None or create_graph or not torch.is_grad_enabled()
+                or self._backward_hooks or not _plain_leaves(rec.params)):
+            return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
+        pieces = FusedLossFn.run_backward(rec, self._rv_kl, _one(rec.eng.device))
+        with torch.no_grad():
+            for q, g in zip(rec.params, pieces):
+                if q.grad is None:
+                    q.grad = g
+                else:
+                    q.grad.add_(g)
+
+
+_ONES = {}
+
+
+def _one(dev):
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def _plain_leaves(params):
+    """Leaf parameters without tensor hooks or post-accumulate hooks (those must see the engine's route)."""
+    for q in params:
+        if q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None) or not q.requires_grad:
+            return False
+    return True
 
 
 def fused_loss(recon_x, x, mu, logvar, kl_beta, segment_length):
@@ -225,7 +273,9 @@ def fused_loss(recon_x, x, mu, logvar, kl_beta, segment_length):
     module = rec.module()
     if module is None or not getattr(module, "fused_loss", True):
         return None
-    return FusedLossFn.apply(rec, kl_beta, *rec.params)
+    out = FusedLossFn.apply(rec, kl_beta, *rec.params).as_subclass(FusedLoss)
+    out._rv_rec, out._rv_kl = rec, float(kl_beta)
+    return out
 
 
 def forward(module, x2, eps=None, params=None):
