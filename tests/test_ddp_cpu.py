@@ -188,3 +188,37 @@ def test_shard_plan_matches_library():
                 assert spans[0][0] == lo and spans[-1][1] == hi
                 assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         L.rv_plan_destroy(plan)
+
+
+def _check_worker(rank, world, port):
+    """One rank of train.py's health check: rank 1 reports a flag wait that ran out, rank 0 is healthy."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      RV_DIST_BACKEND="gloo")
+    import train
+
+    class Engine:
+        def __init__(self, n):
+            self.n = n
+
+        def ddp_timeouts(self):
+            return self.n
+    dp = train.DataParallel(torch.device("cpu"))
+    dp.comm = object()                      # "the library-driven step is in use"
+    dp.engines = [Engine(0), Engine(3 if rank == 1 else 0)]     # the full-batch engine and the ragged tail's
+    dp.check()                              # every rank leaves here, non-zero ...
+    os._exit(0)                             # ... so this line is the failure
+
+
+def test_a_flag_timeout_on_one_rank_stops_every_rank():
+    """train.py's DataParallel.check (round-4 advisor): a rank whose data-parallel step saw a cross-stream flag wait
+    run out -- counted on ANY of its engines, the ragged-tail engine included -- must not raise alone and leave its
+    peers inside their next collective: the ranks agree on the worst count and all exit with the same non-zero code."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_check_worker, args=(r, world, port)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert [p.exitcode for p in procs] == [5, 5]

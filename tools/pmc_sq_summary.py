@@ -7,10 +7,15 @@
 Columns per kernel (averages over its dispatches in the pass):
   us         dispatch duration IN THE PMC PASS (counters serialise dispatches and the chip clocks differently: the bench's
              own in-step figure is in BENCH / profiles/*_bench.json)
-  GHz        GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS give-back; reads high on short dispatches)
-  mfma_busy  SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of SIMD-cycles with the matrix pipe busy
+  mfma us    SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / 2.4 GHz: how long the matrix pipe of an average SIMD was busy, at the
+             clock the dense peak assumes
+  busy       mfma us / us: the share of the dispatch the matrix pipes were busy (at 2.4 GHz; the chip holds less under
+             load, so the true share of CYCLES is higher by clock_nominal / clock_held)
+  busy@grbm  the same against the dispatch's own cycles, GRBM_GUI_ACTIVE / 8 XCDs (reads HIGH on dispatches this short --
+             MI355X_MICROARCH.md, DVFS give-back -- so this column is a LOWER bound of the share of cycles)
   flops/t    the launch's algorithmic FLOPs / duration / dense peak (2.5 PF bf16; 5 PF where the launch's large GEMM runs on
-             fp8 operands) -- the figure the bench prints, next to the counter's
+             fp8 operands) -- the figure the bench prints.  busy == flops/t means every MFMA issued is algorithmic work
+             (no recomputation) and the launch's distance from the peak is matrix-pipe IDLE time, which the next columns split
   of the wave-cycles (SQ_WAVE_CYCLES): wait = SQ_WAIT_ANY (parked at s_waitcnt / barrier), stall = SQ_WAIT_INST_ANY (issue
   stalls, of which lds = SQ_WAIT_INST_LDS), active = SQ_ACTIVE_INST_ANY
   lds_conf   SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -57,8 +62,8 @@ def main():
     clk, dclk = load(sys.argv[2])
     fp8 = len(sys.argv) > 3 and sys.argv[3] == "fp8"
     av = lambda v: sum(v) / len(v) if v else 0.0  # noqa: E731
-    print("%-46s %5s %7s %5s %9s %8s | %5s %5s %5s %6s | %8s" % ("launch", "n", "us", "GHz", "mfma_busy", "flops/t", "wait", "stall", "(lds)",
-                                                                    "active", "lds_conf"))
+    print("%-46s %5s %7s %7s %6s %9s %8s | %5s %5s %5s %6s | %8s" % ("launch", "n", "us", "mfma us", "busy", "busy@grbm", "flops/t", "wait",
+                                                                        "stall", "(lds)", "active", "lds_conf"))
     rows = []
     for name in sq:
         hit = [k for k in KERNELS if k[0] in name]
@@ -75,12 +80,16 @@ def main():
         ft = gflop * 1e9 / (us * 1e-6) / peak if us else 0.0
         wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
         lds_a = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
-        rows.append((label, len(dur[name]), us, ghz, busy, ft, c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc,
+        mfma_us = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / 2.4e3
+        if fp8 and is8:
+            mfma_us *= 1.0      # (an MX-scaled fp8 MFMA is busy twice the cycles of the bf16 form at 4x the K: the counter has it)
+        rows.append((label, len(dur[name]), us, (mfma_us, mfma_us / us if us else 0.0, busy), busy, ft, c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc,
                      c.get("SQ_WAIT_INST_LDS", 0) / wc, c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
                      c.get("SQ_LDS_BANK_CONFLICT", 0) / lds_a if lds_a else 0.0, name))
     for r in sorted(rows):
-        print("%-46s %5d %7.1f %5.2f %8.1f%% %7.1f%% | %4.0f%% %4.0f%% %4.0f%% %5.0f%% | %7.2f%%   %s" % (
-            r[0], r[1], r[2], r[3], 100 * r[4], 100 * r[5], 100 * r[6], 100 * r[7], 100 * r[8], 100 * r[9], 100 * r[10], r[11][:70]))
+        print("%-46s %5d %7.1f %7.1f %5.1f%% %8.1f%% %7.1f%% | %4.0f%% %4.0f%% %4.0f%% %5.0f%% | %7.2f%%   %s" % (
+            r[0], r[1], r[2], r[3][0], 100 * r[3][1], 100 * r[3][2], 100 * r[5], 100 * r[6], 100 * r[7], 100 * r[8], 100 * r[9], 100 * r[10],
+            r[11][:70]))
 
 
 if __name__ == "__main__":
