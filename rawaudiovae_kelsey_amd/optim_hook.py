@@ -117,12 +117,12 @@ _PLANS = weakref.WeakKeyDictionary()   # optimizer -> (signature of its groups, 
 def _discover(opt):
     """Which (param group, VAE module) pairs of this optimizer the hook may take over: the group holds ALL ten
     parameters of a module whose Parameters live in an engine's arena.  Re-derived when the groups change.
-    -> [(group index, weakref(module), the group's OTHER parameters), ...]"""
+    -> [(group index, weakref(module)), ...]"""
     from . import fused
     found = []
     for gi, group in enumerate(opt.param_groups):
         ids = {id(q) for q in group["params"]}
-        seen, taken = set(), set()
+        seen = set()
         mods = []
         for p in group["params"]:
             own = _OWNER.get(id(p))
@@ -137,9 +137,8 @@ def _discover(opt):
                 _decline("group holds only part of the model")   # PyTorch's step
                 continue
             mods.append(module)
-            taken.update(id(q) for q in mine)
-        if len(mods) == 1:     # (two fused models in one group: left to PyTorch -- the list swap below is per group)
-            found.append((gi, weakref.ref(mods[0]), [q for q in group["params"] if id(q) not in taken]))
+        if len(mods) == 1:     # (two fused models in one group: left to PyTorch)
+            found.append((gi, weakref.ref(mods[0])))
         elif mods:
             _decline("several fused models in one group")
     return found
@@ -171,7 +170,7 @@ def _pre_step(opt, args, kwargs):
     plans = _PLANS.get(opt)
     if plans is None or plans[0] != sig:
         plans = _PLANS[opt] = (sig, _discover(opt))
-    for gi, mref, others in plans[1]:
+    for gi, mref in plans[1]:
         group, module = groups[gi], mref()
         if module is None:
             continue
