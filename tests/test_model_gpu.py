@@ -345,6 +345,43 @@ def test_loss_function_on_fused_outputs_is_one_node_on_the_plan(S, H, L, B):
         gc.enable()
 
 
+def test_reference_loop_holds_no_memory_across_steps():
+    """The drop-in loop hangs a record on the forward's outputs, returns a tensor subclass for the loss and hides /
+    restores `.grad` fields around the stock optimizer step: none of it may keep a finished step's tensors alive.  300
+    steps of the reference loop (train.py:184-193) at a mid-sized shape: device memory in use is the same after step 300 as
+    after step 100 (the caching allocator's `memory_allocated` counts live tensors only), with the garbage collector off --
+    reference counting alone must free everything."""
+    import gc
+    from rawvae.model import loss_function
+    S, H, L, B = 512, 1024, 32, 512
+    m = _model(S, H, L)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    xs = [torch.from_numpy(make_frames(B, S, 10 + i)).cuda() for i in range(4)]
+
+    def step(i):
+        x = xs[i % 4]
+        opt.zero_grad()
+        recon, mu, logvar = m(x)
+        loss = loss_function(recon, x, mu, logvar, 1e-4, S)
+        loss.backward()
+        opt.step()
+        return loss
+    gc.collect()
+    gc.disable()
+    try:
+        for i in range(100):
+            step(i)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for i in range(100, 300):
+            last = step(i)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + 4096, (torch.cuda.memory_allocated(), base)
+        assert 0 < float(last.item()) < 1
+    finally:
+        gc.enable()
+
+
 def test_fused_forward_node_guards_and_fallbacks():
     from rawaudiovae_kelsey_amd import _lib, fused
     S, H, L, B = 64, 96, 8, 16
