@@ -146,10 +146,12 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
       for (int cb = 0; cb < 4; ++cb)
         acc[4 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[4 + cb], 0, 0, 0);
   }
-  // lane (q, j) holds partial[j][16 cb + 4 q + e]: park the wave's 16 x 128 partial sums in its weight slot 1
+  // lane (q, j) holds partial[j][16 cb + 4 q + e]: park the wave's 16 x 128 partial sums in its weight slot 1.  Rows are
+  // 512 bytes, a whole number of bank rows, so the eight lanes a 16-byte LDS store services together (same q, eight j)
+  // would all hit the same four banks: the 16-byte quad index is XORed with j & 7 (and again by the reader below)
 #pragma unroll
   for (int cb = 0; cb < 8; ++cb)
-    *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + cb * 16 + q * 4) * 4) = acc[cb];
+    *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + (((cb * 4 + q) ^ (j & 7)) << 2)) * 4) = acc[cb];
   // raw barriers: __syncthreads() would also drain vmcnt, i.e. wait for the fc3 weight slot that is meant to fly
   // across the reduction
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -169,8 +171,9 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         const lds_char* ps = smem + w * L_RING + LW_SLOT;
-        pm[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + l) * 4);
-        pv[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + 64 + l) * 4);
+        const int qm = (int)(l >> 2) ^ (rr & 7), qv = (16 + (int)(l >> 2)) ^ (rr & 7);   // the writer's swizzle
+        pm[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + (qm << 2)) * 4);
+        pv[w] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rr * 128 + (qv << 2)) * 4);
       }
       const f32x4 bm = *reinterpret_cast<const f32x4*>(bh + l), bv = *reinterpret_cast<const f32x4*>(bh + Lp + l);
       float ev[4];
@@ -423,8 +426,8 @@ k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* _
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
-      *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + cb * 16 + q * 4) * 4) = acc[rt][cb];
+    for (int cb = 0; cb < 8; ++cb)   // (quad index XOR j & 7: see k_latent_fwd)
+      *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + (((cb * 4 + q) ^ (j & 7)) << 2)) * 4) = acc[rt][cb];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // raw: __syncthreads() would drain vmcnt, i.e. wait for the fc3 slot in flight
     asm volatile("" ::: "memory");
@@ -434,8 +437,9 @@ k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* _
 #pragma unroll
       for (int w_ = 0; w_ < 8; ++w_) {
         const lds_char* ps = smem + w_ * LP_RING + LW_SLOT;
-        pm[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + l) * 4);
-        pv[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + 64 + l) * 4);
+        const int qm = (int)(l >> 2) ^ (rl & 7), qv = (16 + (int)(l >> 2)) ^ (rl & 7);
+        pm[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + (qm << 2)) * 4);
+        pv[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + (qv << 2)) * 4);
       }
 #pragma unroll
       for (int e_ = 0; e_ < 4; ++e_) {
@@ -733,10 +737,11 @@ k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __re
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[cb], 0, 0, 0);
   }
-  // lane (q, j) holds partial dz[j][16 cb + 4 q + e]: park the wave's 16 x 64 partial sums in its weight slot 0
+  // lane (q, j) holds partial dz[j][16 cb + 4 q + e]: park the wave's 16 x 64 partial sums in its weight slot 0 (256-byte
+  // rows: the 16-byte quad index XOR j & 7 spreads the eight lanes of a store group over the banks, as in k_latent_fwd)
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
-    *(__attribute__((address_space(3))) f32x4*)(W0 + (j * 64 + cb * 16 + q * 4) * 4) = acc[cb];
+    *(__attribute__((address_space(3))) f32x4*)(W0 + (j * 64 + (((cb * 4 + q) ^ (j & 7)) << 2)) * 4) = acc[cb];
   __syncthreads();
 
   float dmu[4] = {0.f, 0.f, 0.f, 0.f}, dlv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -744,7 +749,7 @@ k_latent_bwd(const bf16_t* __restrict__ dP3, const long lddp, const bf16_t* __re
     f32x4 pz[LB_WAVES];
 #pragma unroll
     for (int w = 0; w < LB_WAVES; ++w)
-      pz[w] = *(const __attribute__((address_space(3))) f32x4*)(smem + w * L_RING + (rr * 64 + l) * 4);
+      pz[w] = *(const __attribute__((address_space(3))) f32x4*)(smem + w * L_RING + (rr * 64 + ((((int)(l >> 2)) ^ (rr & 7)) << 2)) * 4);
     const float mua[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, lva[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
