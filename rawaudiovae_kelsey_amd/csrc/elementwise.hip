@@ -171,6 +171,12 @@ __global__ void __launch_bounds__(256) k_fp8_wmax(const unsigned char* __restric
   }
 }
 
+// store policy of the cast's bf16 output: the plan's (common.h rv_store_wt); RV_CAST_WT=0 keeps plain stores (A/B)
+static inline int cast_wt() {
+  static const int off = [] { const char* e = getenv("RV_CAST_WT"); return e && e[0] == '0'; }();
+  return off ? 0 : rv::rv_store_wt;
+}
+
 __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__ src, long rows,
                                                        long cols, long ld_src,
                                                        bf16_t* __restrict__ dst, long rows_p,
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
                                                        float* fp8_state, const float* __restrict__ fp8_scale,
                                                        const float* __restrict__ amax_part, int n_amax, int n_amax2,
                                                        const long long* __restrict__ frame_idx, long first_frame,
-                                                       long hop, long n_samples) {
+                                                       long hop, long n_samples, const int wt) {
   if (blockIdx.x == 0) {
     if (step_counter && threadIdx.x == 0) *step_counter += 1;
     if (fp8_state) {
@@ -233,7 +239,9 @@ __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-      *reinterpret_cast<bf16x8*>(dst + r * ld_dst + c) = o;
+      // (inside a step plan the operand is written through like every other output of the step: the next launch reads it
+      // on all XCDs, and left dirty its 8.4 MB are flushed at the kernel boundary with the chip idle)
+      store_out16(reinterpret_cast<bf16x8*>(dst + r * ld_dst + c), o, wt);
     }
     if (dst_fp8) *reinterpret_cast<unsigned long long*>(dst_fp8 + r * ld_fp8 + c) = q8x8(v, qs);
   }
@@ -804,7 +812,7 @@ int rv_cast_pad_bf16(const float* src, long rows, long cols, long ld_src, void* 
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)nullptr, 0L, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0,
-                     (const long long*)nullptr, 0L, 0L, 0L);
+                     (const long long*)nullptr, 0L, 0L, 0L, cast_wt());
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -823,7 +831,7 @@ int rv_cast_pad_bf16_q8(const float* src, long rows, long cols, long ld_src, voi
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192) + (fp8_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)dst, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state /* [0] = scale of x */,
-                     amax_part, amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, (const long long*)nullptr, 0L, 0L, 0L);
+                     amax_part, amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, (const long long*)nullptr, 0L, 0L, 0L, cast_wt());
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -843,7 +851,7 @@ int rv_gather_cast_frames(const float* audio, long n_samples, const long long* f
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192) + (fp8_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
                      audio, n_frames, S, 0L, (bf16_t*)dst_bf16, rows_p, cols_p, ld_dst, step_counter,
                      (unsigned char*)dst_fp8, ld_fp8, fp8_state, (const float*)fp8_state, amax_part,
-                     amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, frame_index, first_frame, hop, n_samples);
+                     amax_part ? n_amax : 0, amax_part ? n_amax2 : 0, frame_index, first_frame, hop, n_samples, cast_wt());
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -869,7 +877,7 @@ int rv_cast_pad_fp8(const float* src, long rows, long cols, long ld_src, void* d
   hipLaunchKernelGGL(k_cast_pad_bf16, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                      src, rows, cols, ld_src, (bf16_t*)nullptr, rows_p, cols_p, ld_dst, (long long*)nullptr,
                      (unsigned char*)dst_fp8, ld_dst, (float*)nullptr, scale, (const float*)nullptr, 0, 0,
-                     (const long long*)nullptr, 0L, 0L, 0L);
+                     (const long long*)nullptr, 0L, 0L, 0L, cast_wt());
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
