@@ -101,6 +101,22 @@ int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, l
                            void* dP4_bf16, long ld_dp4, float* mse_partial, float* db4_partial,
                            void* stream);
 
+/* decode() in ONE launch (model.py:28-30): h3 = relu(z W3^T + b3) is GENERATED inside the fc4 forward, K tile by K
+ * tile, from the block's rows of z [Bp,64] bf16 and 64-row slices of W3 [Hp,64] bf16 -- fc4's A operand never travels
+ * through the CU's L2 -> LDS port (24 KB instead of 32 KB per K tile; the port bounds that launch), and no kernel streams
+ * all of W3 through every CU.  Everything else as rv_decode_out_loss_fwd (128 x 128 tiles: n_mse_partials =
+ * (Bp/128)*(Sp/128), db4_partial [Bp/128][Sp]).  h3_bf16 (optional) receives the generated operand, which the backward
+ * needs (ReLU mask, fc4's weight gradient): bit-identical to rv_latent_fwd's h3.  Target frames: x [B,S] fp32 (ldx), or
+ * -- audio != NULL -- hop-strided frames of a resident waveform as in the real-data step (frame r =
+ * audio[f*hop : f*hop+S], f = frame_index ? frame_index[r] : first_frame + r).  Served shapes: padded latent width 64,
+ * Bp and Sp multiples of 128, Hp a multiple of 256 up to 4096; RV_ERR_UNSUPPORTED otherwise. */
+int rv_decode_fc3_out_loss_fwd(const void* z_bf16, long ldz, const void* w3_bf16, long ldw3, const float* b3,
+                               void* h3_bf16, long ldh3, const void* w4_bf16, long ldw, const float* b4, long Bp,
+                               long Sp, long Hp, long Lp, long B, long S, const float* x, long ldx,
+                               const float* audio, long n_samples, const long long* frame_index, long first_frame,
+                               long hop, float* recon, long ld_recon, void* dP4_bf16, long ld_dp4,
+                               float* mse_partial, float* db4_partial, void* stream);
+
 /* dX = dY W (autograd of F.linear, train.py:191).  dy [Mp,Kp] bf16, w [Kp,Np] bf16
  * ([out,in] layout, consumed as-is through transposing LDS reads).
  *   mask != NULL : dx_bf16 = (mask > 0) ? dX : 0   (ReLU', threshold_backward) and
@@ -187,7 +203,9 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
  * [Bp][Hp]); mu / logvar differ from the split-K route by fp32 summation order only; eps draws and the KL partial
  * layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a padded hidden width that is not a multiple
  * of 512 up to 2048.  18.8 us against 21-22 us for the three launches at C2 (profiles/r03_*): the training plan's
- * default where it applies (rv_plan_set_option, RV_OPT_LATENT_FUSED). */
+ * default where it applies (rv_plan_set_option, RV_OPT_LATENT_FUSED).
+ * w3_bf16 == NULL: heads + reparameterisation only (bias3, h3_bf16 unused) -- fc3 then runs inside the fc4 forward
+ * (rv_decode_fc3_out_loss_fwd) and this kernel streams 576 KB per CU instead of 832. */
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
@@ -502,6 +520,10 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     hand-off time-outs and must stay 0); 0 (default): rv_latent_fwd, 16 rows per workgroup and all weights through
  *     every CU.  Opt-in because it measured SLOWER in the step at C2 (19.7-21.0 against 18.0-18.8 us, three interleaved
  *     pairs on one box): the in-launch hand-off costs what the halved weight stream saves.
+ *   RV_OPT_FC3_IN_FC4  1: where RV_OPT_LATENT_FUSED applies, the operands are bf16 and rv_decode_fc3_out_loss_fwd serves
+ *     the shape, fc3 runs INSIDE the fc4 forward (its A operand is generated tile by tile from z and W3) and the latent
+ *     launch stops after the reparameterisation; 0: fc3 in the latent launch, h3 through HBM into fc4.  Same h3, bit
+ *     for bit, hence the same step.
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider
@@ -512,7 +534,7 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
  *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
 enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5,
-       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7 };
+       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7, RV_OPT_FC3_IN_FC4 = 8 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and

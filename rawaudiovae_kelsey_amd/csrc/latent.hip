@@ -91,6 +91,7 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
   const int bi = (int)(blockIdx.x >> 3);
   const int ks = (wave + bi) & 7;              // slice index
   const int rot = (bi >> 3) % NU;              // first step / slot of the walk
+  const bool do_fc3 = W3 != nullptr;           // wave-uniform (a kernel argument)
 
   // ---- heads: partial[j][n] = sum over this wave's k of h1[r0 + j][k] Wh[n][k], n = 0..127.  Step s = 64 k; its
   // weight columns come as two half-steps (head-weight rows 0..63 into W0, rows 64..127 into W1).
@@ -122,7 +123,7 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
     if (s + 2 < NU) issue_x(s + 2);
     if (s + 1 < NU) {
       issue_w(s + 1, 0);
-    } else {
+    } else if (do_fc3) {
       // behind the last step: fc3 weight slot 0 and the wave's fc3 bias slice (kw floats <= 1 KiB) start to fly
       issue_fc3(0);
       dma16((const bf16_t*)(b3 + ks * kw + (lane * 4 < kw ? lane * 4 : 0)), ring + LX_OFF);
@@ -131,9 +132,10 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[kk], acc[cb], 0, 0, 0);
-    // half B: needs W(s,B); younger: [X(s+2): 2] + W(s+1,A): 8, or fc3 slot 0 + bias: 9
+    // half B: needs W(s,B); younger: [X(s+2): 2] + W(s+1,A): 8, or fc3 slot 0 + bias: 9 (nothing without fc3)
     if (s + 2 < NU) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (s + 1 < NU || do_fc3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -212,6 +214,7 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
     kl_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
   }
 
+  if (!do_fc3) return;   // heads + reparameterisation only: fc3 runs inside the fc4 forward (gemm_bf16.h A_GEN)
   // ---- fc3: h3[r0 + j][n] = relu(sum_k W3[n][k] z[r0 + j][k] + b3[n]) for this wave's columns, 64 per slot
   if (NU > 1) issue_fc3(1);
   const lds_char* zl = smem + L_Z;
@@ -1078,14 +1081,18 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
                      const float* q_scale, float* amax_part, void* stream) {
   RV_REQUIRE(!h3_fp8 || (q_scale && ldq >= Hp && ldq % 8 == 0 && ((uintptr_t)h3_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_latent_fwd: the fp8 output needs a scale and 8-byte aligned rows");
-  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && w3_bf16 && bias3 && mulv && z_bf16 && kl_partial && h3_bf16, RV_ERR_NULL,
+  // w3_bf16 == NULL: heads + reparameterisation only (z, mu | logvar, the KL partials); fc3 is then the caller's
+  // (rv_decode_fc3_out_loss_fwd generates h3 inside the fc4 forward)
+  const bool heads_only = !w3_bf16;
+  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && mulv && z_bf16 && kl_partial && (heads_only || (bias3 && h3_bf16)), RV_ERR_NULL,
              "rv_latent_fwd: null pointer");
+  RV_REQUIRE(!heads_only || (!h3_fp8 && !amax_part), RV_ERR_UNSUPPORTED, "rv_latent_fwd: the fp8 outputs belong to fc3");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
   RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_fwd: built for a padded latent width of 64 (got %ld)", Lp);
   RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
              "rv_latent_fwd: the hidden width must be a multiple of 512 up to 2048 (got %ld)", Hp);
   RV_REQUIRE(Bp > 0 && Bp % LAT_ROWS == 0 && Hp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp &&
-                 ldw3 >= Lp && ldh3 >= Hp && ldh % 8 == 0 && ldwh % 8 == 0 && ldw3 % 8 == 0 && ldh3 % 8 == 0,
+                 (heads_only || (ldw3 >= Lp && ldh3 >= Hp && ldw3 % 8 == 0 && ldh3 % 8 == 0)) && ldh % 8 == 0 && ldwh % 8 == 0,
              RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld", Bp, Hp);
   RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
                (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16) & 15) == 0,

@@ -95,6 +95,8 @@ struct rv_plan {
   float* ext_grad_out = nullptr;
   const float* loss_grad_dev = nullptr;   // rv_plan_set_loss_grad: the FINALIZE launches multiply by this device scalar
   int latent_fused = 1;          // RV_OPT_LATENT_FUSED: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
+  int fc3_in_fc4 = 0;            // RV_OPT_FC3_IN_FC4: fc3 generated inside the fc4 forward (rv_decode_fc3_out_loss_fwd), the latent
+                                 // launch does heads + reparameterisation only
   int latent_pair = 0;           // RV_OPT_LATENT_PAIR: ... on pairs of workgroups that split the weights (rv_latent_fwd_pair;
                                  // opt-in: measured 1.5-2 us SLOWER in the step at C2)
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
@@ -404,6 +406,7 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
   switch (option) {
     case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; heads_mode_apply(p); return RV_OK;
     case RV_OPT_LATENT_PAIR: p->latent_pair = value ? 1 : 0; return RV_OK;
+    case RV_OPT_FC3_IN_FC4: p->fc3_in_fc4 = value ? 1 : 0; return RV_OK;
     case RV_OPT_FP8: return plan_set_fp8(p, value);
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
     case RV_OPT_DDP_SIGNAL: p->ddp_signal = value ? 1 : 0; return RV_OK;
@@ -684,6 +687,21 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     }
+    // fc3 inside the fc4 forward (bf16 operands, the 128 x 128 tile the partial-sum buffers were sized for)
+    bool fc3_in_fc4 = false;
+    if (p->fc3_in_fc4 && latent_fused && !p->fp8 && rv_decode_fc3_out_loss_fwd_fits(Bp, Sp, Hp, Lp)) {
+      int bm4 = 0, bn4 = 0;
+      rv_gemm_tile(Bp, Sp, 1, &bm4, &bn4);
+      fc3_in_fc4 = bm4 == 128 && bn4 == 128;
+    }
+    if (fc3_in_fc4) {
+      RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), nullptr, 0, nullptr, Bp, Hp, Lp, B, L, eps, eps_buf,
+                              seed, p->b.step_counter, mulv, z, kl_part, nullptr, 0, nullptr, 0, nullptr, nullptr, stream));
+      RV_K(3, rv_decode_fc3_out_loss_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), h3, Hp, p->ws("W4b"), Hp,
+                                        (float*)p->ws("b4p"), Bp, Sp, Hp, Lp, B, S, p->fr_hop ? nullptr : x, S,
+                                        p->fr_hop ? x : nullptr, p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop,
+                                        recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+    } else {
     if (latent_fused && p->latent_pair && rv_latent_fwd_pair_fits(Bp, Hp, Lp)) {
       int* gen = (int*)p->ws("lat_gen");
       RV_K(2, rv_latent_fwd_pair(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp,
@@ -724,6 +742,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                 nullptr, nullptr, stream));
       RV_K(3, rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
                                     recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+    }
     }
   }
   // The latent layer's backward (dz + dW3, both read dP3) and the heads' backward (dP1 + dWh, both read

@@ -110,6 +110,8 @@ class TrainEngine:
         self._latent_pair = False
         if os.environ.get("RV_LATENT_PAIR", "0") == "1":
             self.set_latent_pair(True)
+        if os.environ.get("RV_FC3_IN_FC4", "0") == "1":
+            self.set_fc3_in_fc4(True)
         self._note_init()     # the zero fills above ran on the current stream
 
     # ---- stream hygiene ---------------------------------------------------
@@ -198,6 +200,12 @@ class TrainEngine:
             self.buffer("lat_gen", torch.int32, (-1,)).zero_()     # generation counters and the time-out count start at 0
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, int(bool(enable)))
         self._latent_pair = bool(enable)
+
+    def set_fc3_in_fc4(self, enable):
+        """True: fc3 runs inside the fc4 forward (`rv_decode_fc3_out_loss_fwd`: fc4's A operand is generated tile by tile
+        from z and W3) and the latent launch stops after the reparameterisation, where the plan's shape allows (bf16
+        operands, padded latent width 64); False: fc3 in the latent launch (RV_OPT_FC3_IN_FC4).  Same h3 bit for bit."""
+        lib().rv_plan_set_option(self._plan, _lib.OPT_FC3_IN_FC4, int(bool(enable)))
 
     def set_roctx(self, enable):
         """roctx ranges (rocprofv3 --marker-trace) around the phases of every step this engine enqueues

@@ -910,3 +910,97 @@ def test_scale_by3_one_launch_any_alignment():
     with pytest.raises(Exception):
         lib().rv_scale_by3(ptr(a0), None, 5, None, None, 0, None, None, 0, ptr(g), stream_ptr())
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,S,H,Lt,hop", [(4096, 1024, 2048, 64, 0), (300, 500, 1000, 8, 0), (128, 128, 256, 64, 0),
+                                          (256, 384, 768, 33, 0), (640, 256, 4096, 64, 0), (300, 512, 1024, 16, 128)])
+def test_fc3_inside_fc4_forward_equals_two_launches(L, B, S, H, Lt, hop):
+    """rv_decode_fc3_out_loss_fwd (fc4's A operand h3 = relu(z W3^T + b3) generated tile by tile inside the launch)
+    against the two launches it replaces -- rv_linear_fwd(fc3) into HBM, then rv_decode_out_loss_fwd on 128 x 128 tiles --
+    on the same operands: h3, dP4, recon, the MSE partials and the db4 partial rows BIT-identical (the generator issues
+    the same two MFMAs per fragment in the same order, the main loop is unchanged), and against float64 numpy.  Shapes:
+    C2; ragged B / S / H / L; the shortest K loop the kernel takes (4 tiles: no refill); an odd number of N tiles; the
+    widest hidden layer; target frames read from a resident waveform (the real-data step)."""
+    rng = np.random.default_rng(B + S + H + Lt)
+    Bp, Sp, Hp, Lp = -(-B // 128) * 128, -(-S // 128) * 128, -(-H // 256) * 256, 64
+    z = np.zeros((Bp, Lp), np.float32); z[:B, :Lt] = rand_bf16(rng, (B, Lt), 1.0)
+    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.3)
+    b3 = np.zeros(Hp, np.float32); b3[:H] = rng.standard_normal(H) * 0.2
+    w4 = np.zeros((Sp, Hp), np.float32); w4[:S, :H] = rand_bf16(rng, (S, H), 0.03)
+    b4 = np.zeros(Sp, np.float32); b4[:S] = rng.standard_normal(S) * 0.1
+    zd, w3d, w4d = dev(z, torch.bfloat16), dev(w3, torch.bfloat16), dev(w4, torch.bfloat16)
+    b3d, b4d = dev(b3), dev(b4)
+    if hop:
+        n_samples = (B - 1) * hop + S
+        audio = rng.uniform(-1, 1, n_samples).astype(np.float32)
+        idx = rng.permutation(B).astype(np.int64)
+        x = np.stack([audio[i * hop:i * hop + S] for i in idx])
+        ad, idxd = dev(audio), dev(idx)
+    else:
+        x = rng.uniform(-1, 1, (B, S)).astype(np.float32)
+    xd = dev(x)
+
+    def outs():
+        return dict(h3=torch.full((Bp, Hp), 3.0, device="cuda", dtype=torch.bfloat16),
+                    recon=torch.full((B, S), 9.0, device="cuda"),
+                    dP4=torch.full((Bp, Sp), 3.0, device="cuda", dtype=torch.bfloat16),
+                    mse=torch.full(((Bp // 128) * (Sp // 128),), -1.0, device="cuda"),
+                    db4=torch.full((Bp // 128, Sp), -1.0, device="cuda"))
+    a, b = outs(), outs()
+    L.rv_linear_fwd(zd.data_ptr(), Lp, w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp, 1, a["h3"].data_ptr(), Hp, sp())
+    L.rv_gemm_force_tile(4)
+    try:
+        L.rv_decode_out_loss_fwd(a["h3"].data_ptr(), Hp, w4d.data_ptr(), Hp, b4d.data_ptr(), Bp, Sp, Hp, B, S, xd.data_ptr(), S,
+                                 a["recon"].data_ptr(), S, a["dP4"].data_ptr(), Sp, a["mse"].data_ptr(), a["db4"].data_ptr(), sp())
+    finally:
+        L.rv_gemm_force_tile(-1)
+    for rep in range(2):     # twice: nothing in the launch depends on what an earlier one left in LDS or in the outputs
+        L.rv_decode_fc3_out_loss_fwd(zd.data_ptr(), Lp, w3d.data_ptr(), Lp, b3d.data_ptr(), b["h3"].data_ptr(), Hp,
+                                     w4d.data_ptr(), Hp, b4d.data_ptr(), Bp, Sp, Hp, Lp, B, S,
+                                     None if hop else xd.data_ptr(), S, ad.data_ptr() if hop else None,
+                                     n_samples if hop else 0, idxd.data_ptr() if hop else None, 0, hop,
+                                     b["recon"].data_ptr(), S, b["dP4"].data_ptr(), Sp, b["mse"].data_ptr(),
+                                     b["db4"].data_ptr(), sp())
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, rep)
+    h3ref = np.maximum(z.astype(np.float64) @ w3.astype(np.float64).T + b3, 0)
+    got = b["h3"].float().cpu().numpy()
+    assert np.abs(got - h3ref).max() <= 2 ** -7 * max(np.abs(h3ref).max(), 1e-3)
+    rec = np.tanh(got[:B].astype(np.float64) @ w4.astype(np.float64).T[:, :S] + b4[:S])
+    np.testing.assert_allclose(b["recon"].cpu().numpy(), rec, rtol=0, atol=2e-5)
+    assert abs(float(b["mse"].double().sum()) - float(((rec - x) ** 2).sum())) <= 1e-4 * float(((rec - x) ** 2).sum())
+    from rawaudiovae_kelsey_amd import _lib
+    with pytest.raises(_lib.RvError):     # a latent width the generator does not cover
+        L.rv_decode_fc3_out_loss_fwd(zd.data_ptr(), 128, w3d.data_ptr(), 128, b3d.data_ptr(), None, 0, w4d.data_ptr(), Hp,
+                                     b4d.data_ptr(), Bp, Sp, Hp, 128, B, S, xd.data_ptr(), S, None, 0, None, 0, 0, None, 0,
+                                     b["dP4"].data_ptr(), Sp, None, None, sp())
+
+
+def test_latent_fwd_heads_only_equals_the_full_kernel(L):
+    """rv_latent_fwd with w3 == NULL (heads + reparameterisation only: fc3 is generated inside the fc4 forward) writes the
+    same mu | logvar, z, KL partials and eps as the full kernel, bit for bit."""
+    rng = np.random.default_rng(4)
+    for (B, Lt, H) in [(4096, 64, 2048), (200, 20, 512), (48, 64, 1024)]:
+        Bp, Lp, Hp = -(-B // 16) * 16, 64, H
+        h = np.zeros((Bp, Hp), np.float32); h[:B] = np.maximum(rand_bf16(rng, (B, H), 0.5), 0)
+        wh = np.zeros((2 * Lp, Hp), np.float32)
+        wh[:Lt] = rand_bf16(rng, (Lt, H), 0.05); wh[Lp:Lp + Lt] = rand_bf16(rng, (Lt, H), 0.05)
+        bh = (rng.standard_normal(2 * Lp) * 0.1).astype(np.float32)
+        w3 = rand_bf16(rng, (Hp, Lp), 0.2); b3 = (rng.standard_normal(Hp) * 0.1).astype(np.float32)
+        hd, whd, w3d, bhd, b3d = dev(h, torch.bfloat16), dev(wh, torch.bfloat16), dev(w3, torch.bfloat16), dev(bh), dev(b3)
+        ctr = torch.ones(1, dtype=torch.int64, device="cuda")
+        res = []
+        for heads_only in (False, True):
+            mulv = torch.full((Bp, 2 * Lp), 5.0, device="cuda")
+            zz = torch.full((Bp, Lp), 5.0, device="cuda", dtype=torch.bfloat16)
+            kl = torch.zeros(Bp * Lp // 1024 + 1, device="cuda")
+            e = torch.empty(B, Lt, device="cuda")
+            h3 = torch.empty(Bp, Hp, device="cuda", dtype=torch.bfloat16)
+            L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), None if heads_only else w3d.data_ptr(), Lp,
+                            None if heads_only else b3d.data_ptr(), Bp, Hp, Lp, B, Lt, None, e.data_ptr(), 5, ctr.data_ptr(),
+                            mulv.data_ptr(), zz.data_ptr(), kl.data_ptr(), None if heads_only else h3.data_ptr(), Hp, sp())
+            res.append((mulv, zz, kl, e))
+        torch.cuda.synchronize()
+        for x0, x1 in zip(*res):
+            assert torch.equal(x0, x1)
