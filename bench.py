@@ -461,8 +461,10 @@ def main():
                 native_fallback_reason = "library-driven step failed the startup check (%s)" % startup_check
                 ok = False
         if ok:
+            # RV_DDP_DEFER=0: every step completes itself (default 1: a step's last wait + update go out behind the next
+            # step's cast launch -- include/rawvae_hip.h RV_OPT_DDP_DEFER_TAIL; the timed region ends with the flush)
             runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1", sharded=sharded,
-                                         payload=None if sharded else payload)
+                                         payload=None if sharded else payload, defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
             if sharded:
                 ddp_mode = ("sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the arena -> "
                             "all-gather of %s, all issued by rv_plan_step_ddp" % (
@@ -470,7 +472,8 @@ def main():
                                 if getattr(eng, "shard_gather", "fp32") == "bf16" else "the fp32 parameters"))
             else:
                 ddp_mode = ("%s all-reduce, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its collective "
-                            "stream: fc4's behind the rest of backward, the second behind Adam(fc4)" % runner.payload)
+                            "stream: fc4's behind the rest of backward, the second behind Adam(fc4)%s" % (
+                                runner.payload, "; a step's last wait + update enqueued behind the next step's cast" if runner.defer else ""))
             ddp_mode += ", hipGraph" if runner.use_graph else ""
         else:
             sync = ddp.GradSync(eng.grad, ddp.engine_buckets(eng))
@@ -529,6 +532,8 @@ def main():
             else:
                 for i in range(args.steps):
                     step_fn(first + i)
+            if use_ddp and hasattr(runner, "flush"):
+                runner.flush()                # the K-th step's deferred update belongs to the K steps
             host = time.perf_counter() - t0   # all K steps enqueued (the host runs ahead of the GPU)
             torch.cuda.synchronize()
             if multi:

@@ -524,6 +524,13 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     the shape, fc3 runs INSIDE the fc4 forward (its A operand is generated tile by tile from z and W3) and the latent
  *     launch stops after the reparameterisation; 0: fc3 in the latent launch, h3 through HBM into fc4.  Same h3, bit
  *     for bit, hence the same step.
+ *   RV_OPT_DDP_DEFER_TAIL  1: rv_plan_step_ddp (all-reduce schedule, device-side flags, bf16 operands) returns with its
+ *     LAST wait -- second exchange done -- and the update of that bucket (fc1, heads, fc3) not yet enqueued; the next
+ *     rv_plan_step_ddp call enqueues its own cast launch first (it needs no parameter, and the compute stream has nothing
+ *     else to do while the exchange is on the links), then that wait and update, then its forward.  Anything else that
+ *     follows a step -- reading parameters or optimizer state, a checkpoint, an evaluation pass, the end of training --
+ *     needs rv_plan_ddp_flush(plan, stream) first (rv_plan_step and rv_plan_step_frames do it themselves).  The deferred
+ *     update takes its step number from a copy latched inside the step, so results are bit-identical to 0 (default).
  *   RV_OPT_DDP_W1_WIDE  1: in rv_plan_step_ddp's all-reduce schedule fc1's weight gradient -- the last GEMM of the
  *     backward, which has no optimizer riders there -- runs with twice the K splits of the local step, i.e. on all 256
  *     CUs instead of 128 (where the extents allow).  0 (default): the local step's split count on 128 CUs, whose rider
@@ -534,8 +541,12 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
  *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
 enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5,
-       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7, RV_OPT_FC3_IN_FC4 = 8 };
+       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7, RV_OPT_FC3_IN_FC4 = 8,
+       RV_OPT_DDP_DEFER_TAIL = 9 };
 int rv_plan_set_option(rv_plan*, int option, int value);
+/* Enqueue what a data-parallel step left to "the next call" (RV_OPT_DDP_DEFER_TAIL): the wait for the second exchange
+ * and the update behind it, on the stream the step was enqueued on.  No-op when nothing is pending. */
+int rv_plan_ddp_flush(rv_plan*, void* stream);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and
  * dlogvar [B,L], all exact-shape fp32, each NULL = zero; the reparameterisation backward then takes kl_beta from

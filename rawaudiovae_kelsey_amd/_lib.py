@@ -42,6 +42,7 @@ class CommDesc(C.Structure):
 OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE, OPT_DDP_WAIT_MS = 0, 1, 2, 3, 4, 5, 6
 OPT_LATENT_PAIR = 7
 OPT_FC3_IN_FC4 = 8
+OPT_DDP_DEFER_TAIL = 9
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
 TILE_256x256 = 7     # RV_TILE_256x256 (include/rawvae_hip.h)
@@ -137,6 +138,7 @@ _SIGS = {
     "rv_shard_msg_slots": (c_long, [C.POINTER(ParamDesc), c_int, c_long]),
     "rv_shard_encode": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_shadows_from_msg": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
+    "rv_plan_ddp_flush": (c_int, [c_void_p, c_void_p]),
     "rv_plan_step_ddp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
     "rv_graph_begin": (c_int, [c_void_p]),

@@ -1046,8 +1046,12 @@ int rv_ew_f32(int op, const float* a, const float* b, long n, float* out, void* 
 // collective library's own watchdog) for an edge whose setter sits behind a collective, i.e. behind the slowest PEER:
 // ranks reach a step tens of milliseconds apart as a matter of course and seconds apart around a checkpoint.  A
 // timeout is counted in `timeouts` and the engine raises when it sees a non-zero count (that step's results are invalid).
-__global__ void __launch_bounds__(64) k_flag_set(int* flag, int value) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+__global__ void __launch_bounds__(64) k_flag_set(int* flag, int value, const long long* copy_src, long long* copy_dst) {
+  if (threadIdx.x == 0) {
+    // (rv_flag_set_copy: a device word latched on the way -- the step number this step's deferred update will need)
+    if (copy_src) *copy_dst = *copy_src;
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 __global__ void __launch_bounds__(64) k_flag_wait(const int* flag, int value, int* timeouts, long long max_ticks) {
   if (threadIdx.x == 0) {
@@ -1062,8 +1066,9 @@ __global__ void __launch_bounds__(64) k_flag_wait(const int* flag, int value, in
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
 }
-int rv_flag_set(int* flag, int value, void* stream) {
-  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);
+int rv_flag_set(int* flag, int value, void* stream) { return rv_flag_set_copy(flag, value, nullptr, nullptr, stream); }
+int rv_flag_set_copy(int* flag, int value, const long long* copy_src, long long* copy_dst, void* stream) {
+  hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, copy_src, copy_dst);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -69,6 +69,8 @@ RV_INTERNAL int rv_decode_fc3_out_loss_fwd_fits(long Bp, long Sp, long Hp, long 
 // Device-side cross-stream signalling (elementwise.hip): publish `value` behind the stream's earlier work / hold the
 // stream until the flag has reached `value` (bounded; timeouts are counted in *timeouts).
 RV_INTERNAL int rv_flag_set(int* flag, int value, void* stream);
+// ... and *copy_dst = *copy_src first (same one-wave kernel)
+RV_INTERNAL int rv_flag_set_copy(int* flag, int value, const long long* copy_src, long long* copy_dst, void* stream);
 RV_INTERNAL int rv_flag_wait(const int* flag, int value, int* timeouts, long max_ms, void* stream);
 // rv_adam_multi that withholds the update when `*poison` is non-zero (poison may be NULL): the data-parallel step passes
 // its count of flag waits that ran out, so that a step whose exchange did not complete in time changes no parameter.

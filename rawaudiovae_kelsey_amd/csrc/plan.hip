@@ -127,6 +127,12 @@ struct rv_plan {
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
   long ddp_wait_ms = 30000;    // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
+  // RV_OPT_DDP_DEFER_TAIL: the all-reduce schedule leaves its last wait (second exchange done) and the update behind it
+  // to the NEXT call, which enqueues its own cast launch first -- that launch needs no parameter, and the compute stream
+  // has nothing else to do while the exchange is on the links.  tail_*: what the deferred half needs from its step.
+  int ddp_defer = 0, tail_pending = 0, tail_seq = 0;
+  float tail_lr = 0.f, tail_scale = 1.f;
+  int cast_done = 0;           // the forward's cast launch went out ahead of its phase (ddp_finish_tail's caller)
   int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
   int ddp_w1_wide = 0;
   int roctx = 0;               // RV_OPT_ROCTX: roctx ranges around the step's phases
@@ -407,6 +413,10 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
     case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; heads_mode_apply(p); return RV_OK;
     case RV_OPT_LATENT_PAIR: p->latent_pair = value ? 1 : 0; return RV_OK;
     case RV_OPT_FC3_IN_FC4: p->fc3_in_fc4 = value ? 1 : 0; return RV_OK;
+    case RV_OPT_DDP_DEFER_TAIL:
+      RV_REQUIRE(value || !p->tail_pending, RV_ERR_STATE, "rv_plan_set_option: a deferred update is pending (rv_plan_ddp_flush first)");
+      p->ddp_defer = value ? 1 : 0;
+      return RV_OK;
     case RV_OPT_FP8: return plan_set_fp8(p, value);
     case RV_OPT_SLAB_DTYPE: return plan_set_slab_dtype(p, value);
     case RV_OPT_DDP_SIGNAL: p->ddp_signal = value ? 1 : 0; return RV_OK;
@@ -620,6 +630,10 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                  float kl_beta, float lr, float grad_scale, int adam_from_flat,
                  unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step: plan not bound");
+  if (p->tail_pending) {   // a data-parallel step left its last update to "the next call": this is it
+    const int frc = rv_plan_ddp_flush(p, stream);
+    if (frc) return frc;
+  }
   WtScope wt_scope;
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
@@ -683,7 +697,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_K(1, rv_linear_fwd_fp8(p->ws("xq"), Sp, p->ws("W1q"), Sp, (float*)p->ws("b1p"), f8 + 5, Bp, Hp, Sp, RV_ACT_RELU,
                                h1, Hp, stream));
     } else {
-      RV_K(0, rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
+      if (p->cast_done) p->cast_done = 0;   // went out ahead of the previous step's deferred update (rv_plan_step_ddp)
+      else RV_K(0, rv_cast_pad_bf16(x, B, S, S, xb, Bp, Sp, Sp, p->b.step_counter, stream));
       RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     }
@@ -1037,6 +1052,28 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
   return RV_OK;
 }
 
+// The deferred half of an all-reduce step (RV_OPT_DDP_DEFER_TAIL): wait for the second exchange, update its bucket.
+// The step number comes from the copy edge 1's flag kernel latched (ddp_flags[16..17]): the device counter itself may
+// already have been bumped by the next step's cast launch.
+static int ddp_finish_tail(rv_plan* p, void* stream) {
+  int* fl = (int*)p->ws("ddp_flags");
+  int rc = rv_flag_wait(fl + 3, p->tail_seq, fl + 8, p->ddp_wait_ms, stream);
+  if (rc) return rc;
+  rc = rv_adam_multi_guarded(p->d_flat, 8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr,
+                             p->payload_bf16 ? p->grad_bf16 : nullptr, p->tail_lr, p->tail_scale,
+                             (const long long*)(fl + 16), fl + 8, stream);
+  p->tail_pending = 0;
+  return rc;
+}
+
+int rv_plan_ddp_flush(rv_plan* p, void* stream) {
+  RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_ddp_flush: plan not bound");
+  if (!p->tail_pending) return RV_OK;
+  RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_ddp_flush: needs the stream the step was enqueued on");
+  WtScope wt_scope;
+  return ddp_finish_tail(p, stream);
+}
+
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                      unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
@@ -1044,6 +1081,18 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
   WtScope wt_scope;
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
+  if (p->tail_pending) {
+    // the previous step's deferred half: this step's cast first (it reads x and writes the bf16 frames, nothing else --
+    // fc1's weight gradient, the frames' last reader, is long done), then the wait for the exchange and the update
+    RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step_ddp: x is null");
+    if (!p->reduce_scatter && !p->fp8 && !(p->skip & 1)) {
+      const int crc = rv_cast_pad_bf16(x, p->B, p->S, p->S, p->ws("xb"), p->Bp, p->Sp, p->Sp, p->b.step_counter, stream);
+      if (crc) return crc;
+      p->cast_done = 1;
+    }
+    const int frc = ddp_finish_tail(p, stream);
+    if (frc) { p->cast_done = 0; return frc; }
+  }
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
   void* xb = p->ws("xb"); void* dP1 = p->ws("dP1");
@@ -1119,7 +1168,8 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     // needs EVERY CU whole (256 workgroups, two 256-VGPR waves per SIMD): with one CU short it runs in two rounds
     // (measured: 34 -> 60 us).  The other waiters start spinning late in the backward, beside kernels that leave room.
     if (flags && edge != 0) {
-      RV_TRY(rv_flag_set(fl + edge, seq, (void*)from));
+      // (edge 1 also latches the step number for a deferred update: see ddp_finish_tail)
+      RV_TRY(rv_flag_set_copy(fl + edge, seq, edge == 1 ? p->b.step_counter : nullptr, (long long*)(fl + 16), (void*)from));
       return rv_flag_wait(fl + edge, seq, fl + 8, LOCAL_WAIT_MS, (void*)to);   // edges 0, 1: set behind this device's own kernels
     }
     hipEvent_t e = edge < 2 ? p->ev_ready[edge] : p->ev_done[edge - 2];
@@ -1174,6 +1224,11 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(post(3, sc));
   RV_TRY(await(2, s0));                                    // fc4's sum has arrived (long ago, if the links keep up): its
   RV_TRY(adam_bucket(8, 2));                               // update runs while the second exchange is on the links
+  if (flags && p->ddp_defer && !p->fp8) {
+    // the join and the last update wait for the next call (or rv_plan_ddp_flush): see RV_OPT_DDP_DEFER_TAIL
+    p->tail_pending = 1; p->tail_seq = seq; p->tail_lr = lr; p->tail_scale = scale;
+    return RV_OK;
+  }
   RV_TRY(await(3, s0));                                    // the join
   RV_TRY(adam_bucket(0, 8));
   RV_TRY(fp8_after_update(p, stream));

@@ -439,15 +439,20 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False, payload=None, sharded=False, gather=None):
-        """payload (all-reduce schedule): "fp32" (default, `DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in)."""
+    def __init__(self, engine, comm, stream, use_graph=False, payload=None, sharded=False, gather=None, defer=False):
+        """payload (all-reduce schedule): "fp32" (default, `DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in).
+        defer: every step leaves its last wait and update to the next one, whose cast launch goes out first
+        (`TrainEngine.set_ddp_defer`); the loop calls `flush()` before it reads anything back."""
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
         self.sharded = bool(sharded)
+        self.defer = bool(defer) and not self.sharded and not use_graph
         if stream is not None:
             # before any collective of the step and before any capture: the choice times a few launches and is
             # agreed between the ranks (pick_comm_stream)
             engine._pick_comm_stream(stream)
         engine.attach_comm(comm, sharded=self.sharded, gather=gather, payload=payload)
+        if self.defer:
+            engine.set_ddp_defer(True)
         self._graphs = {}
         self.payload = "fp32" if self.sharded else engine.ddp_payload
 
@@ -458,6 +463,10 @@ class NativeDdpRunner:
         self.engine.set_ddp_payload(payload)
         self.payload = payload
         self._graphs = {}
+
+    def flush(self):
+        """Complete a deferred step (no-op otherwise)."""
+        self.engine.ddp_flush(self.stream)
 
     def step(self, x):
         e = self.engine

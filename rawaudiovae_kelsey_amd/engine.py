@@ -176,6 +176,7 @@ class TrainEngine:
 
     def load_params(self, params):
         """params: name -> array/tensor with the reference's nn.Linear shapes."""
+        self.ddp_flush()
         with torch.no_grad():
             for k in PARAM_NAMES:
                 src = params[k]
@@ -232,6 +233,7 @@ class TrainEngine:
         owner rank only: they are gathered first (a collective -- every rank reaches this point together, because
         the engines of all ranks step in the same order), or this engine would compute with stale weights for
         (world - 1) / world of the arena."""
+        self.ddp_flush()              # a deferred data-parallel update writes parameters and shadows: before anything else
         self._await_init(stream)      # first: the parameters may have been written on another stream, and everything
                                       # below (the masters' gather, the fp8 maxima, the shadow rebuild) reads them on `stream`
         owner = self._shared.get("bf16_gather_engine")
@@ -399,6 +401,7 @@ class TrainEngine:
 
     def _reattach(self, **fields):
         """Change fields of the attached communicator descriptor (rv_comm_desc is copied by the library)."""
+        self.ddp_flush()      # a deferred update belongs to the descriptor it was enqueued under
         d = getattr(self, "_comm_desc", None)
         if d is None:
             raise _lib.RvError("no communicator attached (attach_comm)")
@@ -438,12 +441,31 @@ class TrainEngine:
         if self._shared.get("init_events") or getattr(self, "_local_init", None) is not None:
             self._await_init(stream)
         self._pick_comm_stream(stream)
+        self._ddp_stream = stream
         lib().rv_plan_step_ddp(self._plan, ptr(x), ptr(eps), ptr(recon_out), self.kl_beta, self.lr, self.seed,
                                stream_ptr(stream))
         self.host_steps += 1
         self._shared["version"] += 1
         self._shadow_version = self._shared["version"]
         _ops_invalidate()
+
+    def set_ddp_defer(self, enable):
+        """True: `step_ddp` (all-reduce schedule, eager launches) leaves its last wait -- second exchange done -- and the
+        update of that bucket (fc1, heads, fc3) to the NEXT `step_ddp` call, which enqueues its cast launch first: the
+        compute stream has nothing else to do while the exchange is on the links (RV_OPT_DDP_DEFER_TAIL; bit-identical
+        results).  Whoever reads `param` / `exp_avg*` directly, or steps ANOTHER engine that shares this arena, calls
+        `ddp_flush()` first; `step`, `step_frames`, `refresh_shadows`, the state-dict and health-check methods do it
+        themselves.  False (default): every step completes itself."""
+        if not enable:
+            self.ddp_flush()
+        lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_DEFER_TAIL, int(bool(enable)))
+
+    def ddp_flush(self, stream=None):
+        """Enqueue what a deferred `step_ddp` left over (no-op when nothing is pending), on that step's stream."""
+        if getattr(self, "_plan", None) is None or not hasattr(self, "_ddp_stream"):
+            return
+        st = stream if stream is not None else self._ddp_stream
+        lib().rv_plan_ddp_flush(self._plan, stream_ptr(st))
 
     def _pick_comm_stream(self, stream):
         """The collectives' stream is chosen per compute stream by measurement (ddp.pick_comm_stream: two streams
@@ -519,6 +541,7 @@ class TrainEngine:
         agrees on `ddp_timeouts()` across ranks and stops them together (train.py DataParallel.check)."""
         if getattr(self, "_comm", None) is None:
             return
+        self.ddp_flush()
         fl = getattr(self, "_ddp_flags", None)
         if fl is None:
             fl = self._ddp_flags = self.buffer("ddp_flags", torch.int32, (-1,))
@@ -533,6 +556,7 @@ class TrainEngine:
         agree with their peer ranks on what to do."""
         if getattr(self, "_comm", None) is None:
             return 0
+        self.ddp_flush()      # a deferred wait has not run yet: it counts
         fl = getattr(self, "_ddp_flags", None)
         if fl is None:
             fl = self._ddp_flags = self.buffer("ddp_flags", torch.int32, (-1,))
@@ -564,6 +588,7 @@ class TrainEngine:
 
     # ---- optimizer state in torch.optim.Adam form (checkpoints, train.py:208-212) ----
     def optimizer_state_dict(self):
+        self.ddp_flush()
         t = float(self.steps_done())
         state = {i: {"step": torch.tensor(t), "exp_avg": self.view(self.exp_avg, k).clone(),
                      "exp_avg_sq": self.view(self.exp_avg_sq, k).clone()} for i, k in enumerate(PARAM_NAMES)}
@@ -573,6 +598,7 @@ class TrainEngine:
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd):
+        self.ddp_flush()
         st = sd["state"]
         with torch.no_grad():
             for i, k in enumerate(PARAM_NAMES):

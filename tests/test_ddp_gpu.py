@@ -188,6 +188,47 @@ with torch.cuda.stream(st):
         run.step(x)
 st.synchronize()
 assert torch.equal(shg.param, ref.param), "graph-replayed sharded step differs"
+# deferred tail (RV_OPT_DDP_DEFER_TAIL): each step leaves its last wait + update to the next call, whose cast launch goes
+# out first; different batches per step (the early cast must not disturb the previous step's weight gradient), both
+# payloads; flushed by the runner, by the health check, by a local step and by the state-dict readers -- always the
+# bits of the undeferred run
+xs = [torch.from_numpy(make_frames(B, S, 20 + i)).cuda() for i in range(6)]
+for payload in ("fp32", "bf16"):
+    plain = fresh(); plain.attach_comm(comm, payload=payload)
+    de = fresh(); run = ddp.NativeDdpRunner(de, comm, st, payload=payload, defer=True)
+    assert run.defer
+    with torch.cuda.stream(st):
+        for xi in xs:
+            plain.step_ddp(xi, stream=st)
+            run.step(xi)
+    st.synchronize()
+    assert not torch.equal(de.param, plain.param)          # the last update of fc1 / heads / fc3 is still pending
+    # ... fc4's (the arena's tail) is not
+    assert torch.equal(de.param[-(S * H + S):], plain.param[-(S * H + S):])
+    with torch.cuda.stream(st):
+        run.flush()
+        run.flush()                                         # a second flush is a no-op
+    st.synchronize()
+    for name in ("param", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(de, name), getattr(plain, name)), (payload, name)
+    assert de.losses(6) == plain.losses(6) and de.steps_done() == 6
+    for name in ("W1b", "Whb", "W3b", "W4b"):
+        assert torch.equal(de.buffer(name, torch.bfloat16, (-1,)), plain.buffer(name, torch.bfloat16, (-1,))), name
+    with torch.cuda.stream(st):
+        run.step(xs[0]); plain.step_ddp(xs[0], stream=st)
+        assert de.ddp_timeouts() == 0                       # flushes first (the deferred wait counts)
+        run.step(xs[1]); plain.step_ddp(xs[1], stream=st)
+        de.step(xs[2], stream=st); plain.step(xs[2], stream=st)     # a local step completes the deferred one itself
+        run.step(xs[3]); plain.step_ddp(xs[3], stream=st)
+        sd = de.optimizer_state_dict()                      # so do the state-dict readers
+    st.synchronize()
+    assert torch.equal(de.param, plain.param) and torch.equal(de.exp_avg_sq, plain.exp_avg_sq), payload
+    de.set_ddp_defer(False)
+    with torch.cuda.stream(st):
+        run.step(xs[4]); plain.step_ddp(xs[4], stream=st)
+    st.synchronize()
+    assert torch.equal(de.param, plain.param), payload
+    del plain, de, run
 comm.destroy()
 dist.destroy_process_group()
 print("NATIVE_OK")

@@ -98,7 +98,9 @@ def main():
     for world, bus, lat, payload in cfgs:
         e = engine()
         e.attach_comm(Comm(lib, world, lat, bus, blocks=nblk if bus > 0 else 0, lds=lds), payload=payload)
+        e.set_ddp_defer(os.environ.get("RV_DDP_DEFER", "1") == "1")   # a step's last wait + update behind the next step's cast
         t = time_steps(lambda i: e.step_ddp(xs[i % 8], stream=st), st)
+        e.ddp_flush()
         es = 2 if payload == "bf16" else 4
         if bus > 0:
             ar = [lat + 2.0 * (world - 1) / world * n * es / (bus * 1e3) for n in (n_fc4, n_rest)]

@@ -23,6 +23,7 @@ B="python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-al
 for i in 1 2; do
   $B > $O/tmp_b.json 2>$O/tmp_b.err; line "local step" $O/tmp_b.json
   RV_FORCE_DDP=1 RV_DDP_ALT=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, all-reduce, bf16 payload (bench)" $O/tmp_b.json
+  RV_FORCE_DDP=1 RV_DDP_ALT=0 RV_DDP_DEFER=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "... every step completing itself (RV_DDP_DEFER=0)" $O/tmp_b.json
   RV_FORCE_DDP=1 RV_DDP_ALT=0 RV_DDP_PAYLOAD=fp32 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, all-reduce, fp32 payload (library default)" $O/tmp_b.json
   RV_FORCE_DDP=1 RV_DDP_MODE=sharded RV_DDP_ALT=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, sharded optimizer" $O/tmp_b.json
 done
