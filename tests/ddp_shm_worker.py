@@ -93,19 +93,25 @@ def main():
         # (mode, payload, gather, wide): `wide` = fc1's weight gradient with twice the local step's K splits on all CUs
         # (opt-in: RV_OPT_DDP_W1_WIDE, off by default); with the local split count and the fp32 payload the arithmetic
         # is the reference's
-        modes = (("allreduce", "fp32", None, False), ("allreduce", "fp32", None, True), ("allreduce", "bf16", None, True),
-                 ("sharded", None, "fp32", True), ("sharded", None, "bf16", True))
-        for mode, payload, gather, wide in modes:
+        # `defer`: every step leaves its last wait + update to the next call, behind that step's cast launch
+        # (RV_OPT_DDP_DEFER_TAIL, what bench.py runs at N > 1); the loop flushes before it reads back
+        modes = (("allreduce", "fp32", None, False, False), ("allreduce", "fp32", None, True, False),
+                 ("allreduce", "bf16", None, True, False), ("allreduce", "fp32", None, False, True),
+                 ("allreduce", "bf16", None, False, True), ("sharded", None, "fp32", True, False),
+                 ("sharded", None, "bf16", True, False))
+        for mode, payload, gather, wide, defer in modes:
             ea = fresh()
-            ra = ddp.NativeDdpRunner(ea, comm, st, sharded=mode == "sharded", payload=payload, gather=gather)
+            ra = ddp.NativeDdpRunner(ea, comm, st, sharded=mode == "sharded", payload=payload, gather=gather, defer=defer)
+            assert ra.defer == defer
             ea.set_ddp_w1_wide(wide)
             with torch.cuda.stream(st):
                 for x in xs:
                     ra.step(x)
+                ra.flush()
             torch.cuda.synchronize()
             if mode == "sharded" and gather == "bf16":
                 ddp.gather_sharded_params(ea)   # fp32 weight masters live on their owner ranks
-            tag = "%r %s payload=%s gather=%s wide=%s" % ((S, H, L, B), mode, payload, gather, wide)
+            tag = "%r %s payload=%s gather=%s wide=%s defer=%s" % ((S, H, L, B), mode, payload, gather, wide, defer)
             shadows = [ea.buffer(n, torch.bfloat16, (-1,)) for n in ("W1b", "Whb", "W3b", "W4b")]
             if not agree(same_on_all_ranks(ea.param, *shadows)):
                 failures.append(tag + ": replicas differ")
