@@ -432,12 +432,15 @@ def main():
                 eb = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=7, ring=16)
                 for e in (ea, eb):
                     e.load_params(make_params(S, H, L, 0))
-                ra = ddp.NativeDdpRunner(ea, comm, comp, sharded=sharded, payload=None if sharded else payload)
+                # (the checked runner defers its tail exactly as the timed one will: RV_DDP_DEFER)
+                ra = ddp.NativeDdpRunner(ea, comm, comp, sharded=sharded, payload=None if sharded else payload,
+                                         defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
                 rb = ddp.DdpRunner(eb, ddp.GradSync(eb.grad, ddp.engine_buckets(eb)), comp, use_graphs=False)
                 with torch.cuda.stream(comp):   # same seed and step counters: both engines draw the same eps
                     for i in range(3):
                         ra.step(pool[i % POOL])
                         rb.step(pool[i % POOL])
+                    ra.flush()
                 torch.cuda.synchronize()
                 ddp.gather_sharded_params(ea)
                 chk = torch.stack([ea.param.double().sum(), ea.param.double().abs().sum(),
