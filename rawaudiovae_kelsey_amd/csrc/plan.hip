@@ -717,47 +717,47 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                                         p->fr_hop ? x : nullptr, p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop,
                                         recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
     } else {
-    if (latent_fused && p->latent_pair && rv_latent_fwd_pair_fits(Bp, Hp, Lp)) {
-      int* gen = (int*)p->ws("lat_gen");
-      RV_K(2, rv_latent_fwd_pair(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp,
-                                 Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
-                                 p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
-                                 p->fp8 ? (float*)p->ws("h3_amax") : nullptr, (float*)p->ws("lat_xchg"), gen, gen + Bp / 16,
-                                 stream));
-    } else if (latent_fused)
-      RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
-                              B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
-                              p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
-                              p->fp8 ? (float*)p->ws("h3_amax") : nullptr, stream));
-    else
-      RV_K(2, rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
-                                  eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
-    if (p->fr_hop) {
-      if (p->fp8 && !latent_fused)
-        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
-      else if (!latent_fused)
-        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
-                                nullptr, nullptr, stream));
-      RV_K(3, rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
-                                           (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
-                                           p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S,
-                                           f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp, f8 + 12,
-                                           mse_part, (float*)p->ws("db4p"), stream));
-    } else if (p->fp8) {
-      if (!latent_fused)
-        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
-                                p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
-      RV_K(3, rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
-                                        x, S, recon_out, S, f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp,
-                                        f8 + 12, mse_part, (float*)p->ws("db4p"), stream));
-    } else {
-      if (!latent_fused)
-        RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
-                                nullptr, nullptr, stream));
-      RV_K(3, rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
-                                    recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
-    }
+      if (latent_fused && p->latent_pair && rv_latent_fwd_pair_fits(Bp, Hp, Lp)) {
+        int* gen = (int*)p->ws("lat_gen");
+        RV_K(2, rv_latent_fwd_pair(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp,
+                                   Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
+                                   p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
+                                   p->fp8 ? (float*)p->ws("h3_amax") : nullptr, (float*)p->ws("lat_xchg"), gen, gen + Bp / 16,
+                                   stream));
+      } else if (latent_fused)
+        RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
+                                B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
+                                p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
+                                p->fp8 ? (float*)p->ws("h3_amax") : nullptr, stream));
+      else
+        RV_K(2, rv_heads_reparam_fwd(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), Bp, Lp, Hp, B, L, p->s_heads, mulv_slabs,
+                                    eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, stream));
+      if (p->fr_hop) {
+        if (p->fp8 && !latent_fused)
+          RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                                  p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+        else if (!latent_fused)
+          RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+                                  nullptr, nullptr, stream));
+        RV_K(3, rv_decode_out_loss_fwd_frames(p->fp8 ? p->ws("h3q") : h3, Hp, p->fp8 ? p->ws("W4q") : p->ws("W4b"), Hp,
+                                             (float*)p->ws("b4p"), p->fp8 ? f8 + 6 : nullptr, Bp, Sp, Hp, B, S, x,
+                                             p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop, recon_out, S,
+                                             f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp, f8 + 12,
+                                             mse_part, (float*)p->ws("db4p"), stream));
+      } else if (p->fp8) {
+        if (!latent_fused)
+          RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp,
+                                  p->ws("h3q"), Hp, f8 + 3, (float*)p->ws("h3_amax"), stream));
+        RV_K(3, rv_decode_out_loss_fwd_fp8(p->ws("h3q"), Hp, p->ws("W4q"), Hp, (float*)p->ws("b4p"), f8 + 6, Bp, Sp, Hp, B, S,
+                                          x, S, recon_out, S, f8_bwd ? nullptr : dP4, Sp, f8_bwd ? p->ws("dP4q") : nullptr, Sp,
+                                          f8 + 12, mse_part, (float*)p->ws("db4p"), stream));
+      } else {
+        if (!latent_fused)
+          RV_K(2, rv_linear_fwd_ex(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp, RV_ACT_RELU, h3, Hp, nullptr, 0,
+                                  nullptr, nullptr, stream));
+        RV_K(3, rv_decode_out_loss_fwd(h3, Hp, p->ws("W4b"), Hp, (float*)p->ws("b4p"), Bp, Sp, Hp, B, S, x, S,
+                                      recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
+      }
     }
   }
   // The latent layer's backward (dz + dW3, both read dP3) and the heads' backward (dP1 + dWh, both read
