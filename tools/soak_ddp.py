@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from oracle.inputs import make_frames, make_params  # noqa: E402  (inputs only; nothing under oracle/ computes here)
+from rawaudiovae_kelsey_amd.synth import make_frames, make_params  # noqa: E402
 from rawaudiovae_kelsey_amd import ddp  # noqa: E402
 from rawaudiovae_kelsey_amd.engine import TrainEngine  # noqa: E402
 
