@@ -118,6 +118,10 @@ def main():
             d = (ea.param - eb.param).abs()
             if payload == "bf16" or (mode == "allreduce" and wide):
                 ok = float(d.mean()) < 0.05 * LR and float(d.max()) <= 2.1 * 3 * LR
+            elif world > 2:
+                # three or more summands: the stand-in's exchange and gloo's add the ranks' gradients in different
+                # orders, so the two routes agree to fp32 summation order (observed: max 1.5e-4 lr), not bit for bit
+                ok = float(d.max()) <= 0.01 * LR
             else:
                 ok = bool(torch.equal(ea.param, eb.param))
                 if ok and not (mode == "sharded"):   # sharded: moments are valid on their owner rank only

@@ -37,16 +37,19 @@ def test_two_rank_bench_flow_keeps_replicas_identical():
     assert "cpu_baseline" not in out          # reported at N=1 only
 
 
-def test_native_ddp_step_two_processes_one_gpu():
-    """`rv_plan_step_ddp` with world = 2 (rank 0 AND rank 1), two processes on this one GPU: RCCL refuses two ranks on a
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_ddp_step_two_processes_one_gpu(world):
+    """`rv_plan_step_ddp` with world = 2 and 4 (every rank a process of its own on this one GPU): RCCL refuses two ranks on a
     device, so the collectives are the functional stand-ins of tools/fake_collective.hip (`shm_*`, RCCL's signatures, a
     real exchange through shared memory) -- everything else is the product path.  All four exchange modes (all-reduce
     with fp32 / bf16 payload, sharded optimizer with fp32 all-gather / 16-bit parameter message), small shape and C2:
-    replicas identical, and equal to the torch.distributed route (tests/ddp_shm_worker.py)."""
+    replicas identical, and equal to the torch.distributed route (tests/ddp_shm_worker.py) -- bit for bit with two
+    ranks, to fp32 summation order with four (the two routes add the ranks' gradients in different orders); with and
+    without the deferred tail; and the native step against the ORACLE on the concatenated batch of all ranks."""
     so = os.path.join(REPO, "tools", "libfakecoll.so")
     assert os.path.exists(so), "tools/libfakecoll.so missing: __graft_entry__.build() compiles it"
     env = dict(os.environ, RV_COMM_STREAM_ALLOW_SLOW="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(REPO, "tests", "ddp_shm_worker.py")]
     # (Two processes time-share ONE GPU here, which exposed an ordering bug the one-process tests never showed: an engine
     # initialised on one stream and stepped on another without an edge between the two -- engine._note_init /
