@@ -400,8 +400,13 @@ def main():
     # the bench's exchange is an explicit choice, named in the line (config.ddp_payload): bf16 gradient payload -- what the
     # 8-GPU target is sized against -- with the library's default (fp32, the exact mean) timed beside it (alt_fp32_payload)
     payload = os.environ.get("RV_DDP_PAYLOAD", ddp.BENCH_PAYLOAD)
+    rehearsal = False
     if use_ddp:
-        want_native = multi and backend == "nccl" and os.environ.get("RV_DDP", "native") != "torch"
+        # RV_DDP_REHEARSAL=shm (with RV_DIST_BACKEND=gloo): the library-driven step through the functional stand-in
+        # collectives of tools/fake_collective.hip -- every line of this N > 1 branch on a ONE-GPU box, where RCCL itself
+        # refuses two ranks on a device.  A rehearsal of the flow, never a measurement: the line says so.
+        rehearsal = multi and backend != "nccl" and os.environ.get("RV_DDP_REHEARSAL") == "shm"
+        want_native = multi and (backend == "nccl" or rehearsal) and os.environ.get("RV_DDP", "native") != "torch"
         ok = False
         if not want_native:
             native_fallback_reason = "RV_DDP=torch" if os.environ.get("RV_DDP") == "torch" else \
@@ -409,7 +414,13 @@ def main():
         else:
             why = ""
             try:
-                comm = ddp.RcclComm()
+                if rehearsal:
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                    import standin_comm
+                    comm = standin_comm.ShmComm(standin_comm.load(), "/rv_bench_%s" % os.environ.get("MASTER_PORT", "0"),
+                                                world, rank, (eng.n_params + 8192) * 4)
+                else:
+                    comm = ddp.RcclComm()
                 comm.self_test(dev)
                 ok = True
             except Exception as exc:
@@ -749,6 +760,8 @@ def main():
             **({"replicas_consistent": replicas_consistent} if replicas_consistent is not None else {}),
             **({"native_fallback_reason": native_fallback_reason, "startup_check": startup_check,
                 "rccl_version": getattr(comm, "version", None), "rccl_ranks": getattr(comm, "rccl_count", None),
+                **({"rehearsal": "stand-in collectives through shared memory (tools/fake_collective.hip): the flow, not a measurement"}
+                   if rehearsal else {}),
                 "comm_stream_pick": [{"us_per_round_trip": u, "candidates_tried": n} for u, n in ddp.comm_stream_report()]}
                if use_ddp else {}),
             "step_tflops": value * flops_per_frame(S, H, L) / 1e12,

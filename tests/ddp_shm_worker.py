@@ -29,21 +29,8 @@ from rawaudiovae_kelsey_amd.engine import TrainEngine  # noqa: E402
 from rawaudiovae_kelsey_amd.synth import make_frames, make_params  # noqa: E402
 
 
-class ShmComm:
-    def __init__(self, lib, name, world, rank, cap):
-        lib.shm_comm_create.restype = C.c_void_p
-        lib.shm_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
-        lib.shm_comm_destroy.argtypes = [C.c_void_p]
-        h = lib.shm_comm_create(name.encode(), world, rank, cap)
-        if not h:
-            raise RuntimeError("shm_comm_create failed")
-        self._lib, self.handle, self.world, self.rank = lib, C.c_void_p(h), world, rank
-        self.allreduce_addr = C.cast(lib.shm_allreduce, C.c_void_p)
-        self.reduce_scatter_addr = C.cast(lib.shm_reduce_scatter, C.c_void_p)
-        self.all_gather_addr = C.cast(lib.shm_all_gather, C.c_void_p)
-
-    def destroy(self):
-        self._lib.shm_comm_destroy(self.handle)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from standin_comm import ShmComm  # noqa: E402  (the functional stand-in communicator, shared with bench.py's rehearsal)
 
 
 def agree(flag):

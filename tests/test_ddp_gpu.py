@@ -37,6 +37,28 @@ def test_two_rank_bench_flow_keeps_replicas_identical():
     assert "cpu_baseline" not in out          # reported at N=1 only
 
 
+def test_two_rank_bench_flow_with_the_library_driven_step_through_standins():
+    """The N > 1 branch of bench.py AS THE DRIVER WILL RUN IT -- communicator, startup check against the torch.distributed
+    route, the library-driven all-reduce step with its deferred tail, the flush that ends a timed pass, the fp32-payload
+    side line on the same engine, the replica check, the JSON line -- with two ranks on this one GPU: RCCL refuses that,
+    so the collectives are the functional stand-ins (RV_DDP_REHEARSAL=shm).  A rehearsal of the flow, not a measurement."""
+    env = dict(os.environ, RV_DIST_BACKEND="gloo", RV_DDP_REHEARSAL="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(REPO, "bench.py"),
+           "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
+    assert out["native_fallback_reason"] is None, out["native_fallback_reason"]
+    assert "replicas identical" in out["startup_check"], out["startup_check"]
+    assert out["config"]["ddp_mode"] == "allreduce" and out["config"]["ddp_payload"] == "bf16"
+    assert "behind the next step's cast" in out["config"]["grad_allreduce"]      # the deferred tail is what was timed
+    assert out["replicas_consistent"] is True and "rehearsal" in out
+    assert out["alt_fp32_payload"]["ms_per_step"] > 0
+    assert out["value"] > 0 and 0 < out["final_loss"] < 1
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_native_ddp_step_two_processes_one_gpu(world):
     """`rv_plan_step_ddp` with world = 2 and 4 (every rank a process of its own on this one GPU): RCCL refuses two ranks on a

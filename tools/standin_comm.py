@@ -1,0 +1,41 @@
+"""Communicator objects over the stand-in collectives of tools/fake_collective.hip (tools/libfakecoll.so), for
+rehearsals on ONE GPU -- never on the product path.
+
+`ShmComm`: the FUNCTIONAL stand-ins (`shm_allreduce` / `shm_reduce_scatter` / `shm_all_gather`: RCCL's C signatures, a
+real exchange between processes through shared memory and the host).  It quacks like `ddp.RcclComm` as far as
+`TrainEngine.attach_comm` / `ddp.NativeDdpRunner` / `bench.py` look: `handle`, `world`, `rank`, the three `*_addr`,
+`self_test`, `destroy`.  Used by tests/ddp_shm_worker.py and by `bench.py` under RV_DDP_REHEARSAL=shm (the N > 1 branch of
+the bench with the library-driven step, which RCCL itself cannot run on a one-GPU box: it refuses two ranks on a device).
+"""
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfakecoll.so")
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("tools/libfakecoll.so missing: __graft_entry__.build() compiles it")
+    return C.CDLL(LIB_PATH)
+
+
+class ShmComm:
+    def __init__(self, lib, name, world, rank, cap):
+        lib.shm_comm_create.restype = C.c_void_p
+        lib.shm_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+        lib.shm_comm_destroy.argtypes = [C.c_void_p]
+        h = lib.shm_comm_create(name.encode(), world, rank, cap)
+        if not h:
+            raise RuntimeError("shm_comm_create failed")
+        self._lib, self.handle, self.world, self.rank = lib, C.c_void_p(h), world, rank
+        self.allreduce_addr = C.cast(lib.shm_allreduce, C.c_void_p)
+        self.reduce_scatter_addr = C.cast(lib.shm_reduce_scatter, C.c_void_p)
+        self.all_gather_addr = C.cast(lib.shm_all_gather, C.c_void_p)
+
+    def self_test(self, device=None):
+        """(RcclComm's interface; the exchange itself is exercised by the caller's first step)"""
+
+    def destroy(self):
+        if self.handle:
+            self._lib.shm_comm_destroy(self.handle)
+            self.handle = None
