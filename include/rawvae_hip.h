@@ -545,7 +545,8 @@ enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_RO
        RV_OPT_DDP_DEFER_TAIL = 9 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Enqueue what a data-parallel step left to "the next call" (RV_OPT_DDP_DEFER_TAIL): the wait for the second exchange
- * and the update behind it, on the stream the step was enqueued on.  No-op when nothing is pending. */
+ * and the update behind it -- always on the stream that step was enqueued on (`stream`: that stream, or NULL; anything
+ * else is RV_ERR_STATE, as is a following rv_plan_step_ddp on another stream).  No-op when nothing is pending. */
 int rv_plan_ddp_flush(rv_plan*, void* stream);
 /* Gradients from outside for the following BWD / FINALIZE phases (the autograd boundary of rawvae.model.VAE.forward:
  * any loss, not only loss_function).  d_recon [B,S] with recon [B,S] (the forward's output, for tanh'), dmu and

@@ -132,6 +132,7 @@ struct rv_plan {
   // has nothing else to do while the exchange is on the links.  tail_*: what the deferred half needs from its step.
   int ddp_defer = 0, tail_pending = 0, tail_seq = 0;
   float tail_lr = 0.f, tail_scale = 1.f;
+  void* tail_stream = nullptr;   // the stream the deferring step was enqueued on: its other half goes there and nowhere else
   int cast_done = 0;           // the forward's cast launch went out ahead of its phase (ddp_finish_tail's caller)
   int s_w1_ddp = 1;            // split-K of fc1's weight gradient in the data-parallel step (RV_OPT_DDP_W1_WIDE)
   int ddp_w1_wide = 0;
@@ -631,7 +632,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                  unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step: plan not bound");
   if (p->tail_pending) {   // a data-parallel step left its last update to "the next call": this is it
-    const int frc = rv_plan_ddp_flush(p, stream);
+    const int frc = rv_plan_ddp_flush(p, nullptr);   // (on the stream that step was enqueued on)
     if (frc) return frc;
   }
   WtScope wt_scope;
@@ -1055,7 +1056,8 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
 // The deferred half of an all-reduce step (RV_OPT_DDP_DEFER_TAIL): wait for the second exchange, update its bucket.
 // The step number comes from the copy edge 1's flag kernel latched (ddp_flags[16..17]): the device counter itself may
 // already have been bumped by the next step's cast launch.
-static int ddp_finish_tail(rv_plan* p, void* stream) {
+static int ddp_finish_tail(rv_plan* p) {
+  void* stream = p->tail_stream;
   int* fl = (int*)p->ws("ddp_flags");
   int rc = rv_flag_wait(fl + 3, p->tail_seq, fl + 8, p->ddp_wait_ms, stream);
   if (rc) return rc;
@@ -1069,9 +1071,10 @@ static int ddp_finish_tail(rv_plan* p, void* stream) {
 int rv_plan_ddp_flush(rv_plan* p, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_ddp_flush: plan not bound");
   if (!p->tail_pending) return RV_OK;
-  RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_ddp_flush: needs the stream the step was enqueued on");
+  RV_REQUIRE(!stream || stream == p->tail_stream, RV_ERR_STATE,
+             "rv_plan_ddp_flush: the deferred half of a step belongs on the stream that step was enqueued on (pass it, or NULL)");
   WtScope wt_scope;
-  return ddp_finish_tail(p, stream);
+  return ddp_finish_tail(p);
 }
 
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
@@ -1085,12 +1088,14 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     // the previous step's deferred half: this step's cast first (it reads x and writes the bf16 frames, nothing else --
     // fc1's weight gradient, the frames' last reader, is long done), then the wait for the exchange and the update
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step_ddp: x is null");
+    RV_REQUIRE(stream == p->tail_stream, RV_ERR_STATE,
+               "rv_plan_step_ddp: the previous step deferred its last update on another stream (rv_plan_ddp_flush it first)");
     if (!p->reduce_scatter && !p->fp8 && !(p->skip & 1)) {
       const int crc = rv_cast_pad_bf16(x, p->B, p->S, p->S, p->ws("xb"), p->Bp, p->Sp, p->Sp, p->b.step_counter, stream);
       if (crc) return crc;
       p->cast_done = 1;
     }
-    const int frc = ddp_finish_tail(p, stream);
+    const int frc = ddp_finish_tail(p);
     if (frc) { p->cast_done = 0; return frc; }
   }
   if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
@@ -1226,7 +1231,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_TRY(adam_bucket(8, 2));                               // update runs while the second exchange is on the links
   if (flags && p->ddp_defer && !p->fp8) {
     // the join and the last update wait for the next call (or rv_plan_ddp_flush): see RV_OPT_DDP_DEFER_TAIL
-    p->tail_pending = 1; p->tail_seq = seq; p->tail_lr = lr; p->tail_scale = scale;
+    p->tail_pending = 1; p->tail_seq = seq; p->tail_lr = lr; p->tail_scale = scale; p->tail_stream = stream;
     return RV_OK;
   }
   RV_TRY(await(3, s0));                                    // the join

@@ -464,8 +464,7 @@ class TrainEngine:
         """Enqueue what a deferred `step_ddp` left over (no-op when nothing is pending), on that step's stream."""
         if getattr(self, "_plan", None) is None or not hasattr(self, "_ddp_stream"):
             return
-        st = stream if stream is not None else self._ddp_stream
-        lib().rv_plan_ddp_flush(self._plan, stream_ptr(st))
+        lib().rv_plan_ddp_flush(self._plan, stream_ptr(stream) if stream is not None else None)
 
     def _pick_comm_stream(self, stream):
         """The collectives' stream is chosen per compute stream by measurement (ddp.pick_comm_stream: two streams
