@@ -15,7 +15,8 @@ overlap S/hop-fold, so the unique bytes are 1/8 of the framed batch at hop 128.
 
 wav I/O uses scipy (librosa / soundfile / torchaudio are not available here): PCM is scaled to
 [-1, 1] float32; `librosa.load(sr=...)`'s mono mix-down (mean of channels) and resampling
-(polyphase here, not librosa's soxr) are restated.
+(polyphase here, not librosa's soxr) are restated; the streaming path's `torchaudio.functional.resample` is restated from
+its published algorithm (`_resample_sinc_hann`).
 """
 import itertools
 import random
@@ -55,6 +56,50 @@ def _resample(a, sr_in, sr_out):
     return resample_poly(a, sr_out // g, sr_in // g).astype(np.float32)
 
 
+def _resample_sinc_hann(a, sr_in, sr_out, lowpass_filter_width=6, rolloff=0.99, chunk=1 << 18):
+    """`torchaudio.functional.resample(waveform, orig_freq, new_freq)` with its defaults (resampling_method
+    "sinc_interp_hann", lowpass_filter_width 6, rolloff 0.99), the call of dataset.py:50-51, restated from the
+    published algorithm of torchaudio 2.x (`torchaudio/functional/functional.py`: `_get_sinc_resample_kernel` +
+    `_apply_sinc_resample_kernel`) -- torchaudio is not installed here, so no fixture pins this ("parity unpinned",
+    DESIGN.md section 4; tests check it against the interpolation formula it implements).  With orig / new the two rates
+    over their gcd: a bank of `new` Hann-windowed sinc filters of 2 * width + orig taps, cut-off rolloff * min(orig, new)
+    / 2, applied with stride orig to the signal padded by (width, width + orig) zeros; output j * new + i is filter i at
+    input frame j; ceil(new * n / orig) samples are kept.  The filter bank is evaluated in float64 and rounded to
+    float32, the convolution runs in float32, as torchaudio's does."""
+    import math
+    g = math.gcd(int(sr_in), int(sr_out))
+    orig, new = int(sr_in) // g, int(sr_out) // g
+    if orig == new:
+        return a
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    # (torch divides the int64 phase indices by new_freq in float32 before they meet the float64 tap positions)
+    t = (np.arange(0, -new, -1).astype(np.float32) / np.float32(new)).astype(np.float64)[:, None] + idx
+    t *= base
+    np.clip(t, -lowpass_filter_width, lowpass_filter_width, out=t)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    with np.errstate(divide="ignore", invalid="ignore"):
+        kernels = np.where(t == 0, 1.0, np.sin(t) / t)
+    kernels = (kernels * window * (base / orig)).astype(np.float32)          # [new, 2 * width + orig]
+    taps = kernels.shape[1]
+    n = len(a)
+    x = np.zeros(n + 2 * width + orig, np.float32)
+    x[width:width + n] = a
+    n_frames = (len(x) - taps) // orig + 1
+    out = np.empty((n_frames, new), np.float32)
+    kt = np.ascontiguousarray(kernels.T)
+    for f0 in range(0, n_frames, chunk):
+        f1 = min(n_frames, f0 + chunk)
+        seg = x[f0 * orig:(f1 - 1) * orig + taps]
+        frames = np.lib.stride_tricks.as_strided(seg, shape=(f1 - f0, taps), strides=(orig * seg.itemsize, seg.itemsize),
+                                                 writeable=False)
+        np.matmul(frames, kt, out=out[f0:f1])
+    target = int(math.ceil(new * n / orig))
+    return out.reshape(-1)[:target]
+
+
 def load_audio_mono(path, sampling_rate):
     """`librosa.load(path, sr=sampling_rate)` (train.py:120): mono float32 at `sampling_rate`."""
     a, sr = read_wav(path)
@@ -68,7 +113,7 @@ def load_audio_ch0(path, sampling_rate):
     a, sr = read_wav(path)
     if a.ndim == 2:
         a = np.ascontiguousarray(a[:, 0])
-    return _resample(a, sr, sampling_rate)
+    return _resample_sinc_hann(a, sr, sampling_rate)
 
 
 def write_wav(path, samples, sampling_rate):

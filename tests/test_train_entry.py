@@ -58,6 +58,45 @@ def _ini(tmp_path, iterable=False, **over):
     return p
 
 
+def test_streaming_resampler_is_the_windowed_sinc_interpolation_it_restates():
+    """`data._resample_sinc_hann` restates `torchaudio.functional.resample`'s published algorithm (dataset.py:50-51 calls it
+    with the defaults: sinc_interp_hann, width 6, rolloff 0.99).  torchaudio is absent, so this does NOT pin it to the
+    reference's output; it holds the filter-bank / strided-convolution form to the interpolation formula it implements,
+    evaluated directly in float64 at sampled output positions, for up- and down-sampling rate pairs, plus the output
+    length rule and a tone below both Nyquist rates."""
+    import math
+    from rawaudiovae_kelsey_amd import data as D
+
+    def direct(a, sr_in, sr_out, pos, lpw=6, rolloff=0.99):
+        g = math.gcd(sr_in, sr_out)
+        orig, new = sr_in // g, sr_out // g
+        base = min(orig, new) * rolloff
+        out = []
+        for m in pos:
+            t = np.clip((np.arange(len(a)) - m * orig / new) / orig * base, -lpw, lpw)
+            w = np.cos(t * math.pi / lpw / 2) ** 2
+            tt = t * math.pi
+            s = np.where(tt == 0, 1.0, np.sin(tt) / np.where(tt == 0, 1.0, tt))
+            out.append(float(np.sum(a * s * w) * base / orig))
+        return np.array(out)
+    rng = np.random.default_rng(0)
+    for si, so in [(48000, 44100), (44100, 22050), (22050, 44100), (32000, 44100), (44100, 16000)]:
+        a = rng.standard_normal(3000).astype(np.float32)
+        y = D._resample_sinc_hann(a, si, so)
+        g = math.gcd(si, so)
+        assert y.dtype == np.float32 and len(y) == math.ceil((so // g) * len(a) / (si // g))
+        pos = [0, 1, 2, 57, 500, len(y) // 2, len(y) - 3, len(y) - 1]
+        assert np.abs(y[pos] - direct(a.astype(np.float64), si, so, pos)).max() < 5e-6
+    tone = np.sin(2 * np.pi * 1000.0 * np.arange(48000) / 48000).astype(np.float32)
+    y = D._resample_sinc_hann(tone, 48000, 44100)
+    exp = np.sin(2 * np.pi * 1000.0 * np.arange(len(y)) / 44100)
+    assert np.abs(y[200:-200] - exp[200:-200]).max() < 2e-3
+    assert D._resample_sinc_hann(tone, 44100, 44100) is tone      # same rate: untouched
+    # a long signal goes through the chunked convolution with the same result as one piece
+    long_a = rng.standard_normal(200000).astype(np.float32)
+    assert np.array_equal(D._resample_sinc_hann(long_a, 48000, 44100, chunk=257), D._resample_sinc_hann(long_a, 48000, 44100))
+
+
 def test_wav_io_and_frame_count_host_logic(tmp_path):
     from rawaudiovae_kelsey_amd import data as D
     a = _sine_wav(tmp_path / "m.wav", 0.25, 8000, 200.0)
