@@ -1058,6 +1058,12 @@ static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float*
 // already have been bumped by the next step's cast launch.
 static int ddp_finish_tail(rv_plan* p) {
   void* stream = p->tail_stream;
+  {
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    RV_HIP(hipStreamIsCapturing((hipStream_t)stream, &cap0));
+    RV_REQUIRE(cap0 == hipStreamCaptureStatusNone, RV_ERR_STATE,
+               "a deferred data-parallel update cannot be enqueued into a stream capture (rv_plan_ddp_flush before capturing)");
+  }
   int* fl = (int*)p->ws("ddp_flags");
   int rc = rv_flag_wait(fl + 3, p->tail_seq, fl + 8, p->ddp_wait_ms, stream);
   if (rc) return rc;
@@ -1090,6 +1096,13 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
     RV_REQUIRE(x, RV_ERR_NULL, "rv_plan_step_ddp: x is null");
     RV_REQUIRE(stream == p->tail_stream, RV_ERR_STATE,
                "rv_plan_step_ddp: the previous step deferred its last update on another stream (rv_plan_ddp_flush it first)");
+    {
+      // a captured graph would re-apply the previous step's update on every replay
+      hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+      RV_HIP(hipStreamIsCapturing((hipStream_t)stream, &cap0));
+      RV_REQUIRE(cap0 == hipStreamCaptureStatusNone, RV_ERR_STATE,
+                 "rv_plan_step_ddp: a deferred update is pending and the stream is capturing (rv_plan_ddp_flush before the capture)");
+    }
     if (!p->reduce_scatter && !p->fp8 && !(p->skip & 1)) {
       const int crc = rv_cast_pad_bf16(x, p->B, p->S, p->S, p->ws("xb"), p->Bp, p->Sp, p->Sp, p->b.step_counter, stream);
       if (crc) return crc;
