@@ -101,22 +101,6 @@ int rv_decode_out_loss_fwd(const void* h3_bf16, long ldh, const void* w4_bf16, l
                            void* dP4_bf16, long ld_dp4, float* mse_partial, float* db4_partial,
                            void* stream);
 
-/* decode() in ONE launch (model.py:28-30): h3 = relu(z W3^T + b3) is GENERATED inside the fc4 forward, K tile by K
- * tile, from the block's rows of z [Bp,64] bf16 and 64-row slices of W3 [Hp,64] bf16 -- fc4's A operand never travels
- * through the CU's L2 -> LDS port (24 KB instead of 32 KB per K tile; the port bounds that launch), and no kernel streams
- * all of W3 through every CU.  Everything else as rv_decode_out_loss_fwd (128 x 128 tiles: n_mse_partials =
- * (Bp/128)*(Sp/128), db4_partial [Bp/128][Sp]).  h3_bf16 (optional) receives the generated operand, which the backward
- * needs (ReLU mask, fc4's weight gradient): bit-identical to rv_latent_fwd's h3.  Target frames: x [B,S] fp32 (ldx), or
- * -- audio != NULL -- hop-strided frames of a resident waveform as in the real-data step (frame r =
- * audio[f*hop : f*hop+S], f = frame_index ? frame_index[r] : first_frame + r).  Served shapes: padded latent width 64,
- * Bp and Sp multiples of 128, Hp a multiple of 256 up to 4096; RV_ERR_UNSUPPORTED otherwise. */
-int rv_decode_fc3_out_loss_fwd(const void* z_bf16, long ldz, const void* w3_bf16, long ldw3, const float* b3,
-                               void* h3_bf16, long ldh3, const void* w4_bf16, long ldw, const float* b4, long Bp,
-                               long Sp, long Hp, long Lp, long B, long S, const float* x, long ldx,
-                               const float* audio, long n_samples, const long long* frame_index, long first_frame,
-                               long hop, float* recon, long ld_recon, void* dP4_bf16, long ld_dp4,
-                               float* mse_partial, float* db4_partial, void* stream);
-
 /* dX = dY W (autograd of F.linear, train.py:191).  dy [Mp,Kp] bf16, w [Kp,Np] bf16
  * ([out,in] layout, consumed as-is through transposing LDS reads).
  *   mask != NULL : dx_bf16 = (mask > 0) ? dX : 0   (ReLU', threshold_backward) and
@@ -204,26 +188,12 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
  * layout are identical.  RV_ERR_UNSUPPORTED for other latent widths or a padded hidden width that is not a multiple
  * of 512 up to 2048.  18.8 us against 21-22 us for the three launches at C2 (profiles/r03_*): the training plan's
  * default where it applies (rv_plan_set_option, RV_OPT_LATENT_FUSED).
- * w3_bf16 == NULL: heads + reparameterisation only (bias3, h3_bf16 unused) -- fc3 then runs inside the fc4 forward
- * (rv_decode_fc3_out_loss_fwd) and this kernel streams 576 KB per CU instead of 832. */
+ * w3_bf16 == NULL: heads + reparameterisation only (bias3, h3_bf16 unused; 576 KB per CU instead of 832); fc3 is then
+ * the caller's (rv_linear_fwd). */
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                   float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* stream);
-
-/* rv_latent_fwd on PAIRS of workgroups: workgroups 2i and 2i + 1 share 32 batch rows and split the WEIGHTS -- each
- * contracts one K half of the heads GEMM and computes one half of fc3's output columns -- exchanging their 32 x 128 fp32
- * partial head sums through `xchg` inside the launch (write-through stores, a per-workgroup generation counter in `gen`,
- * sc1 loads; bounded wait, time-outs counted in *err, which must stay 0).  Half the weight bytes pass through every CU's
- * L2 -> LDS port, which is what bounds rv_latent_fwd (13-14 of its 18 us at C2).  Same outputs as rv_latent_fwd_ex up to
- * the fp32 summation order of the head sums (h3_fp8 / q_scale / amax_part: the fp8 forward's extras, NULL = not wanted).
- * xchg: (Bp / 16) x 4096 floats, gen: Bp / 16 ints, err: one int -- the caller's, zeroed once, not shared between
- * launches that may overlap.  RV_ERR_UNSUPPORTED unless Lp == 64, Hp is 1024 or 2048 and Bp a multiple of 32. */
-int rv_latent_fwd_pair(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
-                       const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
-                       const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
-                       float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
-                       const float* q_scale, float* amax_part, float* xchg, int* gen, int* err, void* stream);
 
 /* The backward mirror of rv_latent_fwd's first two steps in ONE launch (same shape limits): dz = dP3 W3 (autograd of
  * fc3's input, model.py:29) for 16 batch rows per workgroup over the full contraction, then rv_reparam_bwd's
@@ -514,16 +484,6 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     rv_plan_step_ddp read the count and apply no update while it is non-zero, so a partial all-reduce never reaches
  *     the parameters; the host side must read the count (it is never cleared on the device), agree on it across ranks
  *     and stop every rank.
- *   RV_OPT_LATENT_PAIR  1: where RV_OPT_LATENT_FUSED applies and the extents allow (hidden width 1024 or 2048, a padded
- *     batch that is a multiple of 32) the fused latent forward runs on pairs of workgroups that split the weights
- *     (rv_latent_fwd_pair; its exchange buffers are the workspace buffers "lat_xchg" / "lat_gen", whose last int counts
- *     hand-off time-outs and must stay 0); 0 (default): rv_latent_fwd, 16 rows per workgroup and all weights through
- *     every CU.  Opt-in because it measured SLOWER in the step at C2 (19.7-21.0 against 18.0-18.8 us, three interleaved
- *     pairs on one box): the in-launch hand-off costs what the halved weight stream saves.
- *   RV_OPT_FC3_IN_FC4  1: where RV_OPT_LATENT_FUSED applies, the operands are bf16 and rv_decode_fc3_out_loss_fwd serves
- *     the shape, fc3 runs INSIDE the fc4 forward (its A operand is generated tile by tile from z and W3) and the latent
- *     launch stops after the reparameterisation; 0: fc3 in the latent launch, h3 through HBM into fc4.  Same h3, bit
- *     for bit, hence the same step.
  *   RV_OPT_DDP_DEFER_TAIL  1: rv_plan_step_ddp (all-reduce schedule, device-side flags, bf16 operands) returns with its
  *     LAST wait -- second exchange done -- and the update of that bucket (fc1, heads, fc3) not yet enqueued; the next
  *     rv_plan_step_ddp call enqueues its own cast launch first (it needs no parameter, and the compute stream has nothing
@@ -541,7 +501,8 @@ int rv_plan_bind(rv_plan*, const rv_plan_buffers*);
  *     form whose time does not depend on it.  (With 0 and the fp32 payload a one-rank step reproduces rv_plan_step bit
  *     for bit; the sums over 4 and over 8 partial slabs round differently.) */
 enum { RV_OPT_LATENT_FUSED = 0, RV_OPT_FP8 = 1, RV_OPT_SLAB_DTYPE = 2, RV_OPT_ROCTX = 3, RV_OPT_DDP_SIGNAL = 4, RV_OPT_DDP_W1_WIDE = 5,
-       RV_OPT_DDP_WAIT_MS = 6, RV_OPT_LATENT_PAIR = 7, RV_OPT_FC3_IN_FC4 = 8,
+       RV_OPT_DDP_WAIT_MS = 6, /* 7, 8: retired in round 6 (the paired latent forward and fc3 inside the fc4 forward, both
+       measured slower in the step: DESIGN.md section 6, profiles/r05_latent_pair_ab.txt, r05_fc3_in_fc4.txt) */
        RV_OPT_DDP_DEFER_TAIL = 9 };
 int rv_plan_set_option(rv_plan*, int option, int value);
 /* Enqueue what a data-parallel step left to "the next call" (RV_OPT_DDP_DEFER_TAIL): the wait for the second exchange

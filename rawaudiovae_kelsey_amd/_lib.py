@@ -40,8 +40,6 @@ class CommDesc(C.Structure):
 
 
 OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE, OPT_DDP_WAIT_MS = 0, 1, 2, 3, 4, 5, 6
-OPT_LATENT_PAIR = 7
-OPT_FC3_IN_FC4 = 8
 OPT_DDP_DEFER_TAIL = 9
 PLAN_GEMM, PLAN_TILE, PLAN_PAIR = 0, 1, 2
 TILE_AUTO, SLAB_F32, SLAB_F16 = -1, 0, 1
@@ -102,13 +100,6 @@ _SIGS = {
     "rv_latent_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long,
                               c_long, c_long, c_long, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_long, c_void_p]),
-    "rv_decode_fc3_out_loss_fwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
-                                           c_void_p, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_long,
-                                           c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_long,
-                                           c_void_p, c_void_p, c_void_p]),
-    "rv_latent_fwd_pair": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long,
-                                   c_long, c_long, c_long, c_void_p, c_void_p, c_u64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rv_reparam_fwd": (c_int, [c_void_p, c_int, c_long, c_long, c_long, c_long, c_void_p, c_void_p,
                                c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rv_loss_fused_workspace_bytes": (c_long, []),

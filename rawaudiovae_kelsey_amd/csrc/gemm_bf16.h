@@ -95,17 +95,6 @@ struct GemmArgs {
   bf16_t* a_copy;
   long ld_copy;
   long long* step_inc;   // EPI_BIAS_ACT_BF16: block 0 bumps the device step counter (the step's first kernel does)
-  // A operand GENERATED inside the launch (gemm_body's A_GEN: fc3 folded into the fc4 forward, model.py:29-30):
-  //   A[m][k] = relu(sum_l gen_z[m][l] * gen_w[k][l] + gen_bias[k]),  l < 64 (the padded latent width),
-  // computed K tile by K tile from the block's 128 x 64 rows of z (held as register fragments) and 64 rows of W3 that
-  // travel in the ring in the A tile's place (8 KB instead of 16 KB per K tile through the CU's L2 -> LDS port), so `A`
-  // is unused.  The operand the backward needs later (h3) is a by-product: the block with tile_n == kt % tiles_n
-  // copies K tile kt of its rows from LDS to a_copy / ld_copy, as the gathered operand above does.
-  const bf16_t* gen_z;
-  long gen_ldz;
-  const bf16_t* gen_w;
-  long gen_ldw;
-  const float* gen_bias;   // [K] fp32, K a multiple of 256
   int wt;                // non-zero: the epilogue's outputs are written through (common.h store_wt16; the launchers copy rv_store_wt)
 };
 
@@ -489,19 +478,13 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 //     before its consumer, and the DMA refill has NSTAGE-1 tiles of MFMA time to land.
 // The barrier publishes every wave's share of tile kt+1 and orders the refill after all
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
-template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false, bool A_GEN = false>
+template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
   static_assert(!FP8 || NSTAGE == 8 || (A_KMAJ && B_KMAJ), "fp8 operands: K-major (forward) GEMMs on the ring loop, any layout on the ping-pong loop");
-  static_assert(!A_GEN || (A_KMAJ && B_KMAJ && !FP8 && NSTAGE >= 3 && NSTAGE <= 5 && BM == 128 && WGM == 2 && WGN == 4 && EPI == EPI_TANH_LOSS),
-                "generated A operand: the fc4 forward on 128-row tiles, 2 x 4 waves, ring loop");
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
-  // A_GEN: a ring stage holds the B tile and 64 rows of the generator's weight (W_BYTES) instead of an A tile; the two
-  // A images the loop alternates between, the first weight slice and the generator's bias sit behind the ring
-  constexpr int W_BYTES = A_GEN ? 64 * 128 : 0;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_GEN ? B_BYTES + W_BYTES : A_BYTES + B_BYTES;
-  constexpr int B_OFF = A_GEN ? 0 : A_BYTES;             // the B image inside a stage
-  constexpr int G_ABUF = NSTAGE * STAGE, G_W0 = G_ABUF + 2 * A_BYTES, G_BIAS = G_W0 + W_BYTES;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int B_OFF = A_BYTES;             // the B image inside a stage
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
   constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
   constexpr bool PINGPONG = NSTAGE == 8;    // 256x256 ping-pong main loop (2 LDS buffers)
@@ -635,7 +618,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
-  StageOffsets<64, true, NW> sw;      // A_GEN: 64 rows of the generator's weight = one 1-KiB piece per wave
   const bf16_t* Agr = Ag;
   bool gathered = false;
   if constexpr (A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) {
@@ -650,13 +632,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
     if (p.step_inc && bid == 0 && tid == 0) *p.step_inc += 1;
   }
-  if (!gathered) sa.init(A_GEN ? p.gen_ldz : p.lda, wave, lane);   // A_GEN: `sa` stages the block's rows of z, once
+  if (!gathered) sa.init(p.lda, wave, lane);
   sb.init(p.ldb, wave, lane);
-  if constexpr (A_GEN) sw.init(p.gen_ldw, wave, lane);
-  // by-product of the gathered / generated operand: K tile kt of this block's rows, from its LDS image to HBM
+  // by-product of the gathered operand: K tile kt of this block's rows, from its LDS image to HBM
   auto copy_out = [&](int kt, const lds_char* slot_) {
-    if constexpr ((A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) || A_GEN) {
-      if ((gathered || A_GEN) && p.a_copy && kt % tiles_n == tile_n) {
+    if constexpr (A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) {
+      if (gathered && p.a_copy && kt % tiles_n == tile_n) {
 #pragma unroll
         for (int i = 0; i < StageOffsets<BM, A_KMAJ, NW>::PER_WAVE; ++i) {
           const int t = wave + NW * i;
@@ -669,105 +650,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   };
 
   const int nk = p.k_tiles;
-  // ---- A_GEN: the generator.  Wave (wm, wn) produces rows wm*64 .. +64 (its own A rows) x columns wn*16 .. +16 of
-  // every 128 x 64 A tile: 4 row fragments x 2 MFMAs (the latent width is 64 = two 32-deep steps) against its 16 rows of
-  // the weight slice, with the operands in k_latent_fwd's order (weight fragment first), so that lane (q, j) owns row j
-  // and the four CONSECUTIVE k = 4 q .. 4 q + 3 of the fragment: bias, bf16, ReLU and one 8-byte LDS store into the
-  // K-major image the A fragments are read from (same values as rv_latent_fwd's h3, bit for bit).
-  // Schedule -- a whole tile ahead, all of it inside SECOND halves, where the tile's own MFMAs (on fragments that are
-  // already in registers) hide the generator's LDS round trip and its VALU work sits in their issue gaps (weight slice
-  // t + 1 travels with B tile t in ring stage t):
-  //     second half of tile t   : slice t+2 (stage t+1 landed: hand-off of tile t) -> 8 MFMAs -> A tile t+2 -> LDS image
-  //                               t&1, whose previous tenant (tile t) was last read in the first half of tile t
-  //     hand-off of tile t+1    : publishes it (this wave's stores have had a whole first half to land)
-  //     second half of tile t+1 : the A fragments of tile t+2 are read from that image
-  bf16x8 zf[A_GEN ? MI : 1][2], wf[2];
-  f32x4 gbias;
-  f32x4 gacc[A_GEN ? MI : 1];
-  lds_char* const abuf = smem + G_ABUF;
-  auto gen_read = [&](const lds_char* wslice, int t) {   // weight fragments + bias of A tile t
-    if constexpr (A_GEN) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf[kk] = load_frag<64, true>(wslice, wn * 16, kk, lane);
-      gbias = *(const __attribute__((address_space(3))) f32x4*)(smem + G_BIAS + (t * 64 + wn * 16 + 4 * (lane >> 4)) * 4);
-    }
-  };
-  auto gen_mfma = [&](int kk) {
-    if constexpr (A_GEN) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        gacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk], zf[mi][kk], kk ? gacc[mi] : f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    }
-  };
-  // bias (packed fp32 adds), bf16, ReLU on the PACKED bf16 pairs as a signed 16-bit max against 0 (a bf16 is negative
-  // iff its bit pattern is a negative int16; -0 becomes +0 as v_max_f32 makes it): 6 VALU instructions per fragment
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  typedef short s16x2_ __attribute__((ext_vector_type(2)));
-  auto gen_pack = [&](int mi) -> bf16x4 {
-    const f32x2_ lo = f32x2_{gacc[mi][0], gacc[mi][1]} + f32x2_{gbias[0], gbias[1]};
-    const f32x2_ hi = f32x2_{gacc[mi][2], gacc[mi][3]} + f32x2_{gbias[2], gbias[3]};
-    const bf16x2 l2 = __builtin_convertvector(lo, bf16x2), h2 = __builtin_convertvector(hi, bf16x2);   // v_cvt_pk_bf16_f32
-    const s16x2_ lr = __builtin_elementwise_max(__builtin_bit_cast(s16x2_, l2), s16x2_{0, 0});
-    const s16x2_ hr = __builtin_elementwise_max(__builtin_bit_cast(s16x2_, h2), s16x2_{0, 0});
-    const s16x4 o = {lr[0], lr[1], hr[0], hr[1]};
-    return __builtin_bit_cast(bf16x4, o);
-  };
-  auto gen_store = [&](lds_char* img, int mi, const bf16x4 o) {
-    const int q_ = lane >> 4, r = wm * WTM + mi * 16 + (lane & 15);
-    const int c = (wn * 2 + (q_ >> 1)) ^ ((r >> 1) & 7);
-    *(__attribute__((address_space(3))) bf16x4*)(img + r * 128 + c * 16 + (q_ & 1) * 8) = o;
-  };
-  auto gen_tile = [&](const lds_char* wslice, int t, lds_char* img) {   // unpipelined (the prologue's two tiles)
-    if constexpr (A_GEN) {
-      gen_read(wslice, t);
-      gen_mfma(0);
-      gen_mfma(1);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) gen_store(img, mi, gen_pack(mi));
-    }
-  };
-
-  if constexpr (A_GEN) {
-    // oldest entries of the vmcnt queue: the generator's bias (1-KiB pieces dealt over the waves), the block's rows
-    // of z (into A image 1, free until A tile 1 is generated below) and weight slice 0
-    for (int i = wave; i < nk / 4; i += NW)
-      __builtin_amdgcn_global_load_lds((glb_cptr)(p.gen_bias + i * 256 + lane * 4),
-                                       (__attribute__((address_space(3))) void*)(smem + G_BIAS + i * 1024), 16, 0, 0);
-    sa.stage(p.gen_z + m0 * p.gen_ldz, abuf + A_BYTES, wave);
-    sw.stage(p.gen_w, smem + G_W0, wave);
-  }
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < nk) {
-      if constexpr (A_GEN) {
-        const int ws = s + 1 < nk ? s + 1 : nk - 1;   // (the last stage carries a slice nobody reads)
-        sw.stage(p.gen_w + (long)ws * 64 * p.gen_ldw, smem + s * STAGE + B_BYTES, wave);
-      } else {
-        sa.stage(Agr + s * a_step, smem + s * STAGE, wave);
-      }
+      sa.stage(Agr + s * a_step, smem + s * STAGE, wave);
       sb.stage(Bg + s * b_step, smem + s * STAGE + B_OFF, wave);
     }
-  if constexpr (A_GEN) {
-    // everything older than the ring has landed (nk >= NSTAGE: the launcher's condition), for every wave
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE * GL) : "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) zf[mi][kk] = load_frag<BM, true>(abuf + A_BYTES, wm * WTM + mi * 16, kk, lane);
-    gen_tile(smem + G_W0, 0, abuf);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A tile 0 written, the z fragments are in registers
-  }
   // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
   wait_tiles_in_flight<GL>(nk - 1 < NSTAGE - 1 ? nk - 1 : NSTAGE - 1);
   __builtin_amdgcn_s_barrier();
-  // A tile 1 from slice 1 (came with stage 0) into image 1: every wave has its z fragments (barrier above); published
-  // by the hand-off of tile 0
-  if constexpr (A_GEN) gen_tile(smem + B_BYTES, nk > 1 ? 1 : 0, abuf + A_BYTES);
 
   bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(A_GEN ? abuf : smem, wm * WTM + mi * 16, 0, lane);
+  for (int mi = 0; mi < MI; ++mi) a0[mi] = load_frag<BM, A_KMAJ>(smem, wm * WTM + mi * 16, 0, lane);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) b0[ni] = load_frag<BN, B_KMAJ>(smem + B_OFF, wn * WTN + ni * 16, 0, lane);
 
@@ -778,10 +673,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // First half of tile kt: MFMAs on (a0, b0) with the reads of (a1, b1) slotted between them
   // (one MFMA first: its operands were loaded across the loop back-edge, and the lgkmcnt(0) the
   // compiler puts in front of it must not also drain the reads issued in this half).
-  // `aimg`: where tile kt's A image lives (the ring stage, or one of A_GEN's two images)
-  auto first_half = [&](const lds_char* cur, const lds_char* aimg) {
+  auto first_half = [&](const lds_char* cur) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a1[mi] = load_frag<BM, A_KMAJ>(aimg, wm * WTM + mi * 16, 1, lane);
+    for (int mi = 0; mi < MI; ++mi) a1[mi] = load_frag<BM, A_KMAJ>(cur, wm * WTM + mi * 16, 1, lane);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b1[ni] = load_frag<BN, B_KMAJ>(cur + B_OFF, wn * WTN + ni * 16, 1, lane);
     if constexpr (!FP8) {
@@ -808,18 +702,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // Second half of tile kt, entered right after the mid-tile barrier: the LDS-DMA refill of the
   // vacated slot and the first-half fragment reads of tile kt+1 are slotted between the MFMAs on
   // (a1, b1), so the matrix pipe restarts immediately after the barrier.
-  // `gen_c` (A_GEN): also generate A tile kt + 2 (see the schedule above)
-  auto second_half = [&](auto refill_c, auto next_c, auto gen_c, int kt, int slot, int nslot) {
-    constexpr bool REFILL = decltype(refill_c)::value, NEXT = decltype(next_c)::value, GEN = decltype(gen_c)::value;
-    if constexpr (GEN) gen_read(smem + nslot * STAGE + B_BYTES, kt + 2);   // first in the LDS queue: first to return
+  auto second_half = [&](auto refill_c, auto next_c, int kt, int slot, int nslot) {
+    constexpr bool REFILL = decltype(refill_c)::value, NEXT = decltype(next_c)::value;
     if constexpr (REFILL) {
       lds_char* rf = smem + slot * STAGE;
-      if constexpr (A_GEN) {
-        const int ws = kt + NSTAGE + 1 < nk ? kt + NSTAGE + 1 : nk - 1;
-        sw.stage(p.gen_w + (long)ws * 64 * p.gen_ldw, rf + B_BYTES, wave);
-      } else {
-        sa.stage(Agr + (long)(kt + NSTAGE) * a_step, rf, wave);
-      }
+      sa.stage(Agr + (long)(kt + NSTAGE) * a_step, rf, wave);
       sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + B_OFF, wave);
     }
     // fp8: this tile's first-half fragments are still needed by the MFMAs below, so the next tile's go to a
@@ -827,10 +714,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     bf16x8 a0n[FP8 ? MI : 1], b0n[FP8 ? NI : 1];
     if constexpr (NEXT) {
       const lds_char* nxt = smem + nslot * STAGE;
-      const lds_char* nxa = A_GEN ? abuf + ((kt + 1) & 1) * A_BYTES : nxt;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const bf16x8 f = load_frag<BM, A_KMAJ>(nxa, wm * WTM + mi * 16, 0, lane);
+        const bf16x8 f = load_frag<BM, A_KMAJ>(nxt, wm * WTM + mi * 16, 0, lane);
         if constexpr (FP8) a0n[mi] = f; else a0[mi] = f;
       }
 #pragma unroll
@@ -839,27 +725,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         if constexpr (FP8) b0n[ni] = f; else b0[ni] = f;
       }
     }
-    if constexpr (GEN) {
-      // issue order, pinned piece by piece: the staging and every LDS read first (the generator's three lead the
-      // queue), two of the tile's own MFMAs while those return, the generator's eight, then the other six of the tile's
-      // own with one fragment's bias / bf16 / ReLU / LDS store (7 instructions) in each of the first four gaps
-      static_assert(MI == 4 && NI == 2, "generator interleave: 8 MFMAs per half");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i >> 1][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[i & 1], a1[i >> 1], acc[i >> 1][i & 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      gen_mfma(0);
-      gen_mfma(1);
-      __builtin_amdgcn_sched_barrier(0);
-      lds_char* img = abuf + (kt & 1) * A_BYTES;
-#pragma unroll
-      for (int i = 4; i < 8; ++i) {
-        acc[i >> 1][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[i & 1], a1[i >> 1], acc[i >> 1][i & 1], 0, 0, 0);
-        gen_store(img, i - 4, gen_pack(i - 4));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -888,7 +753,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     }
-    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -900,7 +764,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a1[mi]));
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(b1[ni]));
-    if constexpr (A_GEN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the generated tile's LDS stores too
     wait_tiles_in_flight<GL>(newer);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -908,33 +771,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
-  using G_ = std::integral_constant<bool, A_GEN>;
-  auto aimg_of = [&](int kt, int slot) -> lds_char* { return A_GEN ? abuf + (kt & 1) * A_BYTES : smem + slot * STAGE; };
   int slot = 0;  // ring slot of tile kt
   int kt = 0;
   // steady state: a refill is issued every tile
   for (; kt + NSTAGE < nk; ++kt) {
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    copy_out(kt, aimg_of(kt, slot));
-    first_half(smem + slot * STAGE, aimg_of(kt, slot));
+    copy_out(kt, smem + slot * STAGE);
+    first_half(smem + slot * STAGE);
     hand_off(NSTAGE - 2);
-    second_half(T_{}, T_{}, G_{}, kt, slot, nslot);
+    second_half(T_{}, T_{}, kt, slot, nslot);
     slot = nslot;
   }
   // drain: tiles already staged, nothing left to prefetch
   for (; kt + 1 < nk; ++kt) {
     const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    copy_out(kt, aimg_of(kt, slot));
-    first_half(smem + slot * STAGE, aimg_of(kt, slot));
+    copy_out(kt, smem + slot * STAGE);
+    first_half(smem + slot * STAGE);
     hand_off(nk - 2 - kt < NSTAGE - 2 ? nk - 2 - kt : NSTAGE - 2);
-    if (A_GEN && kt + 2 < nk) second_half(F_{}, T_{}, G_{}, kt, slot, nslot);
-    else second_half(F_{}, T_{}, F_{}, kt, slot, nslot);
+    second_half(F_{}, T_{}, kt, slot, nslot);
     slot = nslot;
   }
   // last tile
-  copy_out(kt, aimg_of(kt, slot));
-  first_half(smem + slot * STAGE, aimg_of(kt, slot));
-  second_half(F_{}, F_{}, F_{}, kt, slot, slot);
+  copy_out(kt, smem + slot * STAGE);
+  first_half(smem + slot * STAGE);
+  second_half(F_{}, F_{}, kt, slot, slot);
   }
   __syncthreads();  // every wave is done with the ring before the epilogue's reductions reuse LDS
   // ------------------------------ epilogue ------------------------------
@@ -1280,13 +1140,6 @@ template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, i
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   gemm_body<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI, NSTAGE, FP8>(p, blockIdx.x, smem_dyn);
-}
-
-// The fc4 forward with fc3 folded in (GemmArgs::gen_*): 128 x 128 tiles, A generated tile by tile.
-template <int NSTAGE>
-__global__ void __launch_bounds__(512) gemm_fc34_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  gemm_body<128, 128, 2, 4, true, true, EPI_TANH_LOSS, NSTAGE, false, true>(p, blockIdx.x, smem_dyn);
 }
 
 // Two independent GEMMs in ONE launch (blocks [0, n_first) run the first): neither of the

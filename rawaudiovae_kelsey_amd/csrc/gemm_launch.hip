@@ -456,63 +456,6 @@ int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long
   return launch_auto<true, true, EPI_TANH_LOSS>(a, Bp, Sp, Hp, 1, (hipStream_t)stream);
 }
 
-// The fc4 forward with fc3 INSIDE it (model.py:29-30 in one launch): the A operand h3 = relu(z W3^T + b3) is generated
-// K tile by K tile from the block's rows of z and 64-row slices of W3 (gemm_bf16.h, A_GEN) instead of being staged from
-// HBM -- 24 KB instead of 32 KB per K tile through each CU's L2 -> LDS port -- and rv_latent_fwd no longer streams W3
-// through every CU.  h3 (the backward's ReLU mask and fc4's weight-gradient operand) is written as a by-product,
-// bit-identical to rv_latent_fwd's.  Target frames: x / ldx, or (audio != NULL) hop-strided frames of the resident
-// waveform as in rv_decode_out_loss_fwd_frames.
-int rv_decode_fc3_out_loss_fwd_fits(long Bp, long Sp, long Hp, long Lp) {
-  return Lp == 64 && Bp % 128 == 0 && Sp % 128 == 0 && Hp % 256 == 0 && Hp >= 256 && Hp <= 4096;
-}
-
-int rv_decode_fc3_out_loss_fwd(const void* z, long ldz, const void* w3, long ldw3, const float* b3, void* h3, long ldh3,
-                               const void* w4, long ldw, const float* b4, long Bp, long Sp, long Hp, long Lp, long B, long S,
-                               const float* x, long ldx, const float* audio, long n_samples, const long long* frame_index,
-                               long first_frame, long hop, float* recon, long ld_recon, void* dP4, long ld_dp4,
-                               float* mse_partial, float* db4_partial, void* stream) {
-  RV_REQUIRE(z && w3 && b3 && w4, RV_ERR_NULL, "rv_decode_fc3_out_loss_fwd: null operand");
-  RV_REQUIRE(rv_decode_fc3_out_loss_fwd_fits(Bp, Sp, Hp, Lp), RV_ERR_UNSUPPORTED,
-             "rv_decode_fc3_out_loss_fwd: needs a padded latent width of 64, 128-multiples of rows and columns and a hidden "
-             "width that is a multiple of 256 up to 4096 (got Bp %ld Sp %ld Hp %ld Lp %ld)", Bp, Sp, Hp, Lp);
-  RV_REQUIRE(B <= Bp && S <= Sp, RV_ERR_SHAPE, "rv_decode_fc3_out_loss_fwd: B,S exceed padded extents");
-  RV_REQUIRE(!(x || audio) || dP4, RV_ERR_NULL, "rv_decode_fc3_out_loss_fwd: target given without dP4 output");
-  RV_REQUIRE(!audio || (hop > 0 && n_samples > 0), RV_ERR_SHAPE, "rv_decode_fc3_out_loss_fwd: bad waveform extents");
-  RV_REQUIRE(ldz >= 64 && ldw3 >= 64 && ldz % 8 == 0 && ldw3 % 8 == 0 && ldw % 8 == 0 && ldw >= Hp &&
-                 (!h3 || (ldh3 >= Hp && ldh3 % 8 == 0)),
-             RV_ERR_SHAPE, "rv_decode_fc3_out_loss_fwd: leading dimensions");
-  RV_REQUIRE((((uintptr_t)z | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)w4 | (uintptr_t)h3) & 15) == 0, RV_ERR_SHAPE,
-             "rv_decode_fc3_out_loss_fwd: operands must be 16-byte aligned");
-  GemmArgs a{};
-  a.B = (const bf16_t*)w4; a.ldb = ldw; a.k_tiles = (int)(Hp / 64);
-  a.M_valid = (int)B; a.N_valid = (int)S; a.bias = b4;
-  if (audio) {
-    a.x = audio; a.ld_x = 0; a.x_idx = frame_index; a.x_first = first_frame; a.x_hop = hop; a.x_nsamples = n_samples;
-  } else {
-    a.x = x; a.ld_x = ldx;
-  }
-  a.recon = recon; a.ld_recon = ld_recon;
-  a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
-  a.scale = 2.0f / ((float)B * (float)S);
-  a.gen_z = (const bf16_t*)z; a.gen_ldz = ldz; a.gen_w = (const bf16_t*)w3; a.gen_ldw = ldw3; a.gen_bias = b3;
-  a.a_copy = (bf16_t*)h3; a.ld_copy = ldh3;
-  a.wt = rv_store_wt;
-  a.tiles_m = (int)(Bp / 128); a.tiles_n = (int)(Sp / 128); a.splits = 1;
-  constexpr int NST = 4;
-  // ring (B tile + weight slice per stage) + two A images + weight slice 0 + the generator's bias
-  const int smem = NST * (128 * 128 + 64 * 128) + 2 * 128 * 128 + 64 * 128 + (int)Hp * 4;
-  auto kern = gemm_fc34_kernel<NST>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NST * (128 * 128 + 64 * 128) + 2 * 128 * 128 + 64 * 128 + 4096 * 4);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), smem, (hipStream_t)stream, a);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
 int rv_linear_dgrad(const void* dy, long lddy, const void* w, long ldw, long Mp, long Np, long Kp,
                     const void* mask, long ldmask, void* dx, long lddx, float* colsum,
                     float* dx32, long lddx32, int splits, void* stream) {

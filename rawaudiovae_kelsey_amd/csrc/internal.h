@@ -62,10 +62,6 @@ RV_INTERNAL int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf
                                  const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
                                  float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
                                  const float* q_scale, float* amax_part, void* stream);
-// Whether rv_latent_fwd_pair (public header) applies to these padded extents.
-RV_INTERNAL int rv_latent_fwd_pair_fits(long Bp, long Hp, long Lp);
-// does rv_decode_fc3_out_loss_fwd serve this shape? (1 / 0)
-RV_INTERNAL int rv_decode_fc3_out_loss_fwd_fits(long Bp, long Sp, long Hp, long Lp);
 // Device-side cross-stream signalling (elementwise.hip): publish `value` behind the stream's earlier work / hold the
 // stream until the flag has reached `value` (bounded; timeouts are counted in *timeouts).
 RV_INTERNAL int rv_flag_set(int* flag, int value, void* stream);

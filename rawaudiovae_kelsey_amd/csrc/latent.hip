@@ -298,323 +298,6 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same forward for 32 batch rows per PAIR of workgroups (round 5).  k_latent_fwd is bound by what every CU has to
-// pull through its L2 -> LDS port (832 KB of weights per 16 rows at C2, ~14 of its 18 us), and a CU cannot take more rows
-// without more LDS.  Here workgroups 2i and 2i + 1 share rows [32 i, 32 i + 32) and split the WEIGHTS: workgroup h of the
-// pair contracts K half h of the heads GEMM (all 128 outputs, 32 rows) and later computes h3 columns [h Hp / 2, (h + 1)
-// Hp / 2) of fc3 -- 256 + 128 KB of weights and 64 KB of h1 per CU instead of 832 + 64.  In between, the two exchange their
-// 32 x 128 fp32 partial head sums (16 KB each way) through memory and BOTH finish mu, logvar, z for all 32 rows (a few
-// thousand flops; each writes the outputs of its own 16 rows), so fc3 needs no second hand-off.
-// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", valid form with sc1 stores and loads): every wave
-// writes its threads' share of the partial sums with 16-byte write-through stores (1 KiB = 8 whole lines per wave
-// instruction), waits vmcnt(0); workgroup barrier; ONE lane publishes gen[b] = g (g = this workgroup's own previous value
-// + 1: both partners count their launches, so no reset and no dependence on any other kernel's counter -- a replayed
-// hipGraph works); one lane polls gen[partner] with sc1 loads until it reaches g (bounded: ~100 ms, then `*err` counts it
-// and the step goes on with whatever is there -- the engine raises when it reads the count); barrier; every thread reads
-// the partner's share with sc1 loads.  Liveness: a workgroup waits only for its partner, which is resident or queued
-// behind workgroups that do finish (pairs are adjacent in dispatch order); it never waits for anything that waits for it.
-constexpr int LP_ROWS = 32;
-constexpr int LPX_OFF = 2 * LW_SLOT;               // the wave's one activation slot: 32 rows x 64 k = 4 KiB
-constexpr int LP_RING = 2 * LW_SLOT + 4 * 1024;    // 20 KiB per wave, all 160 KiB of the CU
-constexpr int LP_LDS = 8 * LP_RING;
-// after the streaming loop a wave's activation slot holds: [0, 512) its fc3 bias slice, [512, 516) a KL partial,
-// [1024, 1536) four rows of z (row r of the pair's 32 lives in wave r >> 2's slot)
-constexpr int LPX_KL = 512, LPX_Z = 1024;
-
-__device__ __forceinline__ f32x4 load_sc1_16(const float* p) {
-  f32x4 v;
-  // the wait is inside the statement: hipcc does not count an asm load (cdna_hip_programming.md 5.7)
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-__global__ void __launch_bounds__(512)
-k_latent_fwd_pair(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __restrict__ Wh, const long ldwh,
-                  const float* __restrict__ bh, const bf16_t* __restrict__ W3, const long ldw3,
-                  const float* __restrict__ b3, const long Hp, const long B, const long L,
-                  const float* __restrict__ eps_in, float* __restrict__ eps_out, const uint64_t seed,
-                  const long long* __restrict__ step_counter, float* __restrict__ mulv, bf16_t* __restrict__ z,
-                  float* __restrict__ kl_partial, bf16_t* __restrict__ h3, const long ldh3, const int wt,
-                  unsigned char* __restrict__ h3q, const long ldq, const float* __restrict__ q_scale,
-                  float* __restrict__ amax_part, float* __restrict__ xchg, int* __restrict__ gen, int* __restrict__ err) {
-  constexpr long Lp = 64, L2p = 128;
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  lds_char* smem = (lds_char*)smem_dyn;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = lane >> 4, j = lane & 15;
-  const int b = (int)blockIdx.x, hf = b & 1, partner = b ^ 1;
-  const long r0 = (long)(b >> 1) * LP_ROWS;
-  lds_char* ring = smem + wave * LP_RING;
-  lds_char* const W0 = ring, * const W1 = ring + LW_SLOT;
-  lds_char* const XS = ring + LPX_OFF;
-  const long kw = Hp / 16;         // a wave's K slice of this workgroup's K half = its column slice of this workgroup's h3 half
-  const int NU = (int)(kw / 64);   // 1 or 2
-  // (the stagger of k_latent_fwd: workgroups sharing an XCD start on different slices / steps)
-  const int bi = b >> 3;
-  const int ks = (wave + bi) & 7;
-  const int rot = (bi >> 3) % NU;
-  auto walk = [&](int s) { const int t = s + rot; return t >= NU ? t - NU : t; };
-  const long k0 = (long)hf * (Hp / 2) + ks * kw;      // first k of the wave's slice = first h3 column of its fc3 slice
-  const bf16_t* xg = h1 + r0 * ldh + k0;
-  const bf16_t* wg = Wh + k0;
-  auto issue_x = [&](int s) { stage_rows<32>(xg + 64 * walk(s), ldh, XS, lane); };                                  // 4 pieces
-  auto issue_w = [&](int s, int half) { stage_rows<64>(wg + (long)(64 * half) * ldwh + 64 * walk(s), ldwh, half ? W1 : W0, lane); };   // 8
-  auto issue_fc3 = [&](int u) { stage_rows<64>(W3 + (k0 + 64 * walk(u)) * ldw3, ldw3, (u & 1) ? W1 : W0, lane); };    // 8
-  int my_gen = 0;
-  if (tid == 0) my_gen = gen[b] + 1;      // (written by this workgroup alone, in its previous launch)
-
-  f32x4 acc[2][8];
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) acc[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // issue order:  X0 W(0,A) W(0,B) | X1 W(1,A) | W(1,B) | fc3 slot 0, bias
-  issue_x(0);
-  issue_w(0, 0);
-  issue_w(0, 1);
-  for (int s = 0; s < NU; ++s) {
-    bf16x8 x[2][2], w[4][2];
-    // half A: X(s) and W(s,A) have landed once only W(s,B)'s 8 pieces are younger
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) x[rt][kk] = load_frag<32, true>(XS, rt * 16, kk, lane);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(W0, cb * 16, kk, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: both slots may be refilled
-    if (s + 1 < NU) {
-      issue_x(s + 1);
-      issue_w(s + 1, 0);
-    } else {
-      // behind the last step: fc3 weight slot 0 and the wave's fc3 bias slice (kw floats <= 512 B) start to fly
-      issue_fc3(0);
-      dma16((const bf16_t*)(b3 + k0 + (lane * 4 < kw ? lane * 4 : 0)), XS);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[rt][kk], acc[rt][cb], 0, 0, 0);
-    // half B: W(s,B); younger: X(s+1) 4 + W(s+1,A) 8, or fc3 slot 0 + bias 9 (a smaller count is always safe)
-    if (s + 1 < NU) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(W1, cb * 16, kk, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (s + 1 < NU) issue_w(s + 1, 1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          acc[rt][4 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][kk], x[rt][kk], acc[rt][4 + cb], 0, 0, 0);
-  }
-
-  // ---- this workgroup's partial sums over its K half: the 8 waves' partials through each wave's weight slot 1, one row
-  // tile at a time (weight slot 0 is receiving fc3's first slot).  Thread t takes row rr = t >> 4 of the 32 and columns
-  // l .. l + 3 of mu and of logvar, l = 4 (t & 15): the 512 four-column groups in k_reparam_fwd's order.
-  const int rr = tid >> 4;
-  const long l = (long)(tid & 15) * 4;
-  float pmu[4] = {0.f, 0.f, 0.f, 0.f}, plv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb)   // (quad index XOR j & 7: see k_latent_fwd)
-      *(__attribute__((address_space(3))) f32x4*)(W1 + (j * 128 + (((cb * 4 + q) ^ (j & 7)) << 2)) * 4) = acc[rt][cb];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // raw: __syncthreads() would drain vmcnt, i.e. wait for the fc3 slot in flight
-    asm volatile("" ::: "memory");
-    if ((tid >> 8) == rt) {
-      const int rl = rr & 15;
-      f32x4 pm[8], pv[8];
-#pragma unroll
-      for (int w_ = 0; w_ < 8; ++w_) {
-        const lds_char* ps = smem + w_ * LP_RING + LW_SLOT;
-        const int qm = (int)(l >> 2) ^ (rl & 7), qv = (16 + (int)(l >> 2)) ^ (rl & 7);
-        pm[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + (qm << 2)) * 4);
-        pv[w_] = *(const __attribute__((address_space(3))) f32x4*)(ps + (rl * 128 + (qv << 2)) * 4);
-      }
-#pragma unroll
-      for (int e_ = 0; e_ < 4; ++e_) {
-        pmu[e_] = ((pm[0][e_] + pm[1][e_]) + (pm[2][e_] + pm[3][e_])) + ((pm[4][e_] + pm[5][e_]) + (pm[6][e_] + pm[7][e_]));
-        plv[e_] = ((pv[0][e_] + pv[1][e_]) + (pv[2][e_] + pv[3][e_])) + ((pv[4][e_] + pv[5][e_]) + (pv[6][e_] + pv[7][e_]));
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // every reader is done before the next row tile (or fc3's slot 1) overwrites the slots
-    asm volatile("" ::: "memory");
-  }
-
-  // ---- exchange with the partner (see the header comment); fc3's second weight slot flies meanwhile (slot 1 is free)
-  if (NU > 1) issue_fc3(1);
-  float* mine = xchg + (long)b * (LP_ROWS * 128);
-  const float* theirs = xchg + (long)partner * (LP_ROWS * 128);
-  store_wt16((f32x4*)(mine + (long)tid * 4), f32x4{pmu[0], pmu[1], pmu[2], pmu[3]});
-  store_wt16((f32x4*)(mine + (long)(512 + tid) * 4), f32x4{plv[0], plv[1], plv[2], plv[3]});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached memory (and fc3's slot 0 has landed)
-  __builtin_amdgcn_s_barrier();
-  if (tid == 0) {
-    __hip_atomic_store(gen + b, my_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long t0 = wall_clock64();   // 100 MHz
-    while (__hip_atomic_load(gen + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - my_gen < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 10000000LL) {   // 100 ms
-        atomicAdd(err, 1);
-        break;
-      }
-    }
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  {
-    const f32x4 tm = load_sc1_16(theirs + (long)tid * 4);
-    const f32x4 tv = load_sc1_16(theirs + (long)(512 + tid) * 4);
-    // a + b rounds the same in either order: both workgroups of the pair hold bit-identical sums
-#pragma unroll
-    for (int e_ = 0; e_ < 4; ++e_) { pmu[e_] += tm[e_]; plv[e_] += tv[e_]; }
-  }
-
-  // ---- bias, reparameterise (k_reparam_fwd's arithmetic and eps draws) for all 32 rows; the outputs of rows
-  // [16 hf, 16 hf + 16) are this workgroup's to write
-  float kl = 0.f;
-  {
-    const long bb = r0 + rr;
-    const long i = bb * 16 + (tid & 15);   // group index over the padded [Bp, Lp / 4] grid
-    const bool own = (rr >> 4) == hf;
-    float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bb < B && l < L) {
-      const f32x4 bm = *reinterpret_cast<const f32x4*>(bh + l), bv = *reinterpret_cast<const f32x4*>(bh + Lp + l);
-      float ev[4];
-      if (!eps_in) normal4_fast(seed, (uint64_t)i, step_counter ? (uint64_t)*step_counter : 0, ev);
-#pragma unroll
-      for (int e_ = 0; e_ < 4; ++e_) {
-        if (l + e_ < L) {
-          float e;
-          if (eps_in) {
-            e = eps_in[bb * L + l + e_];
-          } else {
-            e = ev[e_];
-            if (own) eps_out[bb * L + l + e_] = e;
-          }
-          mua[e_] = pmu[e_] + bm[e_];
-          lva[e_] = plv[e_] + bv[e_];
-          const float sd = __expf(0.5f * lva[e_]);
-          zz[e_] = mua[e_] + e * sd;
-          kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
-        }
-      }
-    }
-    const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
-    if (own) {
-      *reinterpret_cast<float4*>(mulv + bb * L2p + l) = make_float4(mua[0], mua[1], mua[2], mua[3]);
-      *reinterpret_cast<float4*>(mulv + bb * L2p + Lp + l) = make_float4(lva[0], lva[1], lva[2], lva[3]);
-      *reinterpret_cast<bf16x4*>(z + bb * Lp + l) = zb;
-    }
-    *(__attribute__((address_space(3))) bf16x4*)(smem + (rr >> 2) * LP_RING + LPX_OFF + LPX_Z + (rr & 3) * 128 + l * 2) = zb;
-  }
-  kl = wave_sum(kl);
-  if (lane == 0) *(__attribute__((address_space(3))) float*)(XS + LPX_KL) = kl;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();   // z complete, KL partials complete
-  asm volatile("" ::: "memory");
-  if (tid == 0) {
-    float ksum[4];
-#pragma unroll
-    for (int w_ = 0; w_ < 4; ++w_)
-      ksum[w_] = *(const __attribute__((address_space(3))) float*)(smem + (4 * hf + w_) * LP_RING + LPX_OFF + LPX_KL);
-    kl_partial[b] = ksum[0] + ksum[1] + ksum[2] + ksum[3];      // the 16-row group 2 (b >> 1) + hf = b, its 4 waves in order
-    // (the poll above is done: the partner may be a launch ahead, never behind by more than this one)
-  }
-
-  // ---- fc3: h3[r0 + row][n] = relu(sum_k W3[n][k] z[row][k] + b3[n]) for this wave's columns, 64 per slot, 32 rows
-  bf16x8 z0[2], z1[2];
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int row = rt * 16 + j;
-    const lds_char* zl = smem + (row >> 2) * LP_RING + LPX_OFF + LPX_Z + (row & 3) * 128;
-    z0[rt] = *(const __attribute__((address_space(3))) bf16x8*)(zl + q * 16);
-    z1[rt] = *(const __attribute__((address_space(3))) bf16x8*)(zl + 64 + q * 16);
-  }
-  const lds_char* bl = XS;   // the wave's bias slice (kw floats)
-  const float qs = h3q ? *q_scale : 0.f;
-  float amax = 0.f;
-  for (int u = 0; u < NU; ++u) {
-    const lds_char* sl = (u & 1) ? W1 : W0;
-    // both slots and the bias landed before the exchange's vmcnt(0)
-    bf16x8 w[4][2];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) w[cb][kk] = load_frag<64, true>(sl, cb * 16, kk, lane);
-    f32x4 bias[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bias[cb] = *(const __attribute__((address_space(3))) f32x4*)(bl + (walk(u) * 64 + cb * 16 + q * 4) * 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      f32x4 a[4];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        a[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], z0[rt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        a[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], z1[rt], a[cb], 0, 0, 0);
-      }
-      // bias + ReLU on the accumulators first (plain VALU: the compiler pads the MFMA-result hazard), then the pairing swap
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[cb][e] = fmaxf(a[cb][e] + bias[cb][e], 0.f);
-      bf16_t* out = h3 + (r0 + rt * 16 + j) * ldh3 + k0;
-      unsigned char* outq = h3q ? h3q + (r0 + rt * 16 + j) * ldq + k0 : nullptr;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        f32x4 lo = a[2 * t], hi = a[2 * t + 1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float a_ = lo[r], b_ = hi[r];
-          swap_rows16(a_, b_);
-          lo[r] = a_;
-          hi[r] = b_;
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (bf16_t)lo[e];
-          o[4 + e] = (bf16_t)hi[e];
-        }
-        store_out16((bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
-        if (h3q || amax_part) {
-          float q8[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            amax = fmaxf(amax, fmaxf(lo[e], hi[e]));   // post-ReLU: non-negative
-            q8[e] = lo[e] * qs;
-            q8[4 + e] = hi[e] * qs;
-          }
-          if (h3q) *(unsigned long long*)(outq + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8) = pack_fp8x8(q8);
-        }
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-  if (amax_part) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0) amax_part[blockIdx.x * 8 + wave] = amax;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave's is in flight towards LDS when it ends
-}
-
-
 // `64` k-rows of 64 bf16 (row stride ld) -> MN-major LDS image at sl (gemm_bf16.h: [k][64 n], 32-byte chunks swizzled
 // by swz_mn<64>(k); fragments by load_frag<64, false>, i.e. transposing LDS reads): the operand whose contraction
 // index is the ROW of the matrix in memory
@@ -1082,7 +765,6 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
   RV_REQUIRE(!h3_fp8 || (q_scale && ldq >= Hp && ldq % 8 == 0 && ((uintptr_t)h3_fp8 & 7) == 0), RV_ERR_SHAPE,
              "rv_latent_fwd: the fp8 output needs a scale and 8-byte aligned rows");
   // w3_bf16 == NULL: heads + reparameterisation only (z, mu | logvar, the KL partials); fc3 is then the caller's
-  // (rv_decode_fc3_out_loss_fwd generates h3 inside the fc4 forward)
   const bool heads_only = !w3_bf16;
   RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && mulv && z_bf16 && kl_partial && (heads_only || (bias3 && h3_bf16)), RV_ERR_NULL,
              "rv_latent_fwd: null pointer");
@@ -1106,42 +788,6 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
                      (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-// rv_latent_fwd_ex on PAIRS of workgroups (k_latent_fwd_pair): half the weight bytes through every CU's L2 -> LDS port.
-// `xchg` [(Bp / 16) x 4096] floats and `gen` [Bp / 16] + `err` ints belong to the caller (zero-initialised once; the plan
-// keeps them in its workspace).  Needs Hp in {1024, 2048} and an even number of 16-row blocks.
-int rv_latent_fwd_pair_fits(long Bp, long Hp, long Lp) { return Lp == 64 && (Hp == 1024 || Hp == 2048) && Bp % LP_ROWS == 0; }
-
-int rv_latent_fwd_pair(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
-                       const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
-                       const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
-                       float* mulv, void* z_bf16, float* kl_partial, void* h3_bf16, long ldh3, void* h3_fp8, long ldq,
-                       const float* q_scale, float* amax_part, float* xchg, int* gen, int* err, void* stream) {
-  RV_REQUIRE(!h3_fp8 || (q_scale && ldq >= Hp && ldq % 8 == 0 && ((uintptr_t)h3_fp8 & 7) == 0), RV_ERR_SHAPE,
-             "rv_latent_fwd_pair: the fp8 output needs a scale and 8-byte aligned rows");
-  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && w3_bf16 && bias3 && mulv && z_bf16 && kl_partial && h3_bf16 && xchg && gen && err,
-             RV_ERR_NULL, "rv_latent_fwd_pair: null pointer");
-  RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd_pair: need eps_in or eps_out");
-  RV_REQUIRE(rv_latent_fwd_pair_fits(Bp, Hp, Lp), RV_ERR_UNSUPPORTED,
-             "rv_latent_fwd_pair: needs a padded latent width of 64, a hidden width of 1024 or 2048 and a batch that is a multiple of 32 "
-             "(got %ld, %ld, %ld)", Lp, Hp, Bp);
-  RV_REQUIRE(Bp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp && ldw3 >= Lp && ldh3 >= Hp && ldh % 8 == 0 &&
-                 ldwh % 8 == 0 && ldw3 % 8 == 0 && ldh3 % 8 == 0, RV_ERR_SHAPE, "rv_latent_fwd_pair: bad extents Bp %ld Hp %ld", Bp, Hp);
-  RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
-               (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16 | (uintptr_t)xchg) & 15) == 0,
-             RV_ERR_SHAPE, "rv_latent_fwd_pair: operands must be 16-byte aligned");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_latent_fwd_pair, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k_latent_fwd_pair, dim3((unsigned)(Bp / 16)), dim3(512), LP_LDS, (hipStream_t)stream,
-                     (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
-                     Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
-                     (bf16_t*)h3_bf16, ldh3, rv_store_wt, (unsigned char*)h3_fp8, ldq, q_scale, amax_part, xchg, gen, err);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -95,10 +95,6 @@ struct rv_plan {
   float* ext_grad_out = nullptr;
   const float* loss_grad_dev = nullptr;   // rv_plan_set_loss_grad: the FINALIZE launches multiply by this device scalar
   int latent_fused = 1;          // RV_OPT_LATENT_FUSED: heads + reparam + fc3 as one launch (rv_latent_fwd) where it applies
-  int fc3_in_fc4 = 0;            // RV_OPT_FC3_IN_FC4: fc3 generated inside the fc4 forward (rv_decode_fc3_out_loss_fwd), the latent
-                                 // launch does heads + reparameterisation only
-  int latent_pair = 0;           // RV_OPT_LATENT_PAIR: ... on pairs of workgroups that split the weights (rv_latent_fwd_pair;
-                                 // opt-in: measured 1.5-2 us SLOWER in the step at C2)
   bool shadows_padded = false;   // rv_plan_refresh_shadows has zeroed the shadows' padding once
   // data-parallel step: the collective library's all-reduce (RCCL's ncclAllReduce), its communicator,
   // a dedicated stream for it, and "bucket ready" / "bucket reduced" events per gradient bucket
@@ -299,8 +295,6 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->n_amax_cap = (int)(Bp / 2 > 4096 ? Bp / 2 : 4096);
   p->n_amax_dp1 = Bp % 512 == 0 ? (int)(8 * (Bp / 512) * (Hp / 64)) : 0;   // one maximum per wave of rv_heads_bwd_ex
   p->add("h3_amax", ((long)p->n_amax_cap + p->n_amax_dp1) * 4);            // h3's maxima, then dP1's right behind them
-  p->add("lat_xchg", (Bp / 16) * 4096 * 4);   // rv_latent_fwd_pair: partial head sums of every workgroup (16 KB each)
-  p->add("lat_gen", (Bp / 16 + 16) * 4);       // ... its generation counters, then the count of hand-off time-outs
   p->add("ddp_flags", 64 * 4);   // data-parallel step: cross-stream sequence flags [0..3], timeout counter [8]
   p->add("mse_part", (long)p->n_mse * 4);
   p->add("kl_part", (long)p->n_kl * 4);
@@ -412,8 +406,6 @@ int rv_plan_set_option(rv_plan* p, int option, int value) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_set_option: plan not bound");
   switch (option) {
     case RV_OPT_LATENT_FUSED: p->latent_fused = value ? 1 : 0; heads_mode_apply(p); return RV_OK;
-    case RV_OPT_LATENT_PAIR: p->latent_pair = value ? 1 : 0; return RV_OK;
-    case RV_OPT_FC3_IN_FC4: p->fc3_in_fc4 = value ? 1 : 0; return RV_OK;
     case RV_OPT_DDP_DEFER_TAIL:
       RV_REQUIRE(value || !p->tail_pending, RV_ERR_STATE, "rv_plan_set_option: a deferred update is pending (rv_plan_ddp_flush first)");
       p->ddp_defer = value ? 1 : 0;
@@ -703,29 +695,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_K(1, rv_linear_fwd_ex(xb, Sp, p->ws("W1b"), Sp, (float*)p->ws("b1p"), Bp, Hp, Sp, RV_ACT_RELU, h1, Hp, nullptr, 0,
                                 nullptr, nullptr, stream));
     }
-    // fc3 inside the fc4 forward (bf16 operands, the 128 x 128 tile the partial-sum buffers were sized for)
-    bool fc3_in_fc4 = false;
-    if (p->fc3_in_fc4 && latent_fused && !p->fp8 && rv_decode_fc3_out_loss_fwd_fits(Bp, Sp, Hp, Lp)) {
-      int bm4 = 0, bn4 = 0;
-      rv_gemm_tile(Bp, Sp, 1, &bm4, &bn4);
-      fc3_in_fc4 = bm4 == 128 && bn4 == 128;
-    }
-    if (fc3_in_fc4) {
-      RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), nullptr, 0, nullptr, Bp, Hp, Lp, B, L, eps, eps_buf,
-                              seed, p->b.step_counter, mulv, z, kl_part, nullptr, 0, nullptr, 0, nullptr, nullptr, stream));
-      RV_K(3, rv_decode_fc3_out_loss_fwd(z, Lp, p->ws("W3b"), Lp, (float*)p->ws("b3p"), h3, Hp, p->ws("W4b"), Hp,
-                                        (float*)p->ws("b4p"), Bp, Sp, Hp, Lp, B, S, p->fr_hop ? nullptr : x, S,
-                                        p->fr_hop ? x : nullptr, p->fr_nsamples, p->fr_idx, p->fr_first, p->fr_hop,
-                                        recon_out, S, dP4, Sp, mse_part, (float*)p->ws("db4p"), stream));
-    } else {
-      if (latent_fused && p->latent_pair && rv_latent_fwd_pair_fits(Bp, Hp, Lp)) {
-        int* gen = (int*)p->ws("lat_gen");
-        RV_K(2, rv_latent_fwd_pair(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp,
-                                   Lp, B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
-                                   p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
-                                   p->fp8 ? (float*)p->ws("h3_amax") : nullptr, (float*)p->ws("lat_xchg"), gen, gen + Bp / 16,
-                                   stream));
-      } else if (latent_fused)
+    {
+      if (latent_fused)
         RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
                                 B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
                                 p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,

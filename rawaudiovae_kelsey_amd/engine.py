@@ -107,11 +107,6 @@ class TrainEngine:
             raise _lib.RvError("slab_dtype %r (expected 'fp32' or 'fp16')" % (slab_dtype,))
         self.slab_dtype = slab_dtype
         L_.rv_plan_set_option(self._plan, _lib.OPT_SLAB_DTYPE, _lib.SLAB_F16 if slab_dtype == "fp16" else _lib.SLAB_F32)
-        self._latent_pair = False
-        if os.environ.get("RV_LATENT_PAIR", "0") == "1":
-            self.set_latent_pair(True)
-        if os.environ.get("RV_FC3_IN_FC4", "0") == "1":
-            self.set_fc3_in_fc4(True)
         self._note_init()     # the zero fills above ran on the current stream
 
     # ---- stream hygiene ---------------------------------------------------
@@ -192,21 +187,6 @@ class TrainEngine:
         fused kernel (padded latent width 64, hidden width a multiple of 512 up to 2048, bf16); False: always three
         launches (`rv_plan_set_option`, RV_OPT_LATENT_FUSED)."""
         lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_FUSED, int(bool(enable)))
-
-    def set_latent_pair(self, enable):
-        """True: the fused latent forward on pairs of workgroups that split the weights (`rv_latent_fwd_pair`) where the
-        extents allow; False (default): `rv_latent_fwd`, every workgroup streams all weights (RV_OPT_LATENT_PAIR; the paired
-        form measured slower in the step at C2 -- DESIGN.md section 6 -- and stays an option)."""
-        if enable:
-            self.buffer("lat_gen", torch.int32, (-1,)).zero_()     # generation counters and the time-out count start at 0
-        lib().rv_plan_set_option(self._plan, _lib.OPT_LATENT_PAIR, int(bool(enable)))
-        self._latent_pair = bool(enable)
-
-    def set_fc3_in_fc4(self, enable):
-        """True: fc3 runs inside the fc4 forward (`rv_decode_fc3_out_loss_fwd`: fc4's A operand is generated tile by tile
-        from z and W3) and the latent launch stops after the reparameterisation, where the plan's shape allows (bf16
-        operands, padded latent width 64); False: fc3 in the latent launch (RV_OPT_FC3_IN_FC4).  Same h3 bit for bit."""
-        lib().rv_plan_set_option(self._plan, _lib.OPT_FC3_IN_FC4, int(bool(enable)))
 
     def set_roctx(self, enable):
         """roctx ranges (rocprofv3 --marker-trace) around the phases of every step this engine enqueues
@@ -514,22 +494,7 @@ class TrainEngine:
         """Number of steps started on the device (reads the device counter; synchronises)."""
         n = int(self.step_counter.item())
         self.check_ddp_signals()
-        self.check_latent_pair()
         return n
-
-    def check_latent_pair(self):
-        """The paired latent forward's in-launch hand-off is bounded (100 ms); a wait that ran out left that step's mu /
-        logvar / h3 incomplete.  Raises if any did (include/rawvae_hip.h, RV_OPT_LATENT_PAIR)."""
-        if not getattr(self, "_latent_pair", False):
-            return
-        cnt = getattr(self, "_lat_err", None)
-        if cnt is None:
-            gen = self.buffer("lat_gen", torch.int32, (-1,))
-            cnt = self._lat_err = gen[self.padded()[0] // 16:][:1]
-        n = int(cnt.item())
-        if n:
-            raise _lib.RvError("latent forward: %d partner hand-off(s) between paired workgroups timed out -- the results of "
-                               "those steps are invalid (RV_LATENT_PAIR=0 selects the unpaired kernel)" % n)
 
     def check_ddp_signals(self):
         """The data-parallel step's device-side flag waits are bounded (5 s behind local kernels, RV_DDP_WAIT_MS --

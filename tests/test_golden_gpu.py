@@ -44,12 +44,15 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
 
 
-@pytest.fixture(scope="module")
-def c2_step():
-    """One C2 forward + backward on the HIP path and on the bf16-quantised oracle (same inputs)."""
+@pytest.fixture(scope="module", params=["c2_f32", "refini_f32"])
+def c2_step(request):
+    """One forward + backward on the HIP path and on the bf16-quantised oracle (same inputs), at C2 and at the
+    reference's own configuration (`refini`: S=1024 H=2048 L=256 -- default.ini:3,18-19 / kelsey_iterable.ini:17-18 --,
+    batch 4096 as kelsey_iterable.ini:26), where the latent-sized launches are the GEMM forms with fused
+    reparameterisation epilogues instead of C2's row-local kernels."""
     from rawaudiovae_kelsey_amd import engine as E
     with open(os.path.join(GOLDEN, "summary.json")) as f:
-        cs = json.load(f)["cases"]["c2_f32"]
+        cs = json.load(f)["cases"][request.param]
     S, H, L, B = cs["shape"]
     e = _engine(S, H, L, B)
     x, eps = make_frames(B, S, 1234), make_eps(B, L, 4321)

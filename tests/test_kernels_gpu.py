@@ -381,87 +381,6 @@ def test_latent_fwd_one_launch_equals_three(L, B, Lt, H):
                         h31.data_ptr(), Hp, sp())
 
 
-@pytest.mark.parametrize("B,Lt,H", [(4096, 64, 2048), (100, 3, 1024), (300, 40, 2000), (4000, 64, 900)])
-def test_latent_fwd_on_workgroup_pairs_equals_the_unpaired_kernel(L, B, Lt, H):
-    """rv_latent_fwd_pair (workgroups 2i / 2i + 1 share 32 rows, split the weights and exchange their partial head sums
-    inside the launch) against rv_latent_fwd on the same bf16 operands and eps, and against float64 numpy: mu / logvar to
-    the fp32 summation order of the head sums (1e-5 of the term scale), z equal except where that crosses a bf16 rounding
-    boundary, KL partials per 16-row block, h3 equal on rows whose z is equal (fc3 is the same 64-term sum in the same
-    order), the same Philox draws; launched four times in a row on one set of exchange buffers (the generation counters
-    advance, nothing is reset), no hand-off time-out."""
-    rng = np.random.default_rng(9)
-    Bp, Lp, Hp = -(-B // 128) * 128, 64, -(-H // 1024) * 1024
-    h = np.zeros((Bp, Hp), np.float32); h[:B, :H] = np.maximum(rand_bf16(rng, (B, H), 0.5), 0)
-    wh = np.zeros((2 * Lp, Hp), np.float32)
-    wh[:Lt, :H] = rand_bf16(rng, (Lt, H), 0.05); wh[Lp:Lp + Lt, :H] = rand_bf16(rng, (Lt, H), 0.05)
-    bh = np.zeros(2 * Lp, np.float32)
-    bh[:Lt] = rng.standard_normal(Lt) * 0.1; bh[Lp:Lp + Lt] = rng.standard_normal(Lt) * 0.1
-    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.2)
-    b3 = np.zeros(Hp, np.float32); b3[:H] = rng.standard_normal(H) * 0.1
-    eps = rng.standard_normal((B, Lt)).astype(np.float32)
-    hd, whd, w3d = dev(h, torch.bfloat16), dev(wh, torch.bfloat16), dev(w3, torch.bfloat16)
-    bhd, b3d, ed = dev(bh), dev(b3), dev(eps)
-    ctr = torch.ones(1, dtype=torch.int64, device="cuda")
-    xchg = torch.zeros(Bp // 16 * 4096, device="cuda")
-    gen = torch.zeros(Bp // 16 + 1, dtype=torch.int32, device="cuda")
-
-    def outs():
-        return (torch.empty(Bp, 2 * Lp, device="cuda"), torch.empty(Bp, Lp, device="cuda", dtype=torch.bfloat16),
-                torch.zeros(Bp * Lp // 1024, device="cuda"), torch.empty(Bp, Hp, device="cuda", dtype=torch.bfloat16))
-
-    def pair(e_in, e_out, seed, o):
-        L.rv_latent_fwd_pair(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
-                             B, Lt, e_in, e_out, seed, ctr.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
-                             o[3].data_ptr(), Hp, None, 0, None, None, xchg.data_ptr(), gen.data_ptr(),
-                             gen.data_ptr() + 4 * (Bp // 16), sp())
-    o1 = outs()
-    pair(ed.data_ptr(), None, 0, o1)
-    o2 = outs()
-    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
-                    B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
-                    o2[3].data_ptr(), Hp, sp())
-    torch.cuda.synchronize()
-    assert int(gen[-1]) == 0 and bool((gen[:-1] == 1).all())
-    ref = h[:B].astype(np.float64) @ wh.astype(np.float64).T + bh
-    mu, lv = ref[:, :Lt], ref[:, Lp:Lp + Lt]
-    got = o1[0].cpu().numpy()
-    np.testing.assert_allclose(got[:B, :Lt], mu, rtol=1e-5, atol=2e-5)
-    np.testing.assert_allclose(got[:B, Lp:Lp + Lt], lv, rtol=1e-5, atol=2e-5)
-    assert not got[B:].any() and not got[:, Lt:Lp].any() and not got[:, Lp + Lt:].any()
-    np.testing.assert_allclose(got, o2[0].cpu().numpy(), rtol=1e-5, atol=2e-5)
-    za, zb = o1[1].float().cpu().numpy(), o2[1].float().cpu().numpy()
-    assert np.mean(za != zb) < 2e-3 and not za[B:].any() and not za[:, Lt:].any()
-    np.testing.assert_allclose(za, zb, rtol=1e-2, atol=1e-6)
-    kl_ref = float(np.sum(1 + lv - mu ** 2 - np.exp(lv)))
-    assert abs(float(o1[2].double().sum()) - kl_ref) <= 1e-5 * abs(kl_ref) + 1e-4
-    np.testing.assert_allclose(o1[2].cpu().numpy(), o2[2].cpu().numpy(), rtol=1e-4, atol=1e-4)
-    h3ref = np.maximum(za[:B].astype(np.float64) @ w3.astype(np.float64).T + b3, 0)
-    np.testing.assert_allclose(o1[3].float().cpu().numpy()[:B], h3ref, rtol=1e-2, atol=1e-3)
-    rows_same = (za == zb).all(axis=1)
-    assert rows_same.mean() > 0.8
-    assert torch.equal(o1[3][torch.from_numpy(rows_same).cuda()], o2[3][torch.from_numpy(rows_same).cuda()])
-    # repeated launches on the same exchange buffers: bit-identical outputs every time, the counters advance
-    for k in range(3):
-        o3 = outs()
-        pair(ed.data_ptr(), None, 0, o3)
-        for a, b in zip(o1, o3):
-            assert torch.equal(a, b)
-    torch.cuda.synchronize()
-    assert int(gen[-1]) == 0 and bool((gen[:-1] == 4).all())
-    # generated eps: the same Philox draws as the unpaired kernel
-    e1, e3 = torch.empty(B, Lt, device="cuda"), torch.empty(B, Lt, device="cuda")
-    pair(None, e1.data_ptr(), 77, outs())
-    L.rv_latent_fwd(hd.data_ptr(), Hp, whd.data_ptr(), Hp, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp,
-                    B, Lt, None, e3.data_ptr(), 77, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
-                    o2[3].data_ptr(), Hp, sp())
-    assert torch.equal(e1, e3)
-    from rawaudiovae_kelsey_amd import _lib
-    with pytest.raises(_lib.RvError):      # a hidden width the pairing does not cover
-        L.rv_latent_fwd_pair(hd.data_ptr(), 512, whd.data_ptr(), 512, bhd.data_ptr(), w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, 512, Lp,
-                             B, Lt, ed.data_ptr(), None, 0, ctr.data_ptr(), o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(),
-                             o2[3].data_ptr(), 512, None, 0, None, None, xchg.data_ptr(), gen.data_ptr(), gen.data_ptr(), sp())
-
-
 @pytest.mark.parametrize("B,Lt,H,ext", [(100, 3, 512, False), (4096, 64, 2048, False), (300, 40, 900, True), (200, 64, 1536, True)])
 def test_latent_bwd_one_launch_equals_two(L, B, Lt, H, ext):
     """rv_latent_bwd (dz = dP3 W3 over the full contraction + the reparameterisation / KL backward + the loss scalar
@@ -910,71 +829,6 @@ def test_scale_by3_one_launch_any_alignment():
     with pytest.raises(Exception):
         lib().rv_scale_by3(ptr(a0), None, 5, None, None, 0, None, None, 0, ptr(g), stream_ptr())
     torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("B,S,H,Lt,hop", [(4096, 1024, 2048, 64, 0), (300, 500, 1000, 8, 0), (128, 128, 256, 64, 0),
-                                          (256, 384, 768, 33, 0), (640, 256, 4096, 64, 0), (300, 512, 1024, 16, 128)])
-def test_fc3_inside_fc4_forward_equals_two_launches(L, B, S, H, Lt, hop):
-    """rv_decode_fc3_out_loss_fwd (fc4's A operand h3 = relu(z W3^T + b3) generated tile by tile inside the launch)
-    against the two launches it replaces -- rv_linear_fwd(fc3) into HBM, then rv_decode_out_loss_fwd on 128 x 128 tiles --
-    on the same operands: h3, dP4, recon, the MSE partials and the db4 partial rows BIT-identical (the generator issues
-    the same two MFMAs per fragment in the same order, the main loop is unchanged), and against float64 numpy.  Shapes:
-    C2; ragged B / S / H / L; the shortest K loop the kernel takes (4 tiles: no refill); an odd number of N tiles; the
-    widest hidden layer; target frames read from a resident waveform (the real-data step)."""
-    rng = np.random.default_rng(B + S + H + Lt)
-    Bp, Sp, Hp, Lp = -(-B // 128) * 128, -(-S // 128) * 128, -(-H // 256) * 256, 64
-    z = np.zeros((Bp, Lp), np.float32); z[:B, :Lt] = rand_bf16(rng, (B, Lt), 1.0)
-    w3 = np.zeros((Hp, Lp), np.float32); w3[:H, :Lt] = rand_bf16(rng, (H, Lt), 0.3)
-    b3 = np.zeros(Hp, np.float32); b3[:H] = rng.standard_normal(H) * 0.2
-    w4 = np.zeros((Sp, Hp), np.float32); w4[:S, :H] = rand_bf16(rng, (S, H), 0.03)
-    b4 = np.zeros(Sp, np.float32); b4[:S] = rng.standard_normal(S) * 0.1
-    zd, w3d, w4d = dev(z, torch.bfloat16), dev(w3, torch.bfloat16), dev(w4, torch.bfloat16)
-    b3d, b4d = dev(b3), dev(b4)
-    if hop:
-        n_samples = (B - 1) * hop + S
-        audio = rng.uniform(-1, 1, n_samples).astype(np.float32)
-        idx = rng.permutation(B).astype(np.int64)
-        x = np.stack([audio[i * hop:i * hop + S] for i in idx])
-        ad, idxd = dev(audio), dev(idx)
-    else:
-        x = rng.uniform(-1, 1, (B, S)).astype(np.float32)
-    xd = dev(x)
-
-    def outs():
-        return dict(h3=torch.full((Bp, Hp), 3.0, device="cuda", dtype=torch.bfloat16),
-                    recon=torch.full((B, S), 9.0, device="cuda"),
-                    dP4=torch.full((Bp, Sp), 3.0, device="cuda", dtype=torch.bfloat16),
-                    mse=torch.full(((Bp // 128) * (Sp // 128),), -1.0, device="cuda"),
-                    db4=torch.full((Bp // 128, Sp), -1.0, device="cuda"))
-    a, b = outs(), outs()
-    L.rv_linear_fwd(zd.data_ptr(), Lp, w3d.data_ptr(), Lp, b3d.data_ptr(), Bp, Hp, Lp, 1, a["h3"].data_ptr(), Hp, sp())
-    L.rv_gemm_force_tile(4)
-    try:
-        L.rv_decode_out_loss_fwd(a["h3"].data_ptr(), Hp, w4d.data_ptr(), Hp, b4d.data_ptr(), Bp, Sp, Hp, B, S, xd.data_ptr(), S,
-                                 a["recon"].data_ptr(), S, a["dP4"].data_ptr(), Sp, a["mse"].data_ptr(), a["db4"].data_ptr(), sp())
-    finally:
-        L.rv_gemm_force_tile(-1)
-    for rep in range(2):     # twice: nothing in the launch depends on what an earlier one left in LDS or in the outputs
-        L.rv_decode_fc3_out_loss_fwd(zd.data_ptr(), Lp, w3d.data_ptr(), Lp, b3d.data_ptr(), b["h3"].data_ptr(), Hp,
-                                     w4d.data_ptr(), Hp, b4d.data_ptr(), Bp, Sp, Hp, Lp, B, S,
-                                     None if hop else xd.data_ptr(), S, ad.data_ptr() if hop else None,
-                                     n_samples if hop else 0, idxd.data_ptr() if hop else None, 0, hop,
-                                     b["recon"].data_ptr(), S, b["dP4"].data_ptr(), Sp, b["mse"].data_ptr(),
-                                     b["db4"].data_ptr(), sp())
-        torch.cuda.synchronize()
-        for k in a:
-            assert torch.equal(a[k], b[k]), (k, rep)
-    h3ref = np.maximum(z.astype(np.float64) @ w3.astype(np.float64).T + b3, 0)
-    got = b["h3"].float().cpu().numpy()
-    assert np.abs(got - h3ref).max() <= 2 ** -7 * max(np.abs(h3ref).max(), 1e-3)
-    rec = np.tanh(got[:B].astype(np.float64) @ w4.astype(np.float64).T[:, :S] + b4[:S])
-    np.testing.assert_allclose(b["recon"].cpu().numpy(), rec, rtol=0, atol=2e-5)
-    assert abs(float(b["mse"].double().sum()) - float(((rec - x) ** 2).sum())) <= 1e-4 * float(((rec - x) ** 2).sum())
-    from rawaudiovae_kelsey_amd import _lib
-    with pytest.raises(_lib.RvError):     # a latent width the generator does not cover
-        L.rv_decode_fc3_out_loss_fwd(zd.data_ptr(), 128, w3d.data_ptr(), 128, b3d.data_ptr(), None, 0, w4d.data_ptr(), Hp,
-                                     b4d.data_ptr(), Bp, Sp, Hp, 128, B, S, xd.data_ptr(), S, None, 0, None, 0, 0, None, 0,
-                                     b["dP4"].data_ptr(), Sp, None, None, sp())
 
 
 def test_latent_fwd_heads_only_equals_the_full_kernel(L):

@@ -60,10 +60,11 @@ def test_small_adam_and_trajectory(tag, dtype, rtol):
                                        atol=rtol * np.abs(v[k]).max())
 
 
-@pytest.mark.parametrize("case", ["smoke_f64", "smoke_f32", "c2_f64", "c2_f32"])
+@pytest.mark.parametrize("case", ["smoke_f64", "smoke_f32", "c2_f64", "c2_f32", "refini_f64", "refini_f32"])
 def test_summary_smoke(case):
-    """Smoke shape and the benchmark shape C2 (1024, 2048, 64, 4096): the oracle is pinned to the
-    reference at the size bench.py runs, not only at toy sizes."""
+    """Smoke shape, the benchmark shape C2 (1024, 2048, 64, 4096) and the reference's own model (`refini`: 1024, 2048,
+    256 -- /root/reference/default.ini:3,18-19, kelsey_iterable.ini:17-18 -- at kelsey_iterable.ini:26's batch 4096): the
+    oracle is pinned to the reference at the sizes bench.py runs, not only at toy sizes."""
     with open(os.path.join(GOLDEN, "summary.json")) as f:
         summ = json.load(f)
     cs = summ["cases"][case]

@@ -10,9 +10,13 @@ What is captured:
     gradients, parameters and Adam moments after 1 and 3 optimizer steps, and a
     20-step loss trajectory -- in fp32 (the reference's dtype) and in fp64
     (`model.double()`, the tight pin for the oracle's formulas).
-  * smoke shape (512,2048,8,32) and the benchmark shape C2 (1024,2048,64,4096):
-    loss, per-tensor L2 norms and 16 sampled elements of outputs and gradients
-    at step 0, and a 20-step loss trajectory.
+  * smoke shape (512,2048,8,32), the benchmark shape C2 (1024,2048,64,4096) and
+    the reference's own configuration `refini` (1024,2048,256,4096: the model of
+    default.ini:3,18-19 and kelsey_iterable.ini:17-18 at the batch of
+    kelsey_iterable.ini:26): loss, per-tensor L2 norms and 16 sampled elements of
+    outputs and gradients at step 0, and a 20-step loss trajectory.
+    `python tools/make_golden.py --case refini` adds / refreshes one case and
+    leaves every other fixture as it is.
   * default-init statistics and a checksum of `VAE(64,96,8)` under
     torch.manual_seed(0).
 
@@ -227,12 +231,26 @@ def main():
         with open(os.path.join(OUT, "summary.json"), "w") as f:
             json.dump(summ, f, indent=1)
         return
+    cases = (("smoke", (512, 2048, 8, 32)), ("c2", (1024, 2048, 64, 4096)), ("refini", (1024, 2048, 256, 4096)))
+    if "--case" in sys.argv:   # one summary case only; everything else in summary.json stays as committed
+        want = sys.argv[sys.argv.index("--case") + 1]
+        with open(os.path.join(OUT, "summary.json")) as f:
+            summ = json.load(f)
+        for name, shp in cases:
+            if name != want:
+                continue
+            for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+                summ["cases"]["%s_%s" % (name, tag)] = summary_case(*shp, dtype)
+                print(name, tag, "loss0", summ["cases"]["%s_%s" % (name, tag)]["loss0"])
+        with open(os.path.join(OUT, "summary.json"), "w") as f:
+            json.dump(summ, f, indent=1)
+        return
     small_case(torch.float32, "f32")
     small_case(torch.float64, "f64")
     summ = {"kl_beta": KL_BETA, "lr": LR, "torch": torch.__version__,
             "seeds": {"params": 0, "frames": "1234+step", "eps": "4321+step", "sample_idx": 99},
             "init_seed0_64_96_8": init_stats(), "cases": {}}
-    for name, shp in (("smoke", (512, 2048, 8, 32)), ("c2", (1024, 2048, 64, 4096))):
+    for name, shp in cases:
         for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
             summ["cases"]["%s_%s" % (name, tag)] = summary_case(*shp, dtype)
             print(name, tag, "loss0", summ["cases"]["%s_%s" % (name, tag)]["loss0"])
