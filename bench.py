@@ -95,6 +95,10 @@ def step_launches(eng):
             n += el * (26 if d.shadow_bf16 else 28) + el * d.grad_splits * (2 if d.grad_half else 4)
         return n
     s_w1, s_w4 = descs[0].grad_splits, descs[8].grad_splits
+    rf = eng.rider_first()   # tensors [rf, 10) are updated beside fc1's weight gradient, [0, rf) by the last launch
+    names = ["fc1", "fc1", "fc21", "fc21", "fc22", "fc22", "fc3", "fc3", "fc4", "fc4"]
+    riders = ", ".join(dict.fromkeys(names[rf:]))
+    tail = ", ".join(dict.fromkeys(names[:rf]))
     rows = [
         ("k_cast_pad_bf16 (frames fp32 -> padded bf16 operand)", 0.0, B * S * 4 + Bp * Sp * 2),
         ("gemm_bf16_kernel<256,128> fc1 forward: relu(x W1^T + b1) 4096x2048x1024", 2.0 * B * S * H,
@@ -111,9 +115,10 @@ def step_launches(eng):
         ("k_heads_bwd: dP1 = relu'(dmulv Wh) + dWh, one pass over h1", 4.0 * B * H * 2 * L,
          Bp * Hp * 2 + Bp * 2 * Lp * 2 + Bp * Hp * 2 + descs[2].grad_splits * 2 * Lp * Hp * 4),
         ("gemm_wgrad_adam_kernel fc1 weight gradient dW=dY^T X 2048x1024x4096 split-K %d (%s slabs) on 128 CUs + Adam of "
-         "fc21, fc22, fc3, fc4 on the other 128" % (s_w1, eng.slab_dtype), 2.0 * B * S * H,
-         Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + adam_bytes(descs[2:10])),
-        ("k_adam<true> Adam of fc1 (sums the %d dW1 slabs, refreshes the bf16 shadow)" % s_w1, 0.0, adam_bytes(descs[0:2])),
+         "%s on the other 128" % (s_w1, eng.slab_dtype, riders), 2.0 * B * S * H,
+         Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + adam_bytes(descs[rf:10])),
+        ("k_adam<true> Adam of %s (sums the gradient slabs, %d of dW1; refreshes the bf16 shadows)" % (tail, s_w1), 0.0,
+         adam_bytes(descs[0:rf])),
     ]
     return rows
 

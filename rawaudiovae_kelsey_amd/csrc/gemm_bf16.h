@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "philox.h"
 
 namespace rv {
 
@@ -34,6 +35,11 @@ enum : int {
   EPI_F32 = 1,            // out_f32[split] = acc (+bias)          (heads, dz, wgrads)
   EPI_TANH_LOSS = 2,      // recon = tanh(acc+bias); mse; dP4      (fc4)
   EPI_MASK_BF16 = 3,      // out_bf16 = mask>0 ? acc : 0; colsum   (dgrad + ReLU')
+  // latent widths above 64 (the reference's own latent_dim = 256, default.ini:18): the latent-sized contractions are
+  // GEMMs in their own right there, and the elementwise steps between them are epilogues
+  EPI_REPARAM = 4,        // heads GEMM: acc = mu | logvar of the same latents; z = mu + eps exp(logvar / 2), KL partial
+                          // (model.py:21-26,45)
+  EPI_REPARAM_BWD = 5,    // dz GEMM: dmu, dlogvar from dz (autograd of model.py:23-26 + the KL term), their column sums
 };
 
 struct GemmArgs {
@@ -95,6 +101,25 @@ struct GemmArgs {
   bf16_t* a_copy;
   long ld_copy;
   long long* step_inc;   // EPI_BIAS_ACT_BF16: block 0 bumps the device step counter (the step's first kernel does)
+  // EPI_REPARAM / EPI_REPARAM_BWD (latent-sized GEMMs with the reparameterisation in the epilogue).  EPI_REPARAM: B is the
+  // stacked head weight [2 lat_lp, K] (fc21 rows, then fc22 rows); output tile column block tn covers latents
+  // [64 tn, 64 tn + 64) of BOTH heads -- the B tile's 128 rows are gathered as 16 mu rows, 16 logvar rows, 16 mu rows ...
+  // so that a wave's two column fragments hold mu and logvar of the same 16 latents and every lane owns both values of
+  // its (row, latent) pairs.  `bias` = the stacked head bias [2 lat_lp].
+  long lat_lp, lat_l;            // padded / exact latent width
+  const float* eps_in;           // [M_valid, lat_l] fp32, or NULL: Philox draws (seed, step_counter), written to eps_out
+  float* eps_out;
+  unsigned long long seed;
+  const long long* step_counter;
+  float* mulv;                   // EPI_REPARAM: out [Mp, 2 lat_lp] fp32 (mu | logvar).  EPI_REPARAM_BWD: the same tensor, read
+  bf16_t* z;                     // EPI_REPARAM: out [Mp, lat_lp] bf16
+  float* kl_partial;             // EPI_REPARAM: 4 slots per block (sum, 0, 0, 0): one per 1024 elements of the [Mp, lat_lp] grid
+  const float* eps;              // EPI_REPARAM_BWD: the eps the forward used [M_valid, lat_l]
+  float kl_beta, inv_nk;         // EPI_REPARAM_BWD: kl_beta, 1 / (B L)
+  const float* dmu_ext;          // EPI_REPARAM_BWD: gradients arriving from outside [M_valid, lat_l], or NULL
+  const float* dlv_ext;
+  bf16_t* dmulv;                 // EPI_REPARAM_BWD: out [Mp, 2 lat_lp] bf16 (dmu | dlogvar)
+  float* dbh_partial;            // EPI_REPARAM_BWD: [Mp / 16][2 lat_lp] column sums: row 4 tile_m holds the tile's, rows + 1..3 zeros
   int wt;                // non-zero: the epilogue's outputs are written through (common.h store_wt16; the launchers copy rv_store_wt)
 };
 
@@ -633,7 +658,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     if (p.step_inc && bid == 0 && tid == 0) *p.step_inc += 1;
   }
   if (!gathered) sa.init(p.lda, wave, lane);
-  sb.init(p.ldb, wave, lane);
+  const bf16_t* Bgr = Bg;
+  if constexpr (EPI == EPI_REPARAM) {
+    static_assert(B_KMAJ && BN == 128 && WTN == 32, "reparameterisation epilogue: 128-column tiles (64 latents x 2 heads), 32-column wave tiles");
+    Bgr = p.B + k0;
+    sb.init_rows([&](int r) { return (((r >> 4) & 1) * p.lat_lp + (long)tile_n * 64 + (r >> 5) * 16 + (r & 15)) * p.ldb; }, wave, lane);
+  } else {
+    sb.init(p.ldb, wave, lane);
+  }
   // by-product of the gathered operand: K tile kt of this block's rows, from its LDS image to HBM
   auto copy_out = [&](int kt, const lds_char* slot_) {
     if constexpr (A_KMAJ && EPI == EPI_BIAS_ACT_BF16 && !FP8) {
@@ -654,7 +686,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   for (int s = 0; s < NSTAGE; ++s)
     if (s < nk) {
       sa.stage(Agr + s * a_step, smem + s * STAGE, wave);
-      sb.stage(Bg + s * b_step, smem + s * STAGE + B_OFF, wave);
+      sb.stage(Bgr + s * b_step, smem + s * STAGE + B_OFF, wave);
     }
   // tile 0 landed (tiles 1..NSTAGE-1 may still be in flight)
   wait_tiles_in_flight<GL>(nk - 1 < NSTAGE - 1 ? nk - 1 : NSTAGE - 1);
@@ -707,7 +739,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     if constexpr (REFILL) {
       lds_char* rf = smem + slot * STAGE;
       sa.stage(Agr + (long)(kt + NSTAGE) * a_step, rf, wave);
-      sb.stage(Bg + (long)(kt + NSTAGE) * b_step, rf + B_OFF, wave);
+      sb.stage(Bgr + (long)(kt + NSTAGE) * b_step, rf + B_OFF, wave);
     }
     // fp8: this tile's first-half fragments are still needed by the MFMAs below, so the next tile's go to a
     // second register set and are moved over afterwards
@@ -811,12 +843,69 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     if (mask_lds) mask_dma(2 * CM, WTM / 8, mk_lds + MK_C0);   // chunks 1..: the ring is free now
   }
 
+  if constexpr (EPI == EPI_REPARAM) {
+    // The B tile's rows were gathered head-interleaved (above), so fragment (mi, 0) of this wave holds mu and fragment
+    // (mi, 1) logvar of the SAME (row, latent) pairs: lane (q, j) owns row mi * 16 + j of the wave tile and the four
+    // consecutive latents l .. l + 3.  No pairing swap, no hand-over between lanes: bias, eps, exp, z and the KL term
+    // straight on the accumulators (k_reparam_fwd's arithmetic and eps draws -- counter = the (row, 4-latent group) index
+    // over the padded [Mp, lat_lp / 4] grid --, elementwise.hip), 16-byte fp32 / 8-byte bf16 stores, 64 bytes per row
+    // and store instruction.
+    static_assert(NI == 2, "reparameterisation epilogue: one mu and one logvar fragment per wave");
+    const int q = lane >> 4, j = lane & 15;
+    const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
+    const long l = (long)tile_n * 64 + wn * 16 + 4 * q;
+    const f32x4 bm = *(const f32x4*)(p.bias + l), bv = *(const f32x4*)(p.bias + Lp_ + l);
+    const uint64_t step_ = p.step_counter ? (uint64_t)*p.step_counter : 0;
+    float kl = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const long b = m0 + wm * WTM + mi * 16 + j;
+      float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
+      if (b < p.M_valid && l < L_) {
+        float ev[4];
+        if (!p.eps_in) normal4_fast(p.seed, (uint64_t)(b * (Lp_ >> 2) + (l >> 2)), step_, ev);
+#pragma unroll
+        for (int e_ = 0; e_ < 4; ++e_) {
+          if (l + e_ < L_) {
+            float e;
+            if (p.eps_in) {
+              e = p.eps_in[b * L_ + l + e_];
+            } else {
+              e = ev[e_];
+              p.eps_out[b * L_ + l + e_] = e;
+            }
+            mua[e_] = acc[mi][0][e_] + bm[e_];
+            lva[e_] = acc[mi][1][e_] + bv[e_];
+            const float sd = __expf(0.5f * lva[e_]);
+            zz[e_] = mua[e_] + e * sd;
+            kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
+          }
+        }
+      }
+      store_out16((f32x4*)(p.mulv + b * L2p_ + l), f32x4{mua[0], mua[1], mua[2], mua[3]}, p.wt);
+      store_out16((f32x4*)(p.mulv + b * L2p_ + Lp_ + l), f32x4{lva[0], lva[1], lva[2], lva[3]}, p.wt);
+      const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
+      *(bf16x4*)(p.z + b * Lp_ + l) = zb;
+    }
+    float* red = (float*)smem_generic;
+    const float s_ = block_sum<NW>(kl, red);
+    if (tid < 4) p.kl_partial[4 * (tile_m * tiles_n + tile_n) + tid] = tid == 0 ? s_ : 0.f;
+    return;
+  }
+
   float cs[NP][8];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[t][e] = 0.f;
   float sq = 0.f;
+  float cs2[EPI == EPI_REPARAM_BWD ? NP : 1][8];   // EPI_REPARAM_BWD: column sums of dlogvar (cs: of dmu)
+  if constexpr (EPI == EPI_REPARAM_BWD) {
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs2[t][e] = 0.f;
+  }
 
   float bias[NP][8];
 #pragma unroll
@@ -1033,6 +1122,40 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           }
         }
       }
+    } else if constexpr (EPI == EPI_REPARAM_BWD) {
+      // v = dz of (row, 8 consecutive latents): k_reparam_bwd's arithmetic (elementwise.hip) on the accumulators
+      const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
+      f32x4 m8[CH][2], l8[CH][2];
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const float* mp = p.mulv + rowi[it] * L2p_ + coli[it];
+        m8[it][0] = *(const f32x4*)mp; m8[it][1] = *(const f32x4*)(mp + 4);
+        l8[it][0] = *(const f32x4*)(mp + Lp_); l8[it][1] = *(const f32x4*)(mp + Lp_ + 4);
+      }
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const long b = rowi[it], l = coli[it];
+        bf16x8 om, ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float dmu = 0.f, dlv = 0.f;
+          if (b < p.M_valid && l + e < L_) {
+            const float ee = p.eps[b * L_ + l + e];
+            const float mu_ = m8[it][e >> 2][e & 3], lv_ = l8[it][e >> 2][e & 3];
+            const float sd = __expf(0.5f * lv_);
+            dmu = v[it][e] + p.kl_beta * mu_ * p.inv_nk;
+            dlv = v[it][e] * ee * 0.5f * sd + p.kl_beta * 0.5f * (sd * sd - 1.f) * p.inv_nk;
+            if (p.dmu_ext) dmu += p.dmu_ext[b * L_ + l + e];
+            if (p.dlv_ext) dlv += p.dlv_ext[b * L_ + l + e];
+          }
+          cs[it % NP][e] += dmu;
+          cs2[it % NP][e] += dlv;
+          om[e] = (bf16_t)dmu;
+          ov[e] = (bf16_t)dlv;
+        }
+        store_out16((bf16x8*)(p.dmulv + b * L2p_ + l), om, p.wt);
+        store_out16((bf16x8*)(p.dmulv + b * L2p_ + Lp_ + l), ov, p.wt);
+      }
     } else {  // EPI_MASK_BF16
       {
         // activation > 0 tested on the bf16 bit patterns, two per 32-bit word: the high half is positive iff the word,
@@ -1092,6 +1215,46 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         float b_ = red[0];
         for (int w = 1; w < NW; ++w) b_ = fmaxf(b_, red[w]);
         p.amax_part[bid] = b_;
+      }
+    }
+  }
+  if constexpr (EPI == EPI_REPARAM_BWD) {
+    // the head biases' gradients: column sums of dmu and dlogvar over the tile's rows -- over the 16 row lanes by a
+    // butterfly, over the wave rows through LDS (the ring is free: barrier after the main loop) -- into row 4 tile_m of
+    // the [Mp / 16][2 lat_lp] partial-row table (k_reparam_bwd writes one row per 16 batch rows; the three rows this
+    // tile does not use are zeroed, so the optimizer's descriptors do not depend on which kernel ran)
+    static_assert(BM == 64, "reparameterisation backward epilogue: 64-row tiles (four 16-row slots of the bias partial table)");
+    float* red = (float*)smem_generic;
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a_ = cs[t][e], c_ = cs2[t][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a_ += __shfl_xor(a_, o, 64); c_ += __shfl_xor(c_, o, 64); }
+        cs[t][e] = a_; cs2[t][e] = c_;
+      }
+    if (ej == 0) {
+#pragma unroll
+      for (int t = 0; t < NP; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c_ = wn * WTN + (eq & 1) * 16 + (eq >> 1) * 8 + 32 * t + e;
+          red[wm * BN + c_] = cs[t][e];
+          red[(WGM + wm) * BN + c_] = cs2[t][e];
+        }
+    }
+    __syncthreads();
+    if (p.dbh_partial) {
+      const long L2p_ = 2 * p.lat_lp;
+      for (int i = tid; i < 8 * BN; i += 64 * NW) {   // 4 table rows x {dmu, dlogvar} x BN columns
+        const int row = i / (2 * BN), hd = (i / BN) & 1, c_ = i % BN;
+        float s_ = 0.f;
+        if (row == 0) {
+#pragma unroll
+          for (int w = 0; w < WGM; ++w) s_ += red[(hd * WGM + w) * BN + c_];
+        }
+        p.dbh_partial[((long)tile_m * 4 + row) * L2p_ + hd * p.lat_lp + n0 + c_] = s_;
       }
     }
   }

@@ -743,6 +743,86 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
   }
 }
 
+
+// ---- the same two launches for padded latent widths above 64 (the reference's own latent_dim = 256: default.ini:18,
+// kelsey_iterable.ini:17) ------------------------------------------------------------------------------------------------
+// The row-local kernels above make every workgroup stream ALL latent-sized weights for its 16 rows: 832 KB at Lp = 64,
+// 3 MB at Lp = 256 -- 770 MB through the L2 -> LDS ports per launch, 50 us at their ~60 GB/s each.  From Lp = 128 on
+// the heads GEMM ([Bp, 2 Lp] <- K = Hp) and dz ([Bp, Lp] <- K = Hp) are GEMMs with hundreds of output tiles, so they run
+// on gemm_bf16.h's tiled body and the elementwise steps ride in its epilogues (EPI_REPARAM, EPI_REPARAM_BWD):
+//   forward : 64 x 128 tiles, one per (64 batch rows, 64 latents x both heads) = (Bp / 64) (Lp / 64) workgroups of 8 waves
+//             (256 at the reference's shape); 24 KB per K tile through the port; mu | logvar, z, eps and the KL partials
+//             leave the accumulators directly -- no fp32 slabs, no reparameterisation launch.  fc3 (K = Lp) follows as a
+//             plain forward GEMM (rv_linear_fwd_ex): its A operand needs every latent of a row, i.e. all Lp / 64 tiles.
+//   backward: dz on 64 x 64 tiles (4 waves, two or three workgroups per CU) with the reparameterisation backward and the
+//             head biases' column sums in the epilogue; fc3's weight gradient dW3 = dP3^T z on the SAME launch's extra
+//             workgroups (the second reader of dP3, as in k_latent_bwd), one more workgroup finishes the loss scalar.
+constexpr int HG_STAGES = 4;
+constexpr int HG_LDS = HG_STAGES * (64 + 128) * 128;   // 96 KiB
+
+__global__ void __launch_bounds__(512) k_heads_reparam_gemm(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  gemm_body<64, 128, 2, 4, true, true, EPI_REPARAM, HG_STAGES>(p, blockIdx.x, smem_dyn);
+}
+
+constexpr int DZ_STAGES = 3;
+constexpr int DZ_LDS = DZ_STAGES * (64 + 64) * 128;    // 48 KiB: three workgroups per CU
+
+__global__ void __launch_bounds__(256)
+k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, const int n_w3, const long B, const long L,
+                  const long S, const float kl_beta, const float* __restrict__ mse_partial, const int n_mse,
+                  const float* __restrict__ kl_partial, const int n_kl, float* __restrict__ loss_out,
+                  const long long* __restrict__ step_counter, const int ring_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int bid = (int)blockIdx.x, tid = threadIdx.x;
+  if (bid < n_dz) {
+    gemm_body<64, 64, 2, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
+    return;
+  }
+  if (bid < n_dz + n_w3) {
+    gemm_body<64, 64, 2, 2, false, false, EPI_F32, DZ_STAGES>(w3grad, bid - n_dz, smem_dyn);
+    return;
+  }
+  if (loss_out && mse_partial && kl_partial) {   // the loss scalar (k_reparam_bwd's extra block, same summation order)
+    float* red = (float*)smem_dyn;
+    float m = 0.f, k = 0.f;
+    for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+    for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+    m = block_sum_256(m, red);
+    k = block_sum_256(k, red);
+    if (tid == 0) {
+      const float mse = m / ((float)B * (float)S);
+      const float inv_nk = 1.0f / ((float)B * (float)L);
+      const float kld = -0.5f * k * inv_nk;
+      if (step_counter && ring_n > 0) loss_out += 4 * ((*step_counter - 1) % ring_n);
+      loss_out[0] = mse + kl_beta * kld;
+      loss_out[1] = mse;
+      loss_out[2] = kld;
+    }
+  }
+}
+
+// host side of the two (called by rv_latent_fwd_ex / rv_latent_bwd for Lp > 64; arguments checked there)
+int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const float* bias_heads, long Bp, long Hp, long Lp,
+                       long B, long L, const float* eps_in, float* eps_out, unsigned long long seed,
+                       const long long* step_counter, float* mulv, void* z, float* kl_partial, hipStream_t st) {
+  GemmArgs a{};
+  a.A = (const bf16_t*)h; a.lda = ldh; a.B = (const bf16_t*)wh; a.ldb = ldwh;
+  a.k_tiles = (int)(Hp / 64); a.M_valid = (int)B; a.N_valid = (int)(2 * Lp);
+  a.tiles_m = (int)(Bp / 64); a.tiles_n = (int)(Lp / 64); a.splits = 1;
+  a.bias = bias_heads; a.lat_lp = Lp; a.lat_l = L; a.eps_in = eps_in; a.eps_out = eps_out; a.seed = seed;
+  a.step_counter = step_counter; a.mulv = mulv; a.z = (bf16_t*)z; a.kl_partial = kl_partial;
+  a.wt = rv_store_wt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, HG_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_heads_reparam_gemm, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HG_LDS, st, a);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -770,9 +850,24 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
              "rv_latent_fwd: null pointer");
   RV_REQUIRE(!heads_only || (!h3_fp8 && !amax_part), RV_ERR_UNSUPPORTED, "rv_latent_fwd: the fp8 outputs belong to fc3");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
-  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_fwd: built for a padded latent width of 64 (got %ld)", Lp);
+  RV_REQUIRE(Lp == 64 || Lp == 128 || Lp == 256, RV_ERR_UNSUPPORTED,
+             "rv_latent_fwd: serves padded latent widths of 64, 128 and 256 (got %ld)", Lp);
+  if (Lp > 64) {
+    // GEMM forms (k_heads_reparam_gemm, then fc3 as a forward GEMM): any hidden width that is a multiple of 128
+    RV_REQUIRE(Bp > 0 && Bp % 64 == 0 && Hp > 0 && Hp % 128 == 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp && ldh % 8 == 0 &&
+                   ldwh % 8 == 0 && (heads_only || (ldw3 >= Lp && ldh3 >= Hp && ldw3 % 8 == 0 && ldh3 % 8 == 0)),
+               RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld Lp %ld (Bp a multiple of 64, Hp of 128)", Bp, Hp, Lp);
+    RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
+                 (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16) & 15) == 0,
+               RV_ERR_SHAPE, "rv_latent_fwd: operands must be 16-byte aligned");
+    const int rc = heads_reparam_gemm(h_bf16, ldh, wh_bf16, ldwh, bias_heads, Bp, Hp, Lp, B, L, eps_in, eps_out, seed, step_counter,
+                                      mulv, z_bf16, kl_partial, (hipStream_t)stream);
+    if (rc || heads_only) return rc;
+    return rv_linear_fwd_ex(z_bf16, Lp, w3_bf16, ldw3, bias3, Bp, Hp, Lp, RV_ACT_RELU, h3_bf16, ldh3, h3_fp8, ldq, q_scale, amax_part,
+                            stream);
+  }
   RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
-             "rv_latent_fwd: the hidden width must be a multiple of 512 up to 2048 (got %ld)", Hp);
+             "rv_latent_fwd: the hidden width must be a multiple of 512 up to 2048 at a padded latent width of 64 (got %ld)", Hp);
   RV_REQUIRE(Bp > 0 && Bp % LAT_ROWS == 0 && Hp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp &&
                  (heads_only || (ldw3 >= Lp && ldh3 >= Hp && ldw3 % 8 == 0 && ldh3 % 8 == 0)) && ldh % 8 == 0 && ldwh % 8 == 0,
              RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld", Bp, Hp);
@@ -798,9 +893,10 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
                   const float* kl_partial, int n_kl, float* loss_out, const long long* step_counter, int ring,
                   const void* z_bf16, long ldz, float* dw3_slabs, long lddw3, int dw3_splits, void* stream) {
   RV_REQUIRE(dp3_bf16 && w3_bf16 && mulv && eps && dmulv_bf16, RV_ERR_NULL, "rv_latent_bwd: null pointer");
-  RV_REQUIRE(Lp == 64, RV_ERR_UNSUPPORTED, "rv_latent_bwd: built for a padded latent width of 64 (got %ld)", Lp);
-  RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
-             "rv_latent_bwd: the hidden width must be a multiple of 512 up to 2048 (got %ld)", Hp);
+  RV_REQUIRE(Lp == 64 || Lp == 128 || Lp == 256, RV_ERR_UNSUPPORTED,
+             "rv_latent_bwd: serves padded latent widths of 64, 128 and 256 (got %ld)", Lp);
+  RV_REQUIRE(Lp > 64 ? Hp % 64 == 0 : (Hp % 512 == 0 && Hp <= 2048), RV_ERR_UNSUPPORTED,
+             "rv_latent_bwd: the hidden width must be a multiple of 512 up to 2048 at a padded latent width of 64, of 64 above (got %ld)", Hp);
   RV_REQUIRE(Bp > 0 && Bp % 64 == 0 && B <= Bp && L <= Lp && lddp >= Hp && ldw3 >= Lp && lddp % 8 == 0 &&
                  ldw3 % 8 == 0, RV_ERR_SHAPE, "rv_latent_bwd: bad extents Bp %ld Hp %ld", Bp, Hp);
   RV_REQUIRE((((uintptr_t)dp3_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)mulv | (uintptr_t)dmulv_bf16) & 15) == 0, RV_ERR_SHAPE,
@@ -814,9 +910,29 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.A = (const bf16_t*)dp3_bf16; g.lda = lddp; g.B = (const bf16_t*)z_bf16; g.ldb = ldz;
     g.k_tiles = (int)(Bp / 64 / dw3_splits); g.M_valid = (int)Hp; g.N_valid = (int)Lp;
     g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
-    g.tiles_m = (int)(Hp / 64); g.tiles_n = 1; g.splits = dw3_splits;
+    g.tiles_m = (int)(Hp / 64); g.tiles_n = (int)(Lp / 64); g.splits = dw3_splits;
     g.wt = rv_store_wt;
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
+  }
+  if (Lp > 64) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
+    GemmArgs d{};
+    d.A = (const bf16_t*)dp3_bf16; d.lda = lddp; d.B = (const bf16_t*)w3_bf16; d.ldb = ldw3;
+    d.k_tiles = (int)(Hp / 64); d.M_valid = (int)B; d.N_valid = (int)Lp;
+    d.tiles_m = (int)(Bp / 64); d.tiles_n = (int)(Lp / 64); d.splits = 1;
+    d.lat_lp = Lp; d.lat_l = L; d.mulv = const_cast<float*>(mulv); d.eps = eps; d.kl_beta = kl_beta;
+    d.inv_nk = 1.0f / ((float)B * (float)L); d.dmu_ext = dmu_ext; d.dlv_ext = dlv_ext;
+    d.dmulv = (bf16_t*)dmulv_bf16; d.dbh_partial = dbh_partial;
+    d.wt = rv_store_wt;
+    const int n_dz = d.tiles_m * d.tiles_n;
+    static bool attr_gemm = false;
+    if (!attr_gemm) {
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
+      attr_gemm = true;
+    }
+    hipLaunchKernelGGL(k_dz_reparam_gemm, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(256), DZ_LDS, (hipStream_t)stream, d, g, n_dz, n_w3,
+                       B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
+    RV_CHECK_LAUNCH();
+    return RV_OK;
   }
   static bool attr_done = false;
   if (!attr_done) {

@@ -487,6 +487,28 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
   return plan_set_slab_dtype(p, p->slab_dtype);
 }
 
+// Which tensors' optimizer updates ride beside fc1's weight gradient in the full local step (launch 7: the GEMM fills half
+// the chip for ~30 us, its rider blocks stream ~2.8 TB/s from the other half): tensors [first, 10) of the table, the rest
+// goes into the step's last launch, which runs on all CUs at ~4.8 TB/s.  first = 2 (everything but fc1, ~91 MB) at C2's
+// latent width of 64; at the reference's own latent_dim = 256 that set is 152 MB and made launch 7 twice as long as its
+// GEMM (60 us; profiles/r06_first_look.txt), so the heads' tensors move to the last launch: the smallest of {2, 6, 8}
+// whose bytes fit what the riders move in the GEMM's time.
+static long desc_bytes(const rv_param_desc& d) {
+  const long el = d.rows * d.cols;
+  return el * (d.shadow_bf16 ? 26 : 28) + el * d.grad_splits * (d.grad_half ? 2 : 4);
+}
+static int rider_first(const rv_plan* p) {
+  const long budget = 100L * 1000 * 1000;
+  for (int first : {2, 6, 8}) {
+    long n = 0;
+    for (int i = first; i < 10; ++i) n += desc_bytes(p->d_slab[i]);
+    if (n <= budget) return first;
+  }
+  return 8;
+}
+
+long rv_plan_rider_first(const rv_plan* p) { return p && p->bound ? rider_first(p) : -1; }
+
 int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
   RV_REQUIRE(p && p->bound && out10, RV_ERR_STATE, "rv_plan_descs: plan not bound");
   for (int i = 0; i < 10; ++i) out10[i] = from_flat ? p->d_flat[i] : p->d_slab[i];
@@ -574,9 +596,14 @@ static int fc4_backward(rv_plan* p, void* stream) {
 
 // The latent-sized backward between the fc4 pair and fc1's weight gradient: dz, the reparameterisation backward (which
 // also finishes the loss), fc3's weight gradient, and the heads' dgrad + wgrad.  Row-local form (RV_OPT_LATENT_FUSED,
-// padded latent width 64): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of the same launch) and the
-// heads' backward -- two launches.  Otherwise three: dz + dW3 as split-K slabs, rv_reparam_bwd, the heads' backward.
-static bool latent_bwd_fused(const rv_plan* p) { return p->latent_fused && p->Lp == 64 && p->Hp % 512 == 0 && p->Hp <= 2048; }
+// padded latent width 64; its GEMM form above that): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of
+// the same launch) and the heads' backward -- two launches.  Otherwise three: dz + dW3 as split-K slabs, rv_reparam_bwd,
+// the heads' backward.
+// (padded latent width 64: the row-local kernels, hidden width a multiple of 512 up to 2048; 128 / 256 -- the reference's
+// own latent_dim = 256 -- : the GEMM forms with the reparameterisation in their epilogues, csrc/latent.hip)
+static bool latent_bwd_fused(const rv_plan* p) {
+  return p->latent_fused && (p->Lp == 64 ? p->Hp % 512 == 0 && p->Hp <= 2048 : p->Hp % 128 == 0);
+}
 
 static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, const float* dmu_ext, const float* dlv_ext,
                             void* stream, bool f8_w1 = false) {
@@ -654,8 +681,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     const int n_amax2 = f8_w1 ? p->n_amax_dp1 : 0;
     int n_amax = 0;
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
-    const bool latent_fused = p->latent_fused && Lp == 64 && Hp % 512 == 0 && Hp <= 2048;
-    if (p->fp8 && latent_fused) {
+    const bool latent_fused = latent_bwd_fused(p);   // (same shapes both ways)
+    if (p->fp8 && latent_fused && Lp == 64) {
       n_amax = (int)(Bp / 16) * 8;   // one maximum per wave of rv_latent_fwd_ex
       RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_STATE, "rv_plan_step: h3_amax holds %d entries, the fused latent forward writes %d", p->n_amax_cap, n_amax);
     } else if (p->fp8) {
@@ -758,6 +785,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
     // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
+    int rf = 2;   // first tensor of the table whose update rides beside fc1's weight gradient (rider_first)
     {
       Range r(p->roctx, "rv:fc4-bwd");
       RV_K(4, fc4_backward(p, stream));
@@ -773,17 +801,18 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
       // (fp8 operands: only fc4's update riding here and the rest in the last launch was tried in round 5 -- 166.2-167.1 us
       // per step against 164.0-164.2 with the whole table riding and the GEMM blocks taking 15 % of it: profiles/r05_fp8_riders.txt)
+      rf = rider_first(p);
       if (f8_w1)
         RV_K(7, rv_linear_wgrad_adam_fp8(p->ws("dP1q"), Hp, p->ws("xq"), Sp, (float*)p->ws("fp8_state") + 15, Hp, Sp, Bp, p->s_w1,
-                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2, 8, p->b.param, p->b.exp_avg,
+                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + rf, 10 - rf, p->b.param, p->b.exp_avg,
                                          p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter, 256 - n_gemm, stream));
       else
-        RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + 2,
-                                     8, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+        RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + rf,
+                                     10 - rf, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                      p->b.step_counter, 256 - n_gemm, stream));
     }
     Range r(p->roctx, "rv:adam");
-    RV_K(8, rv_adam_multi(p->d_slab, 2, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
+    RV_K(8, rv_adam_multi(p->d_slab, rf, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                           p->b.step_counter, stream));
     return fp8_after_update(p, stream);
   }

@@ -467,6 +467,11 @@ class TrainEngine:
         lib().rv_plan_descs(self._plan, arr, int(bool(from_flat)))
         return list(arr)
 
+    def rider_first(self):
+        """Tensors [first, 10) of the descriptor table are updated beside fc1's weight gradient, [0, first) by the step's
+        last launch (`rv_plan_rider_first`)."""
+        return int(lib().rv_plan_rider_first(self._plan))
+
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""
         n = C.c_long()
