@@ -79,11 +79,14 @@ def parse():
 
 # ---------------------------------------------------------------------------------------------- per-launch accounting
 def step_launches(eng):
-    """The nine launches of the C2 step in issue order: (name, algorithmic FLOPs, algorithmic HBM bytes).  FLOPs are
-    SURVEY 8d's 2 x MACs of the contractions in the launch; bytes are every operand read once and every output
-    written once at the element types the step uses (bf16 activations, fp32 frames / latent tensors, fp16
-    block-floating-point slabs for dW1 / dW4, fp32 slabs elsewhere; Adam: 12 B read + 12 B written + 2 B shadow per
-    parameter plus its gradient slabs)."""
+    """The launches of one training step in issue order, grouped as the plan groups them (rv_plan_diag_skip bit k leaves
+    group k out): (name, algorithmic FLOPs, algorithmic HBM bytes).  Any model / batch shape: at a padded latent width
+    of 64 (C2) group 2 is the row-local k_latent_fwd, above it (the reference's own latent_dim = 256) the heads GEMM with
+    the reparameterisation in its epilogue followed by fc3's GEMM; groups 5 / 6 likewise.  FLOPs are SURVEY 8d's 2 x MACs
+    of the contractions in the group; bytes are every operand read once and every output written once at the element
+    types the step uses (bf16 activations, fp32 frames / latent tensors, fp16 block-floating-point slabs for dW1 / dW4,
+    fp32 slabs elsewhere; Adam: 12 B read + 12 B written + 2 B shadow per parameter plus its gradient slabs)."""
+    S, H, L, B = eng.S, eng.H, eng.L, eng.B
     Bp, Sp, Hp, Lp = eng.padded()
     sb = 2 if eng.slab_dtype == "fp16" else 4
     descs = eng.plan_descs()
@@ -99,23 +102,30 @@ def step_launches(eng):
     names = ["fc1", "fc1", "fc21", "fc21", "fc22", "fc22", "fc3", "fc3", "fc4", "fc4"]
     riders = ", ".join(dict.fromkeys(names[rf:]))
     tail = ", ".join(dict.fromkeys(names[:rf]))
+    dims = "%dx%dx%d" % (B, H, S)
+    rowlocal = Lp == 64
     rows = [
         ("k_cast_pad_bf16 (frames fp32 -> padded bf16 operand)", 0.0, B * S * 4 + Bp * Sp * 2),
-        ("gemm_bf16_kernel<256,128> fc1 forward: relu(x W1^T + b1) 4096x2048x1024", 2.0 * B * S * H,
+        ("fc1 forward GEMM: relu(x W1^T + b1) %s" % dims, 2.0 * B * S * H,
          Bp * Sp * 2 + Hp * Sp * 2 + Bp * Hp * 2),
-        ("k_latent_fwd: heads GEMM + reparameterisation + KL partials + fc3 (row-local)", 2.0 * B * H * 2 * L + 2.0 * B * L * H,
-         Bp * Hp * 2 + Bp * Hp * 2 + (2 * Lp * Hp + Hp * Lp) * 2 + Bp * 2 * Lp * 4 + Bp * Lp * (4 + 2)),
-        ("gemm_bf16_kernel<128,128> fc4 forward + tanh + MSE partials + dP4: 4096x1024x2048", 2.0 * B * H * S,
+        (("k_latent_fwd: heads GEMM + reparameterisation + KL partials + fc3 (row-local)" if rowlocal else
+          "k_heads_reparam_gemm (heads GEMM, 64x128 tiles, reparameterisation + KL partials in the epilogue) + fc3 forward GEMM"),
+         2.0 * B * H * 2 * L + 2.0 * B * L * H,
+         Bp * Hp * 2 + Bp * Hp * 2 + (2 * Lp * Hp + Hp * Lp) * 2 + Bp * 2 * Lp * 4 + Bp * Lp * (4 + 2) + (0 if rowlocal else Bp * Lp * 2)),
+        ("fc4 forward GEMM + tanh + MSE partials + dP4: %dx%dx%d" % (B, S, H), 2.0 * B * H * S,
          Bp * Hp * 2 + Sp * Hp * 2 + B * S * 4 + Bp * Sp * 2),
-        ("gemm_dgrad_wgrad_kernel<256,256> fc4 backward, one launch: dX=relu'(dY W) 4096x2048x1024 + dW=dY^T X "
-         "1024x2048x4096 split-K %d, %s slabs" % (s_w4, eng.slab_dtype), 4.0 * B * H * S,
+        ("fc4 backward: dX=relu'(dY W) %s + dW=dY^T X %dx%dx%d split-K %d, %s slabs (one paired 256x256 launch where the extents "
+         "allow)" % (dims, S, H, B, s_w4, eng.slab_dtype), 4.0 * B * H * S,
          Bp * Sp * 2 + Sp * Hp * 2 + Bp * Hp * 2 + Bp * Hp * 2 + s_w4 * Sp * Hp * sb),
-        ("k_latent_bwd: dz = dP3 W3 + reparameterisation backward + dW3 (co-resident workgroups)", 4.0 * B * H * L,
+        (("k_latent_bwd: dz = dP3 W3 + reparameterisation backward + dW3 (co-resident workgroups)" if rowlocal else
+          "k_dz_reparam_gemm: dz = dP3 W3 on 64x128 tiles with the reparameterisation backward in the epilogue + dW3 on 128x128 "
+          "tiles, one launch"), 4.0 * B * H * L,
          Bp * Hp * 2 + Hp * Lp * 2 + Bp * Lp * 2 + Bp * 2 * Lp * (4 + 2) + Bp * Lp * 4 + descs[6].grad_splits * Hp * Lp * 4),
-        ("k_heads_bwd: dP1 = relu'(dmulv Wh) + dWh, one pass over h1", 4.0 * B * H * 2 * L,
-         Bp * Hp * 2 + Bp * 2 * Lp * 2 + Bp * Hp * 2 + descs[2].grad_splits * 2 * Lp * Hp * 4),
-        ("gemm_wgrad_adam_kernel fc1 weight gradient dW=dY^T X 2048x1024x4096 split-K %d (%s slabs) on 128 CUs + Adam of "
-         "%s on the other 128" % (s_w1, eng.slab_dtype, riders), 2.0 * B * S * H,
+        (("k_heads_bwd: dP1 = relu'(dmulv Wh) + dWh, one pass over h1" if rowlocal else
+          "heads backward: dP1 = relu'(dmulv Wh) + dWh = dmulv^T h1"), 4.0 * B * H * 2 * L,
+         Bp * Hp * 2 + Bp * 2 * Lp * 2 + Bp * Hp * 2 + descs[2].grad_splits * 2 * Lp * Hp * (2 if descs[2].grad_half else 4)),
+        ("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs) + Adam of %s beside it (rider blocks)" % (
+            H, S, B, s_w1, eng.slab_dtype, riders), 2.0 * B * S * H,
          Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + adam_bytes(descs[rf:10])),
         ("k_adam<true> Adam of %s (sums the gradient slabs, %d of dW1; refreshes the bf16 shadows)" % (tail, s_w1), 0.0,
          adam_bytes(descs[0:rf])),

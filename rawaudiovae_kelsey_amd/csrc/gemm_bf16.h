@@ -312,7 +312,10 @@ __device__ __forceinline__ unsigned long long pack_fp8x8(const float (&v)[8]) {
 // Wait until at most `tiles` staged tiles (GL LDS-DMA instructions each) are still in flight.
 template <int GL>
 __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
-  if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GL) : "memory");
+  if (tiles >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * GL < 63 ? 6 * GL : 63) : "memory");
+  else if (tiles == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * GL < 63 ? 5 * GL : 63) : "memory");
+  else if (tiles == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GL < 63 ? 4 * GL : 63) : "memory");
+  else if (tiles == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GL) : "memory");
   else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GL) : "memory");
   else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -513,7 +516,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 16, NI = WTN / 16;
   constexpr int GL = STAGE / 1024 / NW;  // LDS-DMA instructions per wave per tile
   constexpr bool PINGPONG = NSTAGE == 8;    // 256x256 ping-pong main loop (2 LDS buffers)
-  static_assert(PINGPONG || (NSTAGE >= 2 && NSTAGE <= 5 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
+  // (deep rings -- 6 or 7 slots of a small tile -- exist for the latent-sized GEMMs: what a CU pulls through its L2 -> LDS port
+  // is bytes in flight / latency, and three 24 KB tiles in flight gave 43 GB/s where the port does 60-70)
+  static_assert(PINGPONG || (NSTAGE >= 2 && NSTAGE <= 7 && (NSTAGE - 1) * GL < 64), "vmcnt is a 6-bit counter");
   static_assert(!PINGPONG || (BM == 256 && BN == 256 && WGM == 2 && WGN == 4), "ping-pong loop: 256x256, 2x4 waves");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -596,7 +601,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         mpf[it] = *(const i32x4_*)(p.mask + (roww + 16 * (it / NP)) * p.ld_mask + colw + 32 * (it % NP));
     }
   }
-  if constexpr (PF_X || PF_MASK) {
+  // ... and the reparameterisation epilogues' operands: mu | logvar and eps of the lane's (row, latent) items (EPI_REPARAM_BWD:
+  // 6 x 16 bytes per item), eps of its rows (EPI_REPARAM); eps as 16-byte loads where the exact latent width is a multiple
+  // of 4 and the item lies inside the valid extent -- everything else is read in the epilogue, element by element.
+  constexpr bool PF_RB = EPI == EPI_REPARAM_BWD, PF_RF = EPI == EPI_REPARAM;
+  static_assert(!PF_RB || MI == CM, "reparameterisation backward epilogue: one chunk");
+  f32x4 rb_m[PF_RB ? CH : 1][2], rb_l[PF_RB ? CH : 1][2], rb_e[PF_RB ? CH : (PF_RF ? MI : 1)][2];
+  bool rb_vec[PF_RB ? CH : (PF_RF ? MI : 1)];
+  if constexpr (PF_RB) {
+    const long L2p_ = 2 * p.lat_lp, L_ = p.lat_l;
+    const bool al = (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      const long r_ = roww + 16 * (it / NP), c_ = colw + 32 * (it % NP);
+      const float* mp = p.mulv + r_ * L2p_ + c_;
+      rb_m[it][0] = *(const f32x4*)mp; rb_m[it][1] = *(const f32x4*)(mp + 4);
+      rb_l[it][0] = *(const f32x4*)(mp + p.lat_lp); rb_l[it][1] = *(const f32x4*)(mp + p.lat_lp + 4);
+      rb_vec[it] = al && r_ < p.M_valid && c_ + 8 <= L_;
+      rb_e[it][0] = rb_e[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rb_vec[it]) {
+        rb_e[it][0] = *(const f32x4*)(p.eps + r_ * L_ + c_);
+        rb_e[it][1] = *(const f32x4*)(p.eps + r_ * L_ + c_ + 4);
+      }
+    }
+  }
+  if constexpr (PF_RF) {
+    const long L_ = p.lat_l, l_ = (long)tile_n * 64 + wn * 16 + 4 * (lane >> 4);
+    const bool al = p.eps_in && (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps_in) & 15) == 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const long b_ = m0 + wm * WTM + mi * 16 + (lane & 15);
+      rb_vec[mi] = al && b_ < p.M_valid && l_ + 4 <= L_;
+      rb_e[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rb_vec[mi]) rb_e[mi][0] = *(const f32x4*)(p.eps_in + b_ * L_ + l_);
+    }
+  }
+  if constexpr (PF_X || PF_MASK || PF_RB || PF_RF) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);   // keep these loads ahead of the ring's first LDS-DMA
   }
@@ -869,7 +909,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
           if (l + e_ < L_) {
             float e;
             if (p.eps_in) {
-              e = p.eps_in[b * L_ + l + e_];
+              e = rb_vec[mi] ? rb_e[mi][0][e_] : p.eps_in[b * L_ + l + e_];
             } else {
               e = ev[e_];
               p.eps_out[b * L_ + l + e_] = e;
@@ -1125,13 +1165,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     } else if constexpr (EPI == EPI_REPARAM_BWD) {
       // v = dz of (row, 8 consecutive latents): k_reparam_bwd's arithmetic (elementwise.hip) on the accumulators
       const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
-      f32x4 m8[CH][2], l8[CH][2];
-#pragma unroll
-      for (int it = 0; it < CH; ++it) {
-        const float* mp = p.mulv + rowi[it] * L2p_ + coli[it];
-        m8[it][0] = *(const f32x4*)mp; m8[it][1] = *(const f32x4*)(mp + 4);
-        l8[it][0] = *(const f32x4*)(mp + Lp_); l8[it][1] = *(const f32x4*)(mp + Lp_ + 4);
-      }
+      // (mu | logvar and, where 16-byte loads were possible, eps of these items were fetched before the main loop)
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         const long b = rowi[it], l = coli[it];
@@ -1140,8 +1174,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         for (int e = 0; e < 8; ++e) {
           float dmu = 0.f, dlv = 0.f;
           if (b < p.M_valid && l + e < L_) {
-            const float ee = p.eps[b * L_ + l + e];
-            const float mu_ = m8[it][e >> 2][e & 3], lv_ = l8[it][e >> 2][e & 3];
+            const float ee = rb_vec[it] ? rb_e[it][e >> 2][e & 3] : p.eps[b * L_ + l + e];
+            const float mu_ = rb_m[it][e >> 2][e & 3], lv_ = rb_l[it][e >> 2][e & 3];
             const float sd = __expf(0.5f * lv_);
             dmu = v[it][e] + p.kl_beta * mu_ * p.inv_nk;
             dlv = v[it][e] * ee * 0.5f * sd + p.kl_beta * 0.5f * (sd * sd - 1.f) * p.inv_nk;

@@ -754,21 +754,23 @@ k_heads_bwd(const bf16_t* __restrict__ dmulv, const bf16_t* __restrict__ Wh, con
 //             (256 at the reference's shape); 24 KB per K tile through the port; mu | logvar, z, eps and the KL partials
 //             leave the accumulators directly -- no fp32 slabs, no reparameterisation launch.  fc3 (K = Lp) follows as a
 //             plain forward GEMM (rv_linear_fwd_ex): its A operand needs every latent of a row, i.e. all Lp / 64 tiles.
-//   backward: dz on 64 x 64 tiles (4 waves, two or three workgroups per CU) with the reparameterisation backward and the
-//             head biases' column sums in the epilogue; fc3's weight gradient dW3 = dP3^T z on the SAME launch's extra
-//             workgroups (the second reader of dP3, as in k_latent_bwd), one more workgroup finishes the loss scalar.
-constexpr int HG_STAGES = 4;
-constexpr int HG_LDS = HG_STAGES * (64 + 128) * 128;   // 96 KiB
+//   backward: dz on 64 x 128 tiles (8 waves, 24 KB per K tile) with the reparameterisation backward and the head biases'
+//             column sums in the epilogue; fc3's weight gradient dW3 = dP3^T z on the SAME launch's extra workgroups (the
+//             second reader of dP3, as in k_latent_bwd) on 128 x 128 tiles; two workgroups share a CU (72 KiB each); one
+//             more workgroup finishes the loss scalar.  (A first version ran both on 64 x 64 tiles of 4 waves: 29.2 us at the
+//             reference's shape -- 268 MB through the L2 -> LDS ports for 8.6 GFLOP; these tiles move 167 MB.)
+constexpr int HG_STAGES = 6;                            // five 24 KB tiles in flight per CU (four stages: 19.5 us, 43 GB/s per CU)
+constexpr int HG_LDS = HG_STAGES * (64 + 128) * 128;   // 144 KiB
 
 __global__ void __launch_bounds__(512) k_heads_reparam_gemm(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   gemm_body<64, 128, 2, 4, true, true, EPI_REPARAM, HG_STAGES>(p, blockIdx.x, smem_dyn);
 }
 
-constexpr int DZ_STAGES = 3;
-constexpr int DZ_LDS = DZ_STAGES * (64 + 64) * 128;    // 48 KiB: three workgroups per CU
+constexpr int DZ_STAGES = 5, DW3_STAGES = 2;
+constexpr int DZ_LDS = DZ_STAGES * (64 + 64) * 128;     // 80 KiB (the dW3 blocks use 64 of them): two workgroups per CU
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, const int n_w3, const long B, const long L,
                   const long S, const float kl_beta, const float* __restrict__ mse_partial, const int n_mse,
                   const float* __restrict__ kl_partial, const int n_kl, float* __restrict__ loss_out,
@@ -776,20 +778,23 @@ k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, cons
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int bid = (int)blockIdx.x, tid = threadIdx.x;
   if (bid < n_dz) {
-    gemm_body<64, 64, 2, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
+    gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
     return;
   }
   if (bid < n_dz + n_w3) {
-    gemm_body<64, 64, 2, 2, false, false, EPI_F32, DZ_STAGES>(w3grad, bid - n_dz, smem_dyn);
+    gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid - n_dz, smem_dyn);
     return;
   }
   if (loss_out && mse_partial && kl_partial) {   // the loss scalar (k_reparam_bwd's extra block, same summation order)
     float* red = (float*)smem_dyn;
     float m = 0.f, k = 0.f;
-    for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
-    for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
-    m = block_sum_256(m, red);
-    k = block_sum_256(k, red);
+    // (threads 0..255 only: k_reparam_bwd's extra block has 256 threads, and the sums must come out bit-equal to its)
+    if (tid < 256) {
+      for (int i = tid; i < n_mse; i += 256) m += mse_partial[i];
+      for (int i = tid; i < n_kl; i += 256) k += kl_partial[i];
+    }
+    m = block_sum<8>(m, red);
+    k = block_sum<8>(k, red);
     if (tid == 0) {
       const float mse = m / ((float)B * (float)S);
       const float inv_nk = 1.0f / ((float)B * (float)L);
@@ -912,6 +917,10 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
     g.tiles_m = (int)(Hp / 64); g.tiles_n = (int)(Lp / 64); g.splits = dw3_splits;
     g.wt = rv_store_wt;
+    if (Lp > 64) {   // (the GEMM form's dW3 blocks run on 128 x 128 tiles)
+      RV_REQUIRE(Hp % 128 == 0, RV_ERR_SHAPE, "rv_latent_bwd: the hidden width must be a multiple of 128 (got %ld)", Hp);
+      g.tiles_m = (int)(Hp / 128); g.tiles_n = (int)(Lp / 128);
+    }
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
   if (Lp > 64) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
@@ -929,7 +938,7 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
       (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
       attr_gemm = true;
     }
-    hipLaunchKernelGGL(k_dz_reparam_gemm, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(256), DZ_LDS, (hipStream_t)stream, d, g, n_dz, n_w3,
+    hipLaunchKernelGGL(k_dz_reparam_gemm, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), DZ_LDS, (hipStream_t)stream, d, g, n_dz, n_w3,
                        B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
     RV_CHECK_LAUNCH();
     return RV_OK;

@@ -81,6 +81,7 @@ struct rv_plan {
   // n_mt1_gen partial rows of fc1's bias gradient) and the streaming kernel rv_heads_bwd (hb_groups of both; 0 = the
   // shape does not allow it); s_wh / n_mt1 and the descriptors follow the form in use (heads_mode_apply)
   int s_wh_gen = 1, n_mt1_gen = 1, hb_groups = 0;
+  int heads_pair_gen = 0;   // the generic form is the paired 256 x 256 launch (rv_dgrad_wgrad_pick): its dWh slabs may be fp16
   long off[10];                               // element offsets of the 10 params in the flat arenas
   long n_params;
   std::vector<Buf> bufs;
@@ -177,8 +178,10 @@ static void heads_mode_apply(rv_plan* p) {
   p->d_slab[2].grad_splits = p->s_wh;
   p->d_slab[4].grad_splits = p->s_wh;
   // The streaming heads' backward writes its dWh slabs in the element type of the large weight gradients' (RV_OPT_SLAB_DTYPE):
-  // block-floating-point fp16 by default (rv_heads_bwd_ex), fp32 in the generic form and in the strict mode
-  const bool half = st && p->slab_dtype == RV_SLAB_F16 && p->Lp == 64 && p->Hp % 32 == 0;
+  // block-floating-point fp16 by default (rv_heads_bwd_ex), and so does the generic form where it is the paired 256 x 256
+  // launch (the reference's own latent_dim = 256: eight 512 x 2048 slabs, 32 MB as fp32 -- written by that launch and read
+  // back by the optimizer); fp32 in the generic form's smaller tilings and in the strict mode
+  const bool half = p->slab_dtype == RV_SLAB_F16 && p->Hp % 32 == 0 && (st ? p->Lp == 64 : p->heads_pair_gen != 0);
   p->heads_half = half;
   float* dWh = (float*)p->ws("dWh");
   float* us = (float*)p->ws("dWh_us");
@@ -229,6 +232,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     int paired = 0, bm = 128, sp = 1;
     rv_dgrad_wgrad_pick(Bp, Hp, L2p, &paired, &bm, &sp);
     p->s_wh = p->s_wh_gen = sp;
+    p->heads_pair_gen = paired;
     p->n_mt1 = p->n_mt1_gen = (int)(Bp / bm);
     p->hb_groups = (Lp == 64 && Bp % 512 == 0 && Hp % 64 == 0) ? (int)(Bp / 512) : 0;
   }
@@ -275,7 +279,8 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     p->s_w1_ddp = 2 * p->s_w1;
   p->add("dW1", (long)p->s_w1_ddp * Hp * Sp * 4);
   p->add("dWh", (long)(p->s_wh_gen > p->hb_groups ? p->s_wh_gen : p->hb_groups) * L2p * Hp * 4);
-  p->add("dWh_us", (long)(p->hb_groups > 0 ? p->hb_groups : 1) * 4 * (Hp / 32 + 1) * 4);   // fp16 dWh slabs: 2^-e per slab and granule
+  // fp16 dWh slabs: 2^-e per slab and 32 x 32 granule ([slabs][2 Lp / 32][Hp / 32])
+  p->add("dWh_us", (long)(p->hb_groups > p->s_wh_gen ? p->hb_groups : p->s_wh_gen) * (L2p / 32) * (Hp / 32 + 1) * 4);
   p->add("dW3", (long)p->s_w3 * Hp * Lp * 4);
   p->add("dW4", (long)p->s_w4 * Sp * Hp * 4);
   p->add("dW1_us", (long)p->s_w1_ddp * (Hp / 32) * (Sp / 32) * 4);   // fp16 slabs: 2^-e per 32 x 32 granule and slab
@@ -631,7 +636,8 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
       return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
                              nullptr, 0, nullptr, nullptr, p->heads_half ? (float*)p->ws("dWh_us") : nullptr, stream);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                                 p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, stream);
+                                 p->ws("dWh"), Hp, p->s_wh, p->heads_half ? RV_SLAB_F16 : RV_SLAB_F32,
+                                 p->heads_half ? (float*)p->ws("dWh_us") : nullptr, stream);
   }
   if (do_latent) {
     rc = rv_linear_dgrad_wgrad_f32(dP3, Hp, p->ws("W3b"), Lp, z, Lp, Bp, Lp, Hp, dz_slabs, Lp, p->s_dz, (float*)p->ws("dW3"), Lp,
@@ -643,7 +649,8 @@ static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, co
   }
   if (!do_heads) return RV_OK;
   return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"), p->ws("dWh"), Hp,
-                               p->s_wh, RV_SLAB_F32, nullptr, stream);
+                               p->s_wh, p->heads_half ? RV_SLAB_F16 : RV_SLAB_F32, p->heads_half ? (float*)p->ws("dWh_us") : nullptr,
+                               stream);
 }
 
 int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float* recon_out,
@@ -770,7 +777,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       return rv_heads_bwd_ex(dmulv, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, Lp, dP1, Hp, (float*)p->ws("db1p"), (float*)p->ws("dWh"), Hp,
                              nullptr, 0, nullptr, nullptr, p->heads_half ? (float*)p->ws("dWh_us") : nullptr, st);
     return rv_linear_dgrad_wgrad(dmulv, L2p, p->ws("Whb"), Hp, h1, Hp, Bp, Hp, L2p, dP1, Hp, (float*)p->ws("db1p"),
-                                 (float*)p->ws("dWh"), Hp, p->s_wh, RV_SLAB_F32, nullptr, st);
+                                 (float*)p->ws("dWh"), Hp, p->s_wh, p->heads_half ? RV_SLAB_F16 : RV_SLAB_F32,
+                                 p->heads_half ? (float*)p->ws("dWh_us") : nullptr, st);
   };
   RV_REQUIRE(!(full_local && (p->ext_d_recon || p->ext_dmu || p->ext_dlv)), RV_ERR_STATE,
              "rv_plan_step: external gradients are set (rv_plan_set_external_grads); run the backward phases without ADAM");

@@ -346,7 +346,7 @@ def test_latent_forward_one_launch_vs_three_in_the_step():
     assert float(d.mean()) < 2e-5 and float(d.max()) <= 5 * 2 * 1e-3 + 1e-6
 
 
-@pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 384, 100, 130)])
+@pytest.mark.parametrize("shape", [(1024, 2048, 64, 4096), (256, 384, 100, 130), (1024, 2048, 256, 4096)])
 def test_fp16_split_k_slabs_vs_fp32_slabs(shape):
     """slab_dtype="fp16" (the default): the split-K partials of dW1 / dW4 -- and, where the streaming heads' backward
     runs (C2), the eight row-group partials of the two heads' weight gradients -- are stored as block-floating-point fp16
@@ -365,7 +365,9 @@ def test_fp16_split_k_slabs_vs_fp32_slabs(shape):
         torch.cuda.synchronize()
         out[dt] = ({k: v.clone() for k, v in e.grad_views().items()}, e.last_loss())
     assert out["fp16"][1] == out["fp32"][1]
-    heads16 = shape == (1024, 2048, 64, 4096)      # the streaming heads' backward: batch a multiple of 512, latent width 64
+    # the streaming heads' backward (batch a multiple of 512, latent width 64), or -- the reference's own latent width -- the
+    # heads' backward as the paired 256 x 256 launch: the heads' slabs are fp16 as well
+    heads16 = shape in ((1024, 2048, 64, 4096), (1024, 2048, 256, 4096))
     for k in PARAM_NAMES:
         a, b = out["fp16"][0][k], out["fp32"][0][k]
         if k in ("fc1.weight", "fc4.weight") or (heads16 and k in ("fc21.weight", "fc22.weight")):
