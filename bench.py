@@ -24,7 +24,8 @@ Rank 0 prints ONE JSON line.  `roofline` is for the LONGEST launch of the step, 
 step is timed IN the step with HIP events (a hipGraph of steps minus the same graph without that launch; `kernels` holds
 all nine rows).  `cpu_baseline` is the stock-PyTorch CPU port of the same step (oracle/torch_port.py) timed on this node's
 host cores (N=1 only).  Side lines at N=1 (never the headline; `--no-alts` skips them): `alt_fp8` / `alt_fp8_forward_only`
-(the fp8 weight path), `alt_fp32_slabs`, `alt_deep_c4` (BASELINE configs[3]) and `alt_api_loop` (the reference's loop
+(the fp8 weight path), `alt_ref_ini` / `alt_default_ini` (the reference's own model, latent_dim 256, at batch 4096 and at
+default.ini's 131072, with every launch timed in the step), `alt_fp32_slabs`, `alt_deep_c4` (BASELINE configs[3]) and `alt_api_loop` (the reference's loop
 unchanged through `rawvae.model` + `torch.optim.Adam`; host-bound).
 """
 import argparse
@@ -695,6 +696,51 @@ def main():
                             "final_loss": e2.losses(1)[-1], "repeats": len(reps)}
                 except Exception as exc:   # the headline is already measured: report, do not lose it
                     return {"what": what, "error": str(exc)[:200]}
+            def time_shape(what, S2, H2, L2, B2):
+                """The training step at another model / batch shape (the reference's own .ini files), timed as the headline
+                is (eager launches, median over passes) with every launch group timed in the step (`kernels`)."""
+                try:
+                    torch.cuda.empty_cache()
+                    n_pool = 2 if B2 > 16384 else POOL
+                    steps2 = max(5, args.steps * 4096 // max(B2, 4096))
+                    pool2 = [torch.from_numpy(make_frames(B2, S2, 7000 + i)).to(dev) for i in range(n_pool)]
+                    e2 = E.TrainEngine(S2, H2, L2, B2, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
+                    e2.load_params(make_params(S2, H2, L2, 0))
+                    for i in range(max(3, min(args.warmup, steps2))):
+                        e2.step(pool2[i % n_pool], stream=comp)
+                    torch.cuda.synchronize()
+                    reps = []
+                    for r in range(5):
+                        t0 = time.perf_counter()
+                        for i in range(steps2):
+                            e2.step(pool2[(r * steps2 + i) % n_pool], stream=comp)
+                        torch.cuda.synchronize()
+                        reps.append(time.perf_counter() - t0)
+                    reps.sort()
+                    med = reps[len(reps) // 2]
+                    fps = float(B2) * steps2 / med
+                    rows, noise = time_launches_in_step(e2, pool2[0], steps=max(1, 10 * 4096 // max(B2, 4096)))
+                    out2 = {"what": what, "workload": "S=%d H=%d L=%d, per-GPU batch %d" % (S2, H2, L2, B2),
+                            "ms_per_step": med / steps2 * 1e3, "value": fps, "steps": steps2, "repeats": len(reps),
+                            "flops_per_frame": flops_per_frame(S2, H2, L2),
+                            "step_tflops": fps * flops_per_frame(S2, H2, L2) / 1e12,
+                            "step_mfma_frac": fps * flops_per_frame(S2, H2, L2) / 1e12 / PEAK_BF16_TFLOPS,
+                            "final_loss": e2.losses(1)[-1], "sum_of_launches_us": sum(r_["us"] for r_ in rows),
+                            "method_noise_us": noise,
+                            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r_.items()} for r_ in rows]}
+                    del e2, pool2
+                    torch.cuda.empty_cache()
+                    return out2
+                except Exception as exc:
+                    return {"what": what, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+            # the reference's own configurations (never the headline: BASELINE.json quotes the metric on configs[1] = C2)
+            alts["alt_ref_ini"] = time_shape(
+                "the reference's own model -- segment_length 1024, n_units 2048, latent_dim 256 (default.ini:3,18-19; "
+                "kelsey_iterable.ini:17-18) -- at the batch its HPC run used (kelsey_iterable.ini:26: 4096): the latent-sized "
+                "launches are GEMMs with the reparameterisation in their epilogues (csrc/latent.hip)", 1024, 2048, 256, 4096)
+            alts["alt_default_ini"] = time_shape(
+                "default.ini as shipped (default.ini:3,18-19,27: the same model at batch_size 131072): 32 output tiles per CU, "
+                "the large GEMMs on 256 x 256 tiles (csrc/gemm_launch.hip big_tiles)", 1024, 2048, 256, 131072)
             alts["alt_fp8"] = time_alt(
                 "fp8 weight path (BASELINE configs[4]): all four large GEMM launches on e4m3 operands -- fc1 / fc4 forward, fc4's "
                 "backward (dgrad + wgrad, one 256x256 launch) and fc1's weight gradient (256x256, beside the optimizer riders, which "
@@ -797,11 +843,17 @@ def main():
             # BASELINE configs[0] (the reference's own CPU-runnable case: 512-sample frames, latent 8, batch 32)
             s_fps, s_ms, s_n, _ = time_cpu_step(512, H, 8, 32, make_params(512, H, 8, 0), make_frames(32, 512, 1234),
                                                 seconds=min(3.0, args.cpu_seconds), threads=threads)
+            # SURVEY 8d's third CPU shape: the reference's own model (latent_dim 256) at batch 4096
+            r_fps, r_ms, r_n, _ = time_cpu_step(1024, H, 256, 4096, make_params(1024, H, 256, 0), make_frames(4096, 1024, 1234),
+                                                seconds=min(6.0, args.cpu_seconds), threads=threads)
             out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d steps of the same C2 step (B=4096) in stock PyTorch fp32 on the "
                                              "host, median %.1f ms/step" % (n, ms_c),
                                    "smoke_shape": {"value": s_fps, "unit": "frames/s", "ms_per_step": s_ms,
                                                    "sample": "%d steps of S=512 H=2048 L=8 B=32" % s_n},
+                                   "ref_ini_shape": {"value": r_fps, "unit": "frames/s", "ms_per_step": r_ms,
+                                                     "sample": "%d steps of S=1024 H=2048 L=256 B=4096 (the model of default.ini / "
+                                                               "kelsey_iterable.ini at the latter's batch)" % r_n},
                                    "cgroup_cpu_quota": quota, "cpus_after_quota": usable,
                                    **cpu_description()}
         print(json.dumps(out))

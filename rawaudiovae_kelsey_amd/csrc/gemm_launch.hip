@@ -164,6 +164,7 @@ int launch_tile_fp8(int tile, const GemmArgs& a, long Mp, long Np, long Kp2, hip
   switch (tile) {
     case 0: return launch<64, 64, 2, 2, 4, true, true, EPI, true>(a, Mp, Np, 1, st);
     case 2: return launch<256, 128, 4, 2, 3, true, true, EPI, true>(a, Mp, Np, 1, st);
+    case 5: case 7: return launch<256, 256, 2, 4, 2, true, true, EPI, true>(a, Mp, Np, 1, st);   // (large batches: choose_tile)
     default: return launch<128, 128, 2, 4, 4, true, true, EPI, true>(a, Mp, Np, 1, st);
   }
 }
@@ -257,14 +258,36 @@ bool try_dual(int tile, const GemmArgs& a, long Mp1, long Np1, int s1, const Gem
 
 // Tile used for a GEMM launched with a given split count (deterministic: callers size their
 // partial-sum buffers from it).
-static int choose_tile(long Mp, long Np, int splits) {
+// Large batches (the reference's default.ini trains at batch_size = 131072, default.ini:27): once a GEMM has at least two
+// full rounds of 256 x 256 tiles -- or, for a split-K weight gradient, 2048-deep K slices -- the 256 x 256 ping-pong loop
+// is the faster form (measured at B = 131072, profiles/r06_big_batch_gemms.txt: fc1 forward 0.39 of the MFMA peak against
+// 0.35 on 256 x 128, fc4's dgrad 0.35 against 0.25, the weight gradients 0.49-0.52 against 0.30).  `Kp` = 0: unknown (the
+// plan's queries concern unsplit forward GEMMs, whose choice does not depend on it).
+static bool big_tiles(long Mp, long Np, int splits, long Kp) {
+  if (!tile_fits(7, Mp, Np)) return false;
+  const long t = (Mp / 256) * (Np / 256);
+  if (splits == 1) return t >= 512;
+  return Kp > 0 && Kp / splits >= 2048 && t * splits >= 192;
+}
+
+static int choose_tile(long Mp, long Np, int splits, long Kp = 0, bool allow_big = true) {
   if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) return g_force_tile;
+  if (allow_big && big_tiles(Mp, Np, splits, Kp)) return 7;
   // skinny outputs (the heads: N = 2 Lp = 128): 64x64 tiles, 64 KiB of LDS, two blocks per CU
   // (measured 7.4 us vs 8.4-9.0 on 128x128 for 4096x128x2048)
   if (Np <= 128) return 0;
   // 256x128 only when it fills the chip without slicing K finely (small-N GEMMs do better on 128x128)
   if (tile_fits(2, Mp, Np) && splits <= 4 && (Mp / 256) * (Np / 128) * splits >= 192) return 2;
   return tile_fits(4, Mp, Np) ? 4 : 0;
+}
+
+// (the fused loss forward on fp8 operands keeps the tiles below 256 x 256: its epilogue does not fit the registers there)
+extern "C" int rv_gemm_tile_fp8_loss(long Mp, long Np, int* bm, int* bn) {
+  int m, n;
+  tile_dims(choose_tile(Mp, Np, 1, 0, false), &m, &n);
+  if (bm) *bm = m;
+  if (bn) *bn = n;
+  return RV_OK;
 }
 
 extern "C" int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn) {
@@ -285,6 +308,12 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
   int t = -1;
   if (g_force_tile >= 0 && tile_fits(g_force_tile, Mp, Np)) {
     t = g_force_tile;
+  } else if (tile_fits(7, Mp, Np) && Kp >= 16384 && (Mp / 256) * (Np / 256) <= 256) {
+    // a weight gradient over a large batch: 256 x 256 tiles, as many K splits as fill the chip once (see big_tiles)
+    const int s7 = splits_for((Mp / 256) * (Np / 256), kt, max_splits);
+    if (big_tiles(Mp, Np, s7, Kp)) t = 7;
+  }
+  if (t >= 0) {
   } else if (Np <= 128) {
     t = 0;
   } else if (tile_fits(2, Mp, Np)) {
@@ -316,7 +345,11 @@ template <bool AK, bool BK, int EPI>
 static int launch_auto(const GemmArgs& a, long Mp, long Np, long Kp, int splits, hipStream_t st) {
   RV_REQUIRE(Mp > 0 && Np > 0 && Mp % 64 == 0 && Np % 64 == 0 && splits >= 1, RV_ERR_SHAPE,
              "gemm: extents must be positive multiples of 64 (got %ld %ld)", Mp, Np);
-  return launch_tile<AK, BK, EPI>(choose_tile(Mp, Np, splits), a, Mp, Np, Kp, splits, st);
+  int tile = choose_tile(Mp, Np, splits, Kp);
+  // (the fused loss epilogue holds 16 more values per item than the others: on 256 x 256 tiles the two-slot ring is its
+  // faster loop -- 0.375 against 0.345 of the MFMA peak at B = 131072)
+  if (EPI == EPI_TANH_LOSS && tile == 7 && g_force_tile < 0) tile = 5;
+  return launch_tile<AK, BK, EPI>(tile, a, Mp, Np, Kp, splits, st);
 }
 
 extern "C" {
@@ -400,7 +433,7 @@ int rv_decode_out_loss_fwd_fp8(const void* h3_fp8, long ldh, const void* w4_fp8,
   a.out_bf16 = (bf16_t*)dP4; a.ld_bf16 = ld_dp4; a.blocksum = mse_partial; a.colsum = db4_partial;
   a.out_fp8 = (unsigned char*)dP4_fp8; a.ld_fp8 = ld_dp4q; a.q_scale = dp4_scale;
   a.scale = 2.0f / ((float)B * (float)S); a.dq = dq;
-  return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
+  return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1, 0, false), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
 }
 
 int rv_linear_fwd_f32(const void* x, long ldx, const void* w, long ldw, const float* bias,
@@ -450,7 +483,7 @@ int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const void* w4, long
   if (dq) {
     RV_REQUIRE(Hp % 128 == 0 && ldh % 16 == 0 && ldw % 16 == 0, RV_ERR_SHAPE, "rv_decode_out_loss_fwd_frames: fp8 K and leading dims must be multiples of 128 / 16");
     a.A = (const bf16_t*)h3; a.lda = ldh / 2; a.B = (const bf16_t*)w4; a.ldb = ldw / 2; a.k_tiles = (int)(Hp / 128); a.dq = dq;
-    return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
+    return launch_tile_fp8<EPI_TANH_LOSS>(choose_tile(Bp, Sp, 1, 0, false), a, Bp, Sp, Hp / 2, (hipStream_t)stream);
   }
   a.A = (const bf16_t*)h3; a.lda = ldh; a.B = (const bf16_t*)w4; a.ldb = ldw; a.k_tiles = (int)(Hp / 64);
   return launch_auto<true, true, EPI_TANH_LOSS>(a, Bp, Sp, Hp, 1, (hipStream_t)stream);
@@ -613,7 +646,7 @@ extern "C" {
 // Unpaired backward of a Linear layer: when the wgrad runs on a dual-capable tile (64x64 or 128x128 with
 // 8 waves) that also divides the dgrad's output, the dgrad takes the same tile and both go out in one launch.
 static int dgrad_tile_unpaired(long Mp, long Np, long Kp, int wgrad_splits) {
-  const int tw = choose_tile(Kp, Np, wgrad_splits);
+  const int tw = choose_tile(Kp, Np, wgrad_splits, Mp);
   if (g_force_tile < 0 && (tw == 0 || tw == 4) && tile_fits(tw, Mp, Np)) return tw;
   return choose_tile(Mp, Np, 1);
 }
@@ -651,7 +684,7 @@ int rv_linear_dgrad_wgrad(const void* dy, long lddy, const void* w, long ldw, co
   RV_REQUIRE(sp == splits, RV_ERR_STATE, "rv_linear_dgrad_wgrad: caller passed %d splits, rv_dgrad_wgrad_pick says %d",
              splits, sp);
   if (!paired) {
-    const int td = dgrad_tile_unpaired(Mp, Np, Kp, splits), tw = choose_tile(Kp, Np, splits);
+    const int td = dgrad_tile_unpaired(Mp, Np, Kp, splits), tw = choose_tile(Kp, Np, splits, Mp);
     GemmArgs d{}, g{};
     d.A = (const bf16_t*)dy; d.lda = lddy; d.B = (const bf16_t*)w; d.ldb = ldw;
     d.k_tiles = (int)(Kp / 64); d.M_valid = (int)Mp; d.N_valid = (int)Np;
@@ -693,7 +726,7 @@ int rv_linear_dgrad_wgrad_f32(const void* dy, long lddy, const void* w, long ldw
   RV_REQUIRE(dy && w && x && dx_slabs && dw_slabs, RV_ERR_NULL, "rv_linear_dgrad_wgrad_f32: null operand");
   RV_REQUIRE(dgrad_splits >= 1 && wgrad_splits >= 1 && (Kp / 64) % dgrad_splits == 0 && (Mp / 64) % wgrad_splits == 0,
              RV_ERR_SHAPE, "rv_linear_dgrad_wgrad_f32: splits %d / %d do not divide the K tiles", dgrad_splits, wgrad_splits);
-  const int td = choose_tile(Mp, Np, dgrad_splits), tw = choose_tile(Kp, Np, wgrad_splits);
+  const int td = choose_tile(Mp, Np, dgrad_splits, Kp), tw = choose_tile(Kp, Np, wgrad_splits, Mp);
   int rc;
   if (td == tw) {
     GemmArgs d{}, g{};

@@ -81,6 +81,9 @@ struct rv_plan {
   // n_mt1_gen partial rows of fc1's bias gradient) and the streaming kernel rv_heads_bwd (hb_groups of both; 0 = the
   // shape does not allow it); s_wh / n_mt1 and the descriptors follow the form in use (heads_mode_apply)
   int s_wh_gen = 1, n_mt1_gen = 1, hb_groups = 0;
+  // the fc4 forward's partial counts per operand type: [0] bf16 operands, [1] fp8 operands (whose fused-loss kernel keeps
+  // the smaller tiles at large batches); n_mt4 / n_mse and fc4.bias's descriptor follow the type in use (fwd4_mode_apply)
+  int n_mt4_of[2] = {1, 1}, n_mse_of[2] = {1, 1};
   int heads_pair_gen = 0;   // the generic form is the paired 256 x 256 launch (rv_dgrad_wgrad_pick): its dWh slabs may be fp16
   long off[10];                               // element offsets of the 10 params in the flat arenas
   long n_params;
@@ -238,12 +241,15 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   }
   p->s_w1 = splits_of(Hp, Sp, Bp);
   // per-row-tile partial counts follow the tile each producing GEMM will use
-  p->n_mt4 = row_tiles(Bp, Sp);   // fc4 fwd: dP4 column sums (db4) and MSE partials
-  {
+  for (int f8 = 0; f8 < 2; ++f8) {   // fc4 fwd: dP4 column sums (db4) and MSE partials
     int bm = 128, bn = 128;
-    rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
-    p->n_mse = (int)((Bp / bm) * (Sp / bn));
+    if (f8) rv_gemm_tile_fp8_loss(Bp, Sp, &bm, &bn);
+    else rv_gemm_tile(Bp, Sp, 1, &bm, &bn);
+    p->n_mt4_of[f8] = (int)(Bp / bm);
+    p->n_mse_of[f8] = (int)((Bp / bm) * (Sp / bn));
   }
+  p->n_mt4 = p->n_mt4_of[0];
+  p->n_mse = p->n_mse_of[0];
   p->n_kl = (int)(Bp * Lp / 1024);
   const long sizes[10] = {H * S, H, L * H, L, L * H, L, H * L, H, S * H, S};
   long o = 0;
@@ -288,7 +294,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->add("db1p", (long)(p->n_mt1_gen > p->hb_groups ? p->n_mt1_gen : p->hb_groups) * Hp * 4);
   p->add("dbhp", (Bp / 16) * L2p * 4);
   p->add("db3p", (long)p->n_mt3 * Hp * 4);
-  p->add("db4p", (long)p->n_mt4 * Sp * 4);
+  p->add("db4p", (long)(p->n_mt4_of[0] > p->n_mt4_of[1] ? p->n_mt4_of[0] : p->n_mt4_of[1]) * Sp * 4);
   p->add("xq", Bp * Sp);          // fp8 operands of the fp8 forward path (RV_OPT_FP8)
   p->add("W1q", Hp * Sp);
   p->add("W4q", Sp * Hp);
@@ -301,7 +307,7 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
   p->n_amax_dp1 = Bp % 512 == 0 ? (int)(8 * (Bp / 512) * (Hp / 64)) : 0;   // one maximum per wave of rv_heads_bwd_ex
   p->add("h3_amax", ((long)p->n_amax_cap + p->n_amax_dp1) * 4);            // h3's maxima, then dP1's right behind them
   p->add("ddp_flags", 64 * 4);   // data-parallel step: cross-stream sequence flags [0..3], timeout counter [8]
-  p->add("mse_part", (long)p->n_mse * 4);
+  p->add("mse_part", (long)(p->n_mse_of[0] > p->n_mse_of[1] ? p->n_mse_of[0] : p->n_mse_of[1]) * 4);
   p->add("kl_part", (long)p->n_kl * 4);
   p->bound = false;
   *out = p;
@@ -377,9 +383,18 @@ int rv_plan_set_loss_grad(rv_plan* p, const float* d_loss_dev, float* grad_out) 
   return RV_OK;
 }
 
+static void fwd4_mode_apply(rv_plan* p) {
+  const int f8 = p->fp8 ? 1 : 0;
+  p->n_mt4 = p->n_mt4_of[f8];
+  p->n_mse = p->n_mse_of[f8];
+  p->d_slab[9].grad_splits = p->n_mt4;
+  if (!p->b.grad) p->d_flat[9].grad_splits = p->n_mt4;
+}
+
 static int plan_set_fp8(rv_plan* p, int enable) {
   RV_REQUIRE(enable >= 0 && enable <= 2, RV_ERR_UNSUPPORTED, "rv_plan_set_option: RV_OPT_FP8 takes 0, 1 or 2 (got %d)", enable);
   p->fp8 = enable;   // 1: forward of fc1 / fc4 and backward of fc4; 2: forward only
+  fwd4_mode_apply(p);
   float* st = (float*)p->ws("fp8_state");
   // Adam keeps the fp8 shadows of fc1.weight / fc4.weight current (descriptor 0 and 8)
   for (rv_param_desc* d : {p->d_slab, p->d_flat}) {
@@ -489,6 +504,7 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
     }
   }
   heads_mode_apply(p);
+  fwd4_mode_apply(p);
   return plan_set_slab_dtype(p, p->slab_dtype);
 }
 

@@ -222,3 +222,43 @@ def test_a_flag_timeout_on_one_rank_stops_every_rank():
     for p in procs:
         p.join(120)
     assert [p.exitcode for p in procs] == [5, 5]
+
+
+def _rendezvous_worker(rank, world, port, out):
+    """One rank of a checkpoint epoch: rank 0 spends `slow` seconds in its rank-0-only block, then every rank meets."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      RV_DIST_BACKEND="gloo", RV_DDP_WAIT_MS="200")
+    import time
+    import train
+    dp = train.DataParallel(torch.device("cpu"))
+    dp.rendezvous()                         # (aligns the start)
+    t0 = time.perf_counter()
+    if dp.main:
+        time.sleep(1.5)                     # "write_reconstruction + torch.save": far longer than RV_DDP_WAIT_MS
+    dp.rendezvous()
+    out.put((rank, time.perf_counter() - t0))
+    dp.dist.destroy_process_group()         # (dp.close() also synchronises the GPU)
+
+
+def test_ranks_wait_for_rank_zero_behind_a_checkpoint_longer_than_the_flag_bound():
+    """Round-5 advisor: rank 0 alone evaluates and writes the checkpoint; the other ranks must not enter the next epoch's
+    first data-parallel step -- whose flag waits are bounded by RV_DDP_WAIT_MS -- until it is done.  train.py's
+    DataParallel.rendezvous is that meeting point (a host-side barrier, called on every rank behind the rank-0-only block):
+    with rank 0 busy for 1.5 s and a flag bound of 0.2 s, rank 1 leaves the rendezvous only after rank 0 arrived."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert got[1] >= 1.4, got               # rank 1 waited for rank 0
+    import inspect
+    import train
+    src = inspect.getsource(train.main)
+    assert src.index("torch.save(checkpoint_state(epoch)") < src.index("dp.rendezvous()") < src.index("final_loss = train_loss")
+

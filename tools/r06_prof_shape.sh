@@ -9,7 +9,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python3 $R/tools/step_time.py --shape "$@" --steps 100 --reps 1 > $O/prof.log 2>&1
 cd $R
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1)
-python3 - "$f" <<'PY'
+python3 tools/trace_steps.py $(find $O/prof -name "*kernel_trace.csv" | head -1); python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = 0

@@ -134,6 +134,16 @@ class DataParallel:
         self.dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def rendezvous(self):
+        """Host-side meeting point of all ranks behind work that rank 0 does alone (the evaluation pass and the checkpoint
+        files of a checkpoint epoch).  Without it the other ranks go straight into the next epoch's first data-parallel
+        step and spin on its cross-stream flags behind rank 0 -- whose collectives are not enqueued while it writes files --
+        and a checkpoint that takes longer than the flag waits' bound (RV_DDP_WAIT_MS, thirty seconds by default: a large
+        test set, a slow or shared file system) would poison every plan of a healthy run.  Waiting HERE costs nothing: the
+        ranks block in a host call with no step in flight and no bound."""
+        if self.active:
+            self.dist.barrier()
+
     def check(self):
         """Health of the library-driven step, before results are read back (every rank calls it at the same points).
         A flag wait that ran out on ANY engine of ANY rank (engine.ddp_timeouts: a peer more than RV_DDP_WAIT_MS behind,
@@ -444,6 +454,8 @@ def main(argv=None):
                 best_loss = train_loss
             elif train_loss > best_loss:
                 print("Loss did not improve.")
+        if epoch % checkpoint_interval == 0 and epoch != 0:
+            dp.rendezvous()     # every rank: nobody starts the next epoch's steps while rank 0 is still writing
         final_loss = train_loss
 
     dp.sync_optimizer_state(engine)
