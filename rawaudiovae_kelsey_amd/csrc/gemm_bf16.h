@@ -605,10 +605,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // 6 x 16 bytes per item), eps of its rows (EPI_REPARAM); eps as 16-byte loads where the exact latent width is a multiple
   // of 4 and the item lies inside the valid extent -- everything else is read in the epilogue, element by element.
   constexpr bool PF_RB = EPI == EPI_REPARAM_BWD, PF_RF = EPI == EPI_REPARAM;
-  static_assert(!PF_RB || MI == CM, "reparameterisation backward epilogue: one chunk");
-  f32x4 rb_m[PF_RB ? CH : 1][2], rb_l[PF_RB ? CH : 1][2], rb_e[PF_RB ? CH : (PF_RF ? MI : 1)][2];
-  bool rb_vec[PF_RB ? CH : (PF_RF ? MI : 1)];
-  if constexpr (PF_RB) {
+  constexpr bool PF_RB_ON = PF_RB && MI == CM;   // one chunk (the 64-row tiles): its operands are fetched ahead
+  constexpr int RF_N = MI * (NI / 2);   // EPI_REPARAM: (row fragment, mu | logvar fragment pair) items of a wave
+  f32x4 rb_m[PF_RB ? CH : 1][2], rb_l[PF_RB ? CH : 1][2], rb_e[PF_RB ? CH : (PF_RF ? RF_N : 1)][2];
+  bool rb_vec[PF_RB ? CH : (PF_RF ? RF_N : 1)];
+  if constexpr (PF_RB_ON) {
     const long L2p_ = 2 * p.lat_lp, L_ = p.lat_l;
     const bool al = (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps) & 15) == 0;
 #pragma unroll
@@ -626,14 +627,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
   }
   if constexpr (PF_RF) {
-    const long L_ = p.lat_l, l_ = (long)tile_n * 64 + wn * 16 + 4 * (lane >> 4);
-    const bool al = p.eps_in && (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps_in) & 15) == 0;
+    // (with more than four items -- the 256-row tiles of large batches -- eps is read in the epilogue: the loop has no
+    // registers to spare for it, and one round trip in 16 tiles' worth of work is not what bounds such a block)
+    const long L_ = p.lat_l;
+    const bool al = RF_N <= 4 && p.eps_in && (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps_in) & 15) == 0;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const long b_ = m0 + wm * WTM + mi * 16 + (lane & 15);
-      rb_vec[mi] = al && b_ < p.M_valid && l_ + 4 <= L_;
-      rb_e[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rb_vec[mi]) rb_e[mi][0] = *(const f32x4*)(p.eps_in + b_ * L_ + l_);
+    for (int it = 0; it < RF_N; ++it) {
+      const long b_ = m0 + wm * WTM + (it / (NI / 2)) * 16 + (lane & 15);
+      const long l_ = (long)tile_n * 64 + wn * (WTN / 2) + (it % (NI / 2)) * 16 + 4 * (lane >> 4);
+      rb_vec[it] = al && b_ < p.M_valid && l_ + 4 <= L_;
+      rb_e[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rb_vec[it]) rb_e[it][0] = *(const f32x4*)(p.eps_in + b_ * L_ + l_);
     }
   }
   if constexpr (PF_X || PF_MASK || PF_RB || PF_RF) {
@@ -700,7 +704,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   if (!gathered) sa.init(p.lda, wave, lane);
   const bf16_t* Bgr = Bg;
   if constexpr (EPI == EPI_REPARAM) {
-    static_assert(B_KMAJ && BN == 128 && WTN == 32, "reparameterisation epilogue: 128-column tiles (64 latents x 2 heads), 32-column wave tiles");
+    static_assert(B_KMAJ && BN == 128 && WTN % 32 == 0, "reparameterisation epilogue: 128-column tiles (64 latents x 2 heads), wave tiles of whole (mu, logvar) fragment pairs");
     Bgr = p.B + k0;
     sb.init_rows([&](int r) { return (((r >> 4) & 1) * p.lat_lp + (long)tile_n * 64 + (r >> 5) * 16 + (r & 15)) * p.ldb; }, wave, lane);
   } else {
@@ -890,46 +894,52 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     // straight on the accumulators (k_reparam_fwd's arithmetic and eps draws -- counter = the (row, 4-latent group) index
     // over the padded [Mp, lat_lp / 4] grid --, elementwise.hip), 16-byte fp32 / 8-byte bf16 stores, 64 bytes per row
     // and store instruction.
-    static_assert(NI == 2, "reparameterisation epilogue: one mu and one logvar fragment per wave");
+    static_assert(NI % 2 == 0, "reparameterisation epilogue: (mu, logvar) fragment pairs");
     const int q = lane >> 4, j = lane & 15;
     const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
-    const long l = (long)tile_n * 64 + wn * 16 + 4 * q;
-    const f32x4 bm = *(const f32x4*)(p.bias + l), bv = *(const f32x4*)(p.bias + Lp_ + l);
     const uint64_t step_ = p.step_counter ? (uint64_t)*p.step_counter : 0;
     float kl = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const long b = m0 + wm * WTM + mi * 16 + j;
-      float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
-      if (b < p.M_valid && l < L_) {
-        float ev[4];
-        if (!p.eps_in) normal4_fast(p.seed, (uint64_t)(b * (Lp_ >> 2) + (l >> 2)), step_, ev);
+    for (int pr = 0; pr < NI / 2; ++pr) {
+      const long l = (long)tile_n * 64 + wn * (WTN / 2) + pr * 16 + 4 * q;
+      const f32x4 bm = *(const f32x4*)(p.bias + l), bv = *(const f32x4*)(p.bias + Lp_ + l);
 #pragma unroll
-        for (int e_ = 0; e_ < 4; ++e_) {
-          if (l + e_ < L_) {
-            float e;
-            if (p.eps_in) {
-              e = rb_vec[mi] ? rb_e[mi][0][e_] : p.eps_in[b * L_ + l + e_];
-            } else {
-              e = ev[e_];
-              p.eps_out[b * L_ + l + e_] = e;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int it = mi * (NI / 2) + pr;
+        const long b = m0 + wm * WTM + mi * 16 + j;
+        float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b < p.M_valid && l < L_) {
+          float ev[4];
+          if (!p.eps_in) normal4_fast(p.seed, (uint64_t)(b * (Lp_ >> 2) + (l >> 2)), step_, ev);
+#pragma unroll
+          for (int e_ = 0; e_ < 4; ++e_) {
+            if (l + e_ < L_) {
+              float e;
+              if (p.eps_in) {
+                e = rb_vec[it] ? rb_e[it][0][e_] : p.eps_in[b * L_ + l + e_];
+              } else {
+                e = ev[e_];
+                p.eps_out[b * L_ + l + e_] = e;
+              }
+              mua[e_] = acc[mi][2 * pr][e_] + bm[e_];
+              lva[e_] = acc[mi][2 * pr + 1][e_] + bv[e_];
+              const float sd = __expf(0.5f * lva[e_]);
+              zz[e_] = mua[e_] + e * sd;
+              kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
             }
-            mua[e_] = acc[mi][0][e_] + bm[e_];
-            lva[e_] = acc[mi][1][e_] + bv[e_];
-            const float sd = __expf(0.5f * lva[e_]);
-            zz[e_] = mua[e_] + e * sd;
-            kl += 1.f + lva[e_] - mua[e_] * mua[e_] - sd * sd;
           }
         }
+        store_out16((f32x4*)(p.mulv + b * L2p_ + l), f32x4{mua[0], mua[1], mua[2], mua[3]}, p.wt);
+        store_out16((f32x4*)(p.mulv + b * L2p_ + Lp_ + l), f32x4{lva[0], lva[1], lva[2], lva[3]}, p.wt);
+        const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
+        *(bf16x4*)(p.z + b * Lp_ + l) = zb;
       }
-      store_out16((f32x4*)(p.mulv + b * L2p_ + l), f32x4{mua[0], mua[1], mua[2], mua[3]}, p.wt);
-      store_out16((f32x4*)(p.mulv + b * L2p_ + Lp_ + l), f32x4{lva[0], lva[1], lva[2], lva[3]}, p.wt);
-      const bf16x4 zb = {(bf16_t)zz[0], (bf16_t)zz[1], (bf16_t)zz[2], (bf16_t)zz[3]};
-      *(bf16x4*)(p.z + b * Lp_ + l) = zb;
     }
     float* red = (float*)smem_generic;
     const float s_ = block_sum<NW>(kl, red);
-    if (tid < 4) p.kl_partial[4 * (tile_m * tiles_n + tile_n) + tid] = tid == 0 ? s_ : 0.f;
+    // one KL partial per 1024 elements of the padded [Mp, lat_lp] grid is what the loss reduction sums: this block's BM x 64
+    // elements own BM / 16 slots -- the sum goes into the first, zeros into the others
+    if (tid < BM / 16) p.kl_partial[(BM / 16) * (tile_m * tiles_n + tile_n) + tid] = tid == 0 ? s_ : 0.f;
     return;
   }
 
@@ -1165,7 +1175,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     } else if constexpr (EPI == EPI_REPARAM_BWD) {
       // v = dz of (row, 8 consecutive latents): k_reparam_bwd's arithmetic (elementwise.hip) on the accumulators
       const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
-      // (mu | logvar and, where 16-byte loads were possible, eps of these items were fetched before the main loop)
+      // (64-row tiles: mu | logvar and, where 16-byte loads were possible, eps of these items were fetched before the main
+      // loop; the 256-row tiles of large batches fetch them here, chunk by chunk)
+      if constexpr (!PF_RB_ON) {
+        const bool al = (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps) & 15) == 0;
+#pragma unroll
+        for (int it = 0; it < CH; ++it) {
+          const float* mp = p.mulv + rowi[it] * L2p_ + coli[it];
+          rb_m[it][0] = *(const f32x4*)mp; rb_m[it][1] = *(const f32x4*)(mp + 4);
+          rb_l[it][0] = *(const f32x4*)(mp + Lp_); rb_l[it][1] = *(const f32x4*)(mp + Lp_ + 4);
+          rb_vec[it] = al && rowi[it] < p.M_valid && coli[it] + 8 <= L_;
+          rb_e[it][0] = rb_e[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (rb_vec[it]) {
+            rb_e[it][0] = *(const f32x4*)(p.eps + rowi[it] * L_ + coli[it]);
+            rb_e[it][1] = *(const f32x4*)(p.eps + rowi[it] * L_ + coli[it] + 4);
+          }
+        }
+      }
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         const long b = rowi[it], l = coli[it];
@@ -1257,7 +1283,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     // butterfly, over the wave rows through LDS (the ring is free: barrier after the main loop) -- into row 4 tile_m of
     // the [Mp / 16][2 lat_lp] partial-row table (k_reparam_bwd writes one row per 16 batch rows; the three rows this
     // tile does not use are zeroed, so the optimizer's descriptors do not depend on which kernel ran)
-    static_assert(BM == 64, "reparameterisation backward epilogue: 64-row tiles (four 16-row slots of the bias partial table)");
+    static_assert(BM % 16 == 0, "reparameterisation backward epilogue: BM / 16 rows of the bias partial table per tile");
     float* red = (float*)smem_generic;
 #pragma unroll
     for (int t = 0; t < NP; ++t)
@@ -1281,14 +1307,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     __syncthreads();
     if (p.dbh_partial) {
       const long L2p_ = 2 * p.lat_lp;
-      for (int i = tid; i < 8 * BN; i += 64 * NW) {   // 4 table rows x {dmu, dlogvar} x BN columns
+      for (int i = tid; i < (BM / 16) * 2 * BN; i += 64 * NW) {   // BM / 16 table rows x {dmu, dlogvar} x BN columns
         const int row = i / (2 * BN), hd = (i / BN) & 1, c_ = i % BN;
         float s_ = 0.f;
         if (row == 0) {
 #pragma unroll
           for (int w = 0; w < WGM; ++w) s_ += red[(hd * WGM + w) * BN + c_];
         }
-        p.dbh_partial[((long)tile_m * 4 + row) * L2p_ + hd * p.lat_lp + n0 + c_] = s_;
+        p.dbh_partial[((long)tile_m * (BM / 16) + row) * L2p_ + hd * p.lat_lp + n0 + c_] = s_;
       }
     }
   }

@@ -767,9 +767,22 @@ __global__ void __launch_bounds__(512) k_heads_reparam_gemm(const GemmArgs p) {
   gemm_body<64, 128, 2, 4, true, true, EPI_REPARAM, HG_STAGES>(p, blockIdx.x, smem_dyn);
 }
 
+// Large batches (default.ini trains at batch_size = 131072): with more than four 64-row tiles per CU the bytes a tile pulls
+// through the port per flop are what matters, not filling the chip: 256 x 128 tiles (48 KB per K tile for four times the
+// rows).  The row-local kernels of Lp = 64 hand over to these forms there too: they re-stream every weight for each 16 rows,
+// 0.06-0.08 of the MFMA peak at B = 131072 (profiles/r06_batch_sweep.jsonl).
+constexpr int LG_BIG_TILES = 1024;                       // (Bp / 64) (Lp / 64) above which the 256-row forms run
+constexpr int HGB_STAGES = 3;
+constexpr int HGB_LDS = HGB_STAGES * (256 + 128) * 128;  // 144 KiB
+__global__ void __launch_bounds__(512) k_heads_reparam_gemm_big(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  gemm_body<256, 128, 4, 2, true, true, EPI_REPARAM, HGB_STAGES>(p, blockIdx.x, smem_dyn);
+}
+
 constexpr int DZ_STAGES = 5, DW3_STAGES = 2;
 constexpr int DZ_LDS = DZ_STAGES * (64 + 64) * 128;     // 80 KiB (the dW3 blocks use 64 of them): two workgroups per CU
 
+template <bool BIG>
 __global__ void __launch_bounds__(512)
 k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, const int n_w3, const long B, const long L,
                   const long S, const float kl_beta, const float* __restrict__ mse_partial, const int n_mse,
@@ -778,11 +791,14 @@ k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, cons
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int bid = (int)blockIdx.x, tid = threadIdx.x;
   if (bid < n_dz) {
-    gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
+    if constexpr (BIG) gemm_body<256, 128, 4, 2, true, false, EPI_REPARAM_BWD, HGB_STAGES>(dz, bid, smem_dyn);
+    else gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
     return;
   }
   if (bid < n_dz + n_w3) {
-    gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid - n_dz, smem_dyn);
+    // (a padded latent width of 64 leaves no room for 128-column tiles: 128 x 64 there, three ring slots = 72 KiB)
+    if (w3grad.N_valid < 128) gemm_body<128, 64, 4, 2, false, false, EPI_F32, 3>(w3grad, bid - n_dz, smem_dyn);
+    else gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid - n_dz, smem_dyn);
     return;
   }
   if (loss_out && mse_partial && kl_partial) {   // the loss scalar (k_reparam_bwd's extra block, same summation order)
@@ -814,16 +830,19 @@ int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const
   GemmArgs a{};
   a.A = (const bf16_t*)h; a.lda = ldh; a.B = (const bf16_t*)wh; a.ldb = ldwh;
   a.k_tiles = (int)(Hp / 64); a.M_valid = (int)B; a.N_valid = (int)(2 * Lp);
-  a.tiles_m = (int)(Bp / 64); a.tiles_n = (int)(Lp / 64); a.splits = 1;
+  const bool big = (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
+  a.tiles_m = (int)(Bp / (big ? 256 : 64)); a.tiles_n = (int)(Lp / 64); a.splits = 1;
   a.bias = bias_heads; a.lat_lp = Lp; a.lat_l = L; a.eps_in = eps_in; a.eps_out = eps_out; a.seed = seed;
   a.step_counter = step_counter; a.mulv = mulv; a.z = (bf16_t*)z; a.kl_partial = kl_partial;
   a.wt = rv_store_wt;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, HG_LDS);
+    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_heads_reparam_gemm, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HG_LDS, st, a);
+  if (big) hipLaunchKernelGGL(k_heads_reparam_gemm_big, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HGB_LDS, st, a);
+  else hipLaunchKernelGGL(k_heads_reparam_gemm, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HG_LDS, st, a);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }
@@ -831,6 +850,11 @@ int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const
 }  // namespace
 
 extern "C" {
+
+// Which form serves a shape: the row-local kernels (16 rows per workgroup, every weight through every CU) at a padded latent
+// width of 64 while the batch is small enough that filling the chip is the issue; the GEMM forms above that width and for
+// large batches.  One predicate for both directions and for the plan (internal.h).
+int rv_latent_rowlocal(long Bp, long Hp, long Lp) { return Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && Bp <= 8192; }
 
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
@@ -857,7 +881,7 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");
   RV_REQUIRE(Lp == 64 || Lp == 128 || Lp == 256, RV_ERR_UNSUPPORTED,
              "rv_latent_fwd: serves padded latent widths of 64, 128 and 256 (got %ld)", Lp);
-  if (Lp > 64) {
+  if (!rv_latent_rowlocal(Bp, Hp, Lp)) {
     // GEMM forms (k_heads_reparam_gemm, then fc3 as a forward GEMM): any hidden width that is a multiple of 128
     RV_REQUIRE(Bp > 0 && Bp % 64 == 0 && Hp > 0 && Hp % 128 == 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp && ldh % 8 == 0 &&
                    ldwh % 8 == 0 && (heads_only || (ldw3 >= Lp && ldh3 >= Hp && ldw3 % 8 == 0 && ldh3 % 8 == 0)),
@@ -871,8 +895,6 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
     return rv_linear_fwd_ex(z_bf16, Lp, w3_bf16, ldw3, bias3, Bp, Hp, Lp, RV_ACT_RELU, h3_bf16, ldh3, h3_fp8, ldq, q_scale, amax_part,
                             stream);
   }
-  RV_REQUIRE(Hp % 512 == 0 && Hp <= 2048, RV_ERR_UNSUPPORTED,
-             "rv_latent_fwd: the hidden width must be a multiple of 512 up to 2048 at a padded latent width of 64 (got %ld)", Hp);
   RV_REQUIRE(Bp > 0 && Bp % LAT_ROWS == 0 && Hp > 0 && B <= Bp && L <= Lp && ldh >= Hp && ldwh >= Hp &&
                  (heads_only || (ldw3 >= Lp && ldh3 >= Hp && ldw3 % 8 == 0 && ldh3 % 8 == 0)) && ldh % 8 == 0 && ldwh % 8 == 0,
              RV_ERR_SHAPE, "rv_latent_fwd: bad extents Bp %ld Hp %ld", Bp, Hp);
@@ -900,8 +922,8 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
   RV_REQUIRE(dp3_bf16 && w3_bf16 && mulv && eps && dmulv_bf16, RV_ERR_NULL, "rv_latent_bwd: null pointer");
   RV_REQUIRE(Lp == 64 || Lp == 128 || Lp == 256, RV_ERR_UNSUPPORTED,
              "rv_latent_bwd: serves padded latent widths of 64, 128 and 256 (got %ld)", Lp);
-  RV_REQUIRE(Lp > 64 ? Hp % 64 == 0 : (Hp % 512 == 0 && Hp <= 2048), RV_ERR_UNSUPPORTED,
-             "rv_latent_bwd: the hidden width must be a multiple of 512 up to 2048 at a padded latent width of 64, of 64 above (got %ld)", Hp);
+  const bool rowlocal = rv_latent_rowlocal(Bp, Hp, Lp);
+  RV_REQUIRE(rowlocal || Hp % 128 == 0, RV_ERR_UNSUPPORTED, "rv_latent_bwd: the hidden width must be a multiple of 128 (got %ld)", Hp);
   RV_REQUIRE(Bp > 0 && Bp % 64 == 0 && B <= Bp && L <= Lp && lddp >= Hp && ldw3 >= Lp && lddp % 8 == 0 &&
                  ldw3 % 8 == 0, RV_ERR_SHAPE, "rv_latent_bwd: bad extents Bp %ld Hp %ld", Bp, Hp);
   RV_REQUIRE((((uintptr_t)dp3_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)mulv | (uintptr_t)dmulv_bf16) & 15) == 0, RV_ERR_SHAPE,
@@ -917,17 +939,17 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.out_f32 = dw3_slabs; g.ld_f32 = lddw3; g.split_stride_f32 = Hp * lddw3;
     g.tiles_m = (int)(Hp / 64); g.tiles_n = (int)(Lp / 64); g.splits = dw3_splits;
     g.wt = rv_store_wt;
-    if (Lp > 64) {   // (the GEMM form's dW3 blocks run on 128 x 128 tiles)
-      RV_REQUIRE(Hp % 128 == 0, RV_ERR_SHAPE, "rv_latent_bwd: the hidden width must be a multiple of 128 (got %ld)", Hp);
-      g.tiles_m = (int)(Hp / 128); g.tiles_n = (int)(Lp / 128);
+    if (!rowlocal) {   // (the GEMM form's dW3 blocks run on 128 x 128 tiles, 128 x 64 at a padded latent width of 64)
+      g.tiles_m = (int)(Hp / 128); g.tiles_n = Lp >= 128 ? (int)(Lp / 128) : 1;
     }
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
-  if (Lp > 64) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
+  if (!rowlocal) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
+    const bool big = Lp >= 128 && (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
     GemmArgs d{};
     d.A = (const bf16_t*)dp3_bf16; d.lda = lddp; d.B = (const bf16_t*)w3_bf16; d.ldb = ldw3;
     d.k_tiles = (int)(Hp / 64); d.M_valid = (int)B; d.N_valid = (int)Lp;
-    d.tiles_m = (int)(Bp / 64); d.tiles_n = (int)(Lp / 64); d.splits = 1;
+    d.tiles_m = (int)(Bp / (big ? 256 : 64)); d.tiles_n = (int)(Lp / (big ? 128 : 64)); d.splits = 1;
     d.lat_lp = Lp; d.lat_l = L; d.mulv = const_cast<float*>(mulv); d.eps = eps; d.kl_beta = kl_beta;
     d.inv_nk = 1.0f / ((float)B * (float)L); d.dmu_ext = dmu_ext; d.dlv_ext = dlv_ext;
     d.dmulv = (bf16_t*)dmulv_bf16; d.dbh_partial = dbh_partial;
@@ -935,11 +957,16 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     const int n_dz = d.tiles_m * d.tiles_n;
     static bool attr_gemm = false;
     if (!attr_gemm) {
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
       attr_gemm = true;
     }
-    hipLaunchKernelGGL(k_dz_reparam_gemm, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), DZ_LDS, (hipStream_t)stream, d, g, n_dz, n_w3,
-                       B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
+    if (big)
+      hipLaunchKernelGGL(k_dz_reparam_gemm<true>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), HGB_LDS, (hipStream_t)stream, d, g,
+                         n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
+    else
+      hipLaunchKernelGGL(k_dz_reparam_gemm<false>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), DZ_LDS, (hipStream_t)stream, d, g,
+                         n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
     RV_CHECK_LAUNCH();
     return RV_OK;
   }

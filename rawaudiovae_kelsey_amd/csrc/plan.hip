@@ -171,7 +171,9 @@ int w1_tile(const rv_plan* p) {
 
 // Which form of the heads' backward runs (see rv_plan: s_wh_gen / hb_groups) and the partial counts that follow from it.
 static bool heads_streaming(const rv_plan* p) {
-  return p->latent_fused && p->hb_groups > 0 && p->Hp % 512 == 0 && p->Hp <= 2048;
+  // (large batches: the streaming kernel re-reads its Wh slice per 512 rows at 0.12 of the MFMA peak; the paired / tiled
+  // GEMM forms take over with the other latent-sized launches)
+  return p->latent_fused && p->hb_groups > 0 && rv_latent_rowlocal(p->Bp, p->Hp, p->Lp);
 }
 static void heads_mode_apply(rv_plan* p) {
   const bool st = heads_streaming(p);
@@ -620,11 +622,10 @@ static int fc4_backward(rv_plan* p, void* stream) {
 // padded latent width 64; its GEMM form above that): rv_latent_bwd (dz + reparam backward with dW3 on extra workgroups of
 // the same launch) and the heads' backward -- two launches.  Otherwise three: dz + dW3 as split-K slabs, rv_reparam_bwd,
 // the heads' backward.
-// (padded latent width 64: the row-local kernels, hidden width a multiple of 512 up to 2048; 128 / 256 -- the reference's
-// own latent_dim = 256 -- : the GEMM forms with the reparameterisation in their epilogues, csrc/latent.hip)
-static bool latent_bwd_fused(const rv_plan* p) {
-  return p->latent_fused && (p->Lp == 64 ? p->Hp % 512 == 0 && p->Hp <= 2048 : p->Hp % 128 == 0);
-}
+// (padded latent width 64 at batches up to 8192: the row-local kernels, hidden width a multiple of 512 up to 2048; 128 / 256
+// -- the reference's own latent_dim = 256 --, large batches and every other hidden width: the GEMM forms with the
+// reparameterisation in their epilogues; rv_latent_rowlocal, csrc/latent.hip)
+static bool latent_bwd_fused(const rv_plan* p) { return p->latent_fused && p->Hp % 128 == 0; }
 
 static int latent_heads_bwd(rv_plan* p, const float* eps_used, float kl_beta, const float* dmu_ext, const float* dlv_ext,
                             void* stream, bool f8_w1 = false) {
@@ -705,7 +706,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     int n_amax = 0;
     // heads -> reparam -> fc3: one launch where the fused kernel exists (padded latent width 64), else three
     const bool latent_fused = latent_bwd_fused(p);   // (same shapes both ways)
-    if (p->fp8 && latent_fused && Lp == 64) {
+    if (p->fp8 && latent_fused && rv_latent_rowlocal(Bp, Hp, Lp)) {
       n_amax = (int)(Bp / 16) * 8;   // one maximum per wave of rv_latent_fwd_ex
       RV_REQUIRE(n_amax <= p->n_amax_cap, RV_ERR_STATE, "rv_plan_step: h3_amax holds %d entries, the fused latent forward writes %d", p->n_amax_cap, n_amax);
     } else if (p->fp8) {
@@ -853,7 +854,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     RV_TRY(rv_tanh_bwd_pack(p->ext_d_recon, p->ext_recon, B, S, dP4, Bp, Sp, stream));
     RV_TRY(rv_colsum_partial(dP4, 1, Bp, Sp, Sp, (float*)p->ws("db4p"), Sp, stream));
   }
-  if (do_pair) RV_TRY(fc4_backward(p, stream));
+  if (do_pair) RV_K(4, fc4_backward(p, stream));
   bool w3_done = false;
   if (do_chain_a && do_chain_b && do_w3) {
     RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, p->ext_dmu, p->ext_dlv, stream));
@@ -877,7 +878,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     if (do_chain_b) RV_TRY(heads_bwd(stream));
   }
   if (do_chain_b) {
-    RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
+    RV_K(7, rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
   }
   if (do_w3 && !w3_done) RV_TRY(rv_linear_wgrad(dP3, Hp, z, Lp, Hp, Lp, Bp, p->s_w3, RV_TILE_AUTO, p->ws("dW3"), Lp, RV_SLAB_F32, nullptr, stream));
 
@@ -909,8 +910,8 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     if (!((adam >> i) & 1)) { ++i; continue; }
     int j = i;
     while (j < 10 && ((adam >> j) & 1)) ++j;
-    RV_TRY(rv_adam_multi(ad + i, j - i, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
-                         p->b.step_counter, stream));
+    RV_K(8, rv_adam_multi(ad + i, j - i, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
+                          p->b.step_counter, stream));
     i = j;
   }
   if (adam & 0x101) RV_TRY(fp8_after_update(p, stream));   // fc1.weight or fc4.weight were updated
