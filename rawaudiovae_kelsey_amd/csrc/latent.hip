@@ -790,15 +790,18 @@ k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, cons
                   const long long* __restrict__ step_counter, const int ring_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int bid = (int)blockIdx.x, tid = threadIdx.x;
-  if (bid < n_dz) {
-    if constexpr (BIG) gemm_body<256, 128, 4, 2, true, false, EPI_REPARAM_BWD, HGB_STAGES>(dz, bid, smem_dyn);
-    else gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid, smem_dyn);
+  // the weight-gradient blocks come FIRST in dispatch order: each contracts over a slice of the whole batch and is the
+  // launch's longest block by far at large batches (behind the dz blocks they started when those were done: 413 us at
+  // B = 131072, L = 64)
+  if (bid < n_w3) {
+    // (a padded latent width of 64 leaves no room for 128-column tiles: 128 x 64 there, three ring slots = 72 KiB)
+    if (w3grad.N_valid < 128) gemm_body<128, 64, 4, 2, false, false, EPI_F32, 3>(w3grad, bid, smem_dyn);
+    else gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid, smem_dyn);
     return;
   }
-  if (bid < n_dz + n_w3) {
-    // (a padded latent width of 64 leaves no room for 128-column tiles: 128 x 64 there, three ring slots = 72 KiB)
-    if (w3grad.N_valid < 128) gemm_body<128, 64, 4, 2, false, false, EPI_F32, 3>(w3grad, bid - n_dz, smem_dyn);
-    else gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid - n_dz, smem_dyn);
+  if (bid < n_w3 + n_dz) {
+    if constexpr (BIG) gemm_body<256, 128, 4, 2, true, false, EPI_REPARAM_BWD, HGB_STAGES>(dz, bid - n_w3, smem_dyn);
+    else gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid - n_w3, smem_dyn);
     return;
   }
   if (loss_out && mse_partial && kl_partial) {   // the loss scalar (k_reparam_bwd's extra block, same summation order)

@@ -232,6 +232,14 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     p->n_mt3 = (int)(Bp / bm);
   }
   p->s_w3 = splits_of(Hp, Lp, Bp);
+  if (!rv_latent_rowlocal(Bp, Hp, Lp) && Hp % 128 == 0) {
+    // GEMM form of the latent backward (csrc/latent.hip): dW3 runs beside the dz tiles on 128 x 128 (128 x 64 at a padded
+    // latent width of 64) tiles; enough K splits that its blocks fill the chip once, at least 8 K tiles each
+    const long tiles = (Hp / 128) * (Lp >= 128 ? Lp / 128 : 1), kt = Bp / 64;
+    int s = 1;
+    while (tiles * s < 256 && 2 * s <= 16 && kt % (2 * s) == 0 && kt / (2 * s) >= 8) s *= 2;
+    p->s_w3 = s;
+  }
   {
     // heads backward (dgrad with the ReLU mask of h1 + wgrad) also goes through rv_linear_dgrad_wgrad
     int paired = 0, bm = 128, sp = 1;
