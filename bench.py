@@ -811,6 +811,13 @@ def main():
                        "wgrad_slabs": eng.slab_dtype,
                        **({"ddp_mode": "sharded" if getattr(runner, "sharded", False) else "allreduce",
                            "ddp_payload": getattr(runner, "payload", "fp32"),
+                           # how the payload is summed across ranks: by the collective library, in the payload's own type
+                           # (RCCL's rings add bf16 hop by hop: world - 1 roundings per element; error model and gate in
+                           # DESIGN.md section 5 and tests/ddp_shm_worker.py: 2.9e-3 rel-L2 of the averaged gradient against
+                           # the oracle at world 4 in ring order, 2.2e-3 with one fp32 rounding, 7e-3 allowed)
+                           "ddp_payload_accumulate": ("fp32 (exact mean)" if getattr(runner, "payload", "fp32") == "fp32" else
+                                                      "bf16 hop by hop inside the collective (RCCL); stand-in rehearsals: fp32, "
+                                                      "rounded once" if not rehearsal else "fp32, rounded once (stand-in collectives)"),
                            "shard_gather": getattr(eng, "shard_gather", None)} if runner is not None else {}),
                        "grad_allreduce": ddp_mode},
             # `value` / `ms_per_step` are the MEDIAN over `repeats` passes of exactly `steps` steps each

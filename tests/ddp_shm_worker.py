@@ -172,6 +172,47 @@ def main():
         elif rank == 0:
             print("DDP_VS_ORACLE_OK %r" % ((S, H, L, B),), flush=True)
         del ro, eo
+        # ---- the bf16 gradient payload (what bench.py selects at N > 1) against the same oracle, under BOTH accumulation
+        # orders a collective library may use: fp32 with one rounding (kindest) and -- what a ring all-reduce in the
+        # payload's type does -- bf16 hop by hop, world - 1 roundings per element (harshest; tools/fake_collective.hip
+        # shm_set_bf16_ring).  Error model (tests/test_ddp_cpu.py::test_bf16_payload_error_model_ring_order
+        # holds the arithmetic to it): every rounding to bf16 is relative 1.66e-3 rms of the value rounded; the payload costs
+        # one rounding of each rank's sum plus, in ring order, world - 1 roundings of the growing partial sums -- 2.3e-3 /
+        # 2.7e-3 / 3.2e-3 of the mean at world 2 / 4 / 8 for ranks whose gradients are a common signal plus equal noise
+        # (2.3e-3 / 2.0e-3 / 1.8e-3 with one fp32-accumulated rounding) -- combined in quadrature with the bf16 step's own
+        # distance from the oracle (1e-4 .. 1.5e-3 per tensor).  Gate: 7e-3 rel-L2 per tensor (5e-3 with the fp32 payload); the
+        # measured worst tensor is printed per order (C2, world 4: 2.9e-3 ring order, 2.2e-3 single rounding).
+        for ring_order in (False, True):
+            comm.set_bf16_ring(ring_order)
+            e16 = fresh()
+            r16 = ddp.NativeDdpRunner(e16, comm, st, payload="bf16")
+            e16.set_ddp_w1_wide(False)
+            with torch.cuda.stream(st):
+                e16.step_ddp(torch.from_numpy(xr[rank]).to(dev), eps=torch.from_numpy(er[rank]).to(dev), stream=st)
+            torch.cuda.synchronize()
+            bad, worst = [], 0.0
+            for k in PARAM_NAMES:
+                g_hip = e16.view(e16.exp_avg, k).double().cpu().numpy() / 0.1
+                rel = float(np.linalg.norm(g_hip - g_o[k]) / (np.linalg.norm(g_o[k]) + 1e-300))
+                worst = max(worst, rel)
+                if rel > 7e-3:
+                    bad.append("%s: averaged gradient rel-L2 %.3g vs the oracle (tol 7e-3)" % (k, rel))
+                dp_ = np.abs(e16.view(e16.param, k).double().cpu().numpy() - p64[k])
+                # (Adam's first step moves every element by ~lr in the direction of its gradient's sign; an element whose
+                # near-zero gradient changes sign under the payload's rounding moves the other way, 2 lr apart: bounded
+                # per element, and rare on average -- where a tensor has enough elements for an average to mean that)
+                if dp_.max() > 2.1 * LR or (dp_.size >= 1024 and dp_.mean() > 0.05 * LR):
+                    bad.append("%s: parameters differ from oracle.train_step by max %.2f lr, mean %.3f lr" % (k, dp_.max() / LR, dp_.mean() / LR))
+            if not agree(same_on_all_ranks(e16.param)):
+                bad.append("replicas differ")
+            tag16 = "bf16 payload, %s accumulation" % ("bf16 ring-order" if ring_order else "fp32 single-rounding")
+            if not agree(not bad):
+                failures.append("%r native step (%s) vs oracle.train_step on the concatenated batch: %s" % (
+                    (S, H, L, B), tag16, "; ".join(bad) or "failed on another rank"))
+            elif rank == 0:
+                print("DDP_BF16_PAYLOAD_VS_ORACLE_OK %r world %d %s: worst tensor rel-L2 %.2e" % ((S, H, L, B), world, tag16, worst), flush=True)
+            del r16, e16
+        comm.set_bf16_ring(False)
         dist.barrier()
         comm.destroy()
     dist.barrier()

@@ -262,3 +262,44 @@ def test_ranks_wait_for_rank_zero_behind_a_checkpoint_longer_than_the_flag_bound
     src = inspect.getsource(train.main)
     assert src.index("torch.save(checkpoint_state(epoch)") < src.index("dp.rendezvous()") < src.index("final_loss = train_loss")
 
+
+def test_bf16_payload_error_model_ring_order():
+    """The bf16 gradient payload's cost in accuracy, as arithmetic: w ranks' gradients, each rounded
+    to bf16 once, summed (a) in fp32 and rounded once -- the kindest order a collective may use, the stand-in's default --
+    and (b) hop by hop in bf16 in ring order, w - 1 roundings -- what a ring all-reduce in the payload's type does, the
+    harshest.  One round-to-nearest to bf16's 8 significant bits is a relative error of sigma = 2^-8 / sqrt(3) x 0.7355 =
+    1.66e-3 rms (uniform within half an ulp of 2^-7 at the bottom of a binade, averaged over the binade).  Model: each
+    rank's own rounding (independent: averaged down by the mean) plus one rounding of every partial sum on the way --
+    sigma / (w |mean|) x sqrt(sum_r |g_r|^2 + sum_{k=2..w} |g_1 + .. + g_k|^2).  For ranks whose gradients are a common
+    signal plus noise of the same size that is 2.3e-3 / 2.7e-3 / 3.2e-3 of the exact mean at w = 2 / 4 / 8 in ring order
+    and 2.3e-3 / 2.0e-3 / 1.8e-3 with one fp32-accumulated rounding; the emulation below follows the model within 15 %.
+    The GPU test (tests/ddp_shm_worker.py) measures the payload's error TOGETHER with the bf16 step's own distance from the
+    oracle: 2.9e-3 (ring order) / 2.2e-3 (one rounding) at w = 4 on C2, against a gate of 7e-3."""
+    def bf16(a):
+        u = a.astype(np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).view(np.float32)
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    sigma = 2.0 ** -8 / np.sqrt(3.0) * 0.7355   # rms relative error of one round-to-nearest to 8 significant bits
+    for w in (2, 4, 8):
+        # per-rank gradients: a common signal plus rank noise of the same size (the ranks see different batches)
+        g = (rng.standard_normal(n) + rng.standard_normal((w, n))).astype(np.float32) * 1e-6
+        exact = g.astype(np.float64).mean(0)
+        q = np.stack([bf16(x) for x in g])
+        once = bf16(q.astype(np.float64).sum(0).astype(np.float32)).astype(np.float64) / w
+        run = q[0].copy()
+        for k in range(1, w):
+            run = bf16(run + q[k])
+        ring = run.astype(np.float64) / w
+        rel = lambda a: float(np.linalg.norm(a - exact) / np.linalg.norm(exact))
+        # model: each rank's own rounding (independent, averaged) + the roundings of the growing partial sums
+        own = sigma * np.sqrt((g.astype(np.float64) ** 2).sum()) / w / np.linalg.norm(exact)
+        part = np.cumsum(q.astype(np.float64), axis=0)
+        hops = sigma * np.sqrt(sum((part[k] ** 2).sum() for k in range(1, w))) / w / np.linalg.norm(exact)
+        model_ring = float(np.sqrt(own ** 2 + hops ** 2))
+        model_once = float(np.sqrt(own ** 2 + sigma ** 2))
+        assert abs(rel(ring) - model_ring) <= 0.15 * model_ring, (w, rel(ring), model_ring)
+        assert abs(rel(once) - model_once) <= 0.15 * model_once, (w, rel(once), model_once)
+        assert rel(ring) <= {2: 2.6e-3, 4: 3.0e-3, 8: 3.6e-3}[w], (w, rel(ring))
+        assert rel(once) <= rel(ring) + 1e-5
+

@@ -90,6 +90,12 @@ def test_native_ddp_step_two_processes_one_gpu(world):
     # HIP against the oracle (the worker's last section): the two-process native step on per-rank batches equals
     # oracle.train_step on the concatenated batch, at both shapes
     assert r.stdout.count("DDP_VS_ORACLE_OK") == 2, r.stdout[-2000:]
+    # ... and with the bf16 gradient payload (bench.py's choice at N > 1) under both accumulation orders -- fp32 with one
+    # rounding, and bf16 hop by hop in ring order as a ring all-reduce in the payload's type sums it (world - 1 roundings)
+    # -- 7e-3 rel-L2 per tensor against the same oracle; the measured worst tensor is printed per order and shape
+    lines = [l for l in r.stdout.splitlines() if l.startswith("DDP_BF16_PAYLOAD_VS_ORACLE_OK")]
+    assert len(lines) == 4 and sum("ring-order" in l for l in lines) == 2, r.stdout[-3000:]
+    print("\n".join(lines))
 
 
 def test_native_rccl_step_one_rank_equals_local_step():

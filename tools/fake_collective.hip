@@ -79,6 +79,7 @@ struct ShmComm {
   size_t map_bytes;
   char name[128];
   std::vector<char> tmp;
+  int bf16_ring = 0;     // shm_set_bf16_ring
 };
 
 static double now_s() {
@@ -137,6 +138,11 @@ extern "C" void* shm_comm_create(const char* name, int world, int rank, size_t c
   return c;
 }
 
+// 1: bf16 all-reduces / reduce-scatters accumulate hop by hop in bf16, in ring order (see reduce_into); 0 (default): in fp32
+extern "C" void shm_set_bf16_ring(void* comm, int on) {
+  if (comm) ((ShmComm*)comm)->bf16_ring = on ? 1 : 0;
+}
+
 extern "C" void shm_comm_destroy(void* comm) {
   ShmComm* c = (ShmComm*)comm;
   if (!c) return;
@@ -151,9 +157,26 @@ static uint16_t f_to_bf16(float f) {   // round to nearest even (no NaNs in thes
   return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// out[i] = sum over ranks of slot_r[off + i], i in [0, n): fp32 in rank order; bf16 accumulated in fp32 and rounded
-// once (RCCL's own order of bf16 additions is not specified)
-static void reduce_into(ShmComm* c, size_t elem_off, size_t n, int dtype, char* out) {
+// out[i] = sum over ranks of slot_r[off + i], i in [0, n): fp32 in rank order.  bf16: accumulated in fp32 and rounded once
+// (bf16_ring = 0: the kindest order a collective library could use), or -- bf16_ring = 1, shm_set_bf16_ring -- as a RING
+// reduce-scatter does it: the element's chunk (n_total / world elements each) starts at rank (chunk + 1) % world and every
+// hop adds the next rank's value and rounds the running sum to bf16 again: world - 1 roundings, the harshest order
+// (RCCL's ring sums in the payload's type hop by hop).  `n_total`: the element count of the whole collective.
+static void reduce_into(ShmComm* c, size_t elem_off, size_t n, int dtype, char* out, size_t n_total = 0) {
+  if (dtype == 9 && c->bf16_ring && c->world > 1) {
+    uint16_t* o = (uint16_t*)out;
+    const size_t total = n_total ? n_total : n, chunk = (total + c->world - 1) / c->world;
+    for (size_t i = 0; i < n; ++i) {
+      const int start = (int)(((elem_off + i) / chunk + 1) % c->world);
+      uint16_t run = ((const uint16_t*)(c->slots + start * c->cap))[elem_off + i];
+      for (int k = 1; k < c->world; ++k) {
+        const int r = (start + k) % c->world;
+        run = f_to_bf16(bf16_to_f(run) + bf16_to_f(((const uint16_t*)(c->slots + r * c->cap))[elem_off + i]));
+      }
+      o[i] = run;
+    }
+    return;
+  }
   if (dtype == 7) {
     float* o = (float*)out;
     for (size_t i = 0; i < n; ++i) {
@@ -193,7 +216,7 @@ extern "C" int shm_reduce_scatter(const void* send, void* recv, size_t recvcount
   SHM_TRY(hipStreamSynchronize((hipStream_t)stream));
   SHM_TRY(hipMemcpy(c->slots + c->rank * c->cap, send, bytes, hipMemcpyDeviceToHost));
   if (shm_barrier(c)) return 1;
-  reduce_into(c, (size_t)c->rank * recvcount, recvcount, dtype, c->tmp.data());
+  reduce_into(c, (size_t)c->rank * recvcount, recvcount, dtype, c->tmp.data(), recvcount * c->world);
   if (shm_barrier(c)) return 1;
   SHM_TRY(hipMemcpy(recv, c->tmp.data(), recvcount * es, hipMemcpyHostToDevice));
   return 0;

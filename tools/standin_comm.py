@@ -32,6 +32,12 @@ class ShmComm:
         self.reduce_scatter_addr = C.cast(lib.shm_reduce_scatter, C.c_void_p)
         self.all_gather_addr = C.cast(lib.shm_all_gather, C.c_void_p)
 
+    def set_bf16_ring(self, on):
+        """bf16 payloads summed hop by hop in bf16, in ring order (world - 1 roundings per element: what a ring all-reduce
+        in the payload's type does, the harshest order) instead of in fp32 with one rounding (the default, the kindest)."""
+        self._lib.shm_set_bf16_ring.argtypes = [C.c_void_p, C.c_int]
+        self._lib.shm_set_bf16_ring(self.handle, int(bool(on)))
+
     def self_test(self, device=None):
         """(RcclComm's interface; the exchange itself is exercised by the caller's first step)"""
 
