@@ -15,7 +15,7 @@ fast, consecutive replays are a few us apart).
 N > 1: one process per GPU; each step is one `rv_plan_step_ddp` call that also issues the RCCL collectives (all-reduce
 schedule, two buckets; the bf16 gradient payload by explicit choice of this bench -- named in `config.ddp_payload`, with
 the library's default, the exact fp32 mean, timed beside it as `alt_fp32_payload`: DESIGN.md section 5;
-`RV_DDP_MODE=sharded` / `RV_DDP_PAYLOAD=fp32` select the alternatives).  Weak scaling: per-GPU batch fixed.  Before it is
+`RV_DDP_PAYLOAD=fp32` selects the exact mean; `alt_fp32_payload` and `alt_no_defer` are timed beside the headline).  Weak scaling: per-GPU batch fixed.  Before it is
 timed the library-driven step is checked on scratch engines against the torch.distributed route; after every section
 that can fail on one rank alone the ranks AGREE on success (a MIN all-reduce) -- if any rank failed inside a step, every
 rank exits non-zero instead of going on to a collective its peers will never join.
@@ -412,7 +412,6 @@ def main():
     # that cannot be created) selects the torch.distributed route: six host calls + three dist.all_reduce per step.
     runner, ddp_mode, comm = None, None, None
     native_fallback_reason, startup_check = None, None
-    sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
     # the bench's exchange is an explicit choice, named in the line (config.ddp_payload): bf16 gradient payload -- what the
     # 8-GPU target is sized against -- with the library's default (fp32, the exact mean) timed beside it (alt_fp32_payload)
     payload = os.environ.get("RV_DDP_PAYLOAD", ddp.BENCH_PAYLOAD)
@@ -448,7 +447,7 @@ def main():
                 reasons = [None] * world
                 dist.all_gather_object(reasons, why)
                 native_fallback_reason = "; ".join("rank %d: %s" % (i, r) for i, r in enumerate(reasons) if r) or "another rank failed"
-        if ok and os.environ.get("RV_DDP_CHECK", "1") == "1":
+        if ok:
             # The library-driven step is checked before it is timed, on scratch engines: three steps of it against three
             # steps of the torch.distributed route from the same weights on the same batches.  Replicas must end
             # bit-identical, and the two routes' parameters must agree (Adam moves every element by ~lr per step, so
@@ -460,8 +459,7 @@ def main():
                 for e in (ea, eb):
                     e.load_params(make_params(S, H, L, 0))
                 # (the checked runner defers its tail exactly as the timed one will: RV_DDP_DEFER)
-                ra = ddp.NativeDdpRunner(ea, comm, comp, sharded=sharded, payload=None if sharded else payload,
-                                         defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
+                ra = ddp.NativeDdpRunner(ea, comm, comp, payload=payload, defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
                 rb = ddp.DdpRunner(eb, ddp.GradSync(eb.grad, ddp.engine_buckets(eb)), comp, use_graphs=False)
                 with torch.cuda.stream(comp):   # same seed and step counters: both engines draw the same eps
                     for i in range(3):
@@ -469,7 +467,6 @@ def main():
                         rb.step(pool[i % POOL])
                     ra.flush()
                 torch.cuda.synchronize()
-                ddp.gather_sharded_params(ea)
                 chk = torch.stack([ea.param.double().sum(), ea.param.double().abs().sum(),
                                    ea.buffer("W4b", torch.bfloat16, (-1,)).double().abs().sum()])
                 lo, hi = chk.clone(), chk.clone()
@@ -493,17 +490,11 @@ def main():
         if ok:
             # RV_DDP_DEFER=0: every step completes itself (default 1: a step's last wait + update go out behind the next
             # step's cast launch -- include/rawvae_hip.h RV_OPT_DDP_DEFER_TAIL; the timed region ends with the flush)
-            runner = ddp.NativeDdpRunner(eng, comm, comp, use_graph=os.environ.get("RV_DDP_GRAPH") == "1", sharded=sharded,
-                                         payload=None if sharded else payload, defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
-            if sharded:
-                ddp_mode = ("sharded optimizer: fp32 reduce-scatter (fc4 | rest) -> Adam on this rank's 1/%d of the arena -> "
-                            "all-gather of %s, all issued by rv_plan_step_ddp" % (
-                                world, "the 16-bit parameter message (bf16 weights + fp32 biases)"
-                                if getattr(eng, "shard_gather", "fp32") == "bf16" else "the fp32 parameters"))
-            else:
-                ddp_mode = ("%s all-reduce, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its collective "
-                            "stream: fc4's behind the rest of backward, the second behind Adam(fc4)%s" % (
-                                runner.payload, "; a step's last wait + update enqueued behind the next step's cast" if runner.defer else ""))
+            runner = ddp.NativeDdpRunner(eng, comm, comp, payload=payload,
+                                         defer=os.environ.get("RV_DDP_DEFER", "1") == "1")
+            ddp_mode = ("%s all-reduce, 2 buckets (fc4 | fc1,fc21,fc22,fc3) issued by rv_plan_step_ddp on its collective "
+                        "stream: fc4's behind the rest of backward, the second behind Adam(fc4)%s" % (
+                            runner.payload, "; a step's last wait + update enqueued behind the next step's cast" if runner.defer else ""))
             ddp_mode += ", hipGraph" if runner.use_graph else ""
         else:
             sync = ddp.GradSync(eng.grad, ddp.engine_buckets(eng))
@@ -597,7 +588,6 @@ def main():
             """Replicas must hold identical weights after identical averaged updates."""
             if not multi or world == 1:
                 return None
-            ddp.gather_sharded_params(e)   # 16-bit parameter message: fp32 weight masters live on their owners
             chk = torch.stack([e.param.double().sum(), e.param.double().abs().sum(),
                                e.buffer("W1b", torch.bfloat16, (-1,)).double().sum(),
                                e.buffer("W4b", torch.bfloat16, (-1,)).double().abs().sum()])
@@ -626,7 +616,7 @@ def main():
 
         # ---- side lines at N > 1 (never the headline; each is entered by every rank or by none) ----
         ddp_alts = {}
-        if isinstance(runner, ddp.NativeDdpRunner) and not runner.sharded and os.environ.get("RV_DDP_ALT", "1") != "0" \
+        if isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") != "0" \
                 and agree(replicas_consistent is not False, "headline replicas identical"):
             # the same schedule with the OTHER gradient payload (fp32 = the exact mean, twice the bytes on the links),
             # on the same engine: what the exchange costs at this GPU count
@@ -645,30 +635,30 @@ def main():
                 if multi:
                     die_together("side line (other payload) raised", "%s: %s" % (type(exc).__name__, str(exc)[:300]))
                 ddp_alts["alt_%s_payload" % other] = {"error": str(exc)[:200]}
-        if isinstance(runner, ddp.NativeDdpRunner) and os.environ.get("RV_DDP_ALT", "1") == "2":
-            # opt-in (RV_DDP_ALT=2): the other SCHEDULE on a second engine (sharded optimizer <-> all-reduce)
+        if isinstance(runner, ddp.NativeDdpRunner) and runner.defer and os.environ.get("RV_DDP_ALT", "1") != "0" \
+                and agree(replicas_consistent is not False, "headline replicas identical (before alt_no_defer)"):
+            # the same schedule and payload with every step completing itself (RV_OPT_DDP_DEFER_TAIL off: the library's and
+            # train.py's default) on a second engine -- round-5 advisor: the headline's deferred tail was sized on a one-GPU
+            # model; this is its measured worth on the node the line was taken on
             try:
                 eng2 = E.TrainEngine(S, H, L, B, device=dev, kl_beta=KL_BETA, lr=LR, seed=1000 + rank, ring=256)
                 eng2.load_params(make_params(S, H, L, 0))
-                run2 = ddp.NativeDdpRunner(eng2, comm, comp, sharded=not runner.sharded)
+                run2 = ddp.NativeDdpRunner(eng2, comm, comp, payload=runner.payload, defer=False)
                 for i in range(args.warmup + 1):
                     run2.step(pool[i % POOL])
                 torch.cuda.synchronize()
-                sp_, _ = timed_passes(lambda i: run2.step(pool[i % POOL]), n_rep=min(len(passes), 25))
-                key = "alt_sharded" if run2.sharded else "alt_allreduce"
-                ddp_alts[key] = {"grad_allreduce": "sharded optimizer (reduce-scatter, Adam on 1/%d of the arena, all-gather of the %s)"
-                                 % (world, "16-bit parameter message" if getattr(eng2, "shard_gather", "fp32") == "bf16" else "fp32 parameters")
-                                 if run2.sharded else "%s all-reduce schedule" % run2.payload,
-                                 "ms_per_step": sp_[len(sp_) // 2] / args.steps * 1e3,
-                                 "value": float(B) * world * args.steps / sp_[len(sp_) // 2], "repeats": len(sp_)}
+                sp_, _ = timed_passes(lambda i: run2.step(pool[i % POOL]), n_rep=min(len(passes), 7))
+                ddp_alts["alt_no_defer"] = {"grad_allreduce": "%s payload, every step completing itself" % run2.payload,
+                                            "ms_per_step": sp_[len(sp_) // 2] / args.steps * 1e3,
+                                            "value": float(B) * world * args.steps / sp_[len(sp_) // 2], "repeats": len(sp_)}
                 rc2 = replicas_identical(eng2)
                 if rc2 is not None:
-                    ddp_alts[key]["replicas_consistent"] = rc2
+                    ddp_alts["alt_no_defer"]["replicas_consistent"] = rc2
                 del run2, eng2
             except Exception as exc:
                 if multi:
-                    die_together("side line (other schedule) raised", "%s: %s" % (type(exc).__name__, str(exc)[:300]))
-                ddp_alts["alt_schedule"] = {"error": str(exc)[:200]}
+                    die_together("side line (no deferred tail) raised", "%s: %s" % (type(exc).__name__, str(exc)[:300]))
+                ddp_alts["alt_no_defer"] = {"error": str(exc)[:200]}
 
         # ---- per-launch timing and side lines at N = 1 ----
         launches, noise_us = None, None
@@ -809,7 +799,7 @@ def main():
                        "launch": "hipGraph (one graph of %d steps)" % POOL if pool_graph is not None else
                                  "hipGraph" if (use_graph or getattr(runner, "use_graph", False)) else "eager",
                        "wgrad_slabs": eng.slab_dtype,
-                       **({"ddp_mode": "sharded" if getattr(runner, "sharded", False) else "allreduce",
+                       **({"ddp_mode": "allreduce",
                            "ddp_payload": getattr(runner, "payload", "fp32"),
                            # how the payload is summed across ranks: by the collective library, in the payload's own type
                            # (RCCL's rings add bf16 hop by hop: world - 1 roundings per element; error model and gate in
@@ -817,8 +807,8 @@ def main():
                            # the oracle at world 4 in ring order, 2.2e-3 with one fp32 rounding, 7e-3 allowed)
                            "ddp_payload_accumulate": ("fp32 (exact mean)" if getattr(runner, "payload", "fp32") == "fp32" else
                                                       "bf16 hop by hop inside the collective (RCCL); stand-in rehearsals: fp32, "
-                                                      "rounded once" if not rehearsal else "fp32, rounded once (stand-in collectives)"),
-                           "shard_gather": getattr(eng, "shard_gather", None)} if runner is not None else {}),
+                                                      "rounded once" if not rehearsal else "fp32, rounded once (stand-in collectives)")}
+                          if runner is not None else {}),
                        "grad_allreduce": ddp_mode},
             # `value` / `ms_per_step` are the MEDIAN over `repeats` passes of exactly `steps` steps each
             "timing": {"repeats": len(passes), "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),

@@ -337,28 +337,9 @@ int rv_linear_wgrad_adam(const void* dy_bf16, long lddy, const void* x_bf16, lon
                          float* param, float* exp_avg, float* exp_avg_sq, float lr, float grad_scale,
                          const long long* step_counter, int n_adam_blocks, void* stream);
 
-/* Sharded data-parallel optimizer (rv_plan_step_ddp in sharded mode; also callable on their own):
- * rv_adam_flat: the Adam update of elements [lo, lo + n) of the flat arenas, gradient element i of the shard at
- *   grad_shard[i] (a reduce-scatter's output), multiplied by grad_scale first.
- * rv_params_from_flat: parameters (unless `param` is NULL: shadows only; `flat` may then be the parameter arena
- *   itself, which is how rv_plan_refresh_shadows rebuilds all shadows in one launch) AND every operand shadow of the
- *   `descs` tensors from a flat fp32 source (an
- *   all-gather's output): arena element o is flat[o - flat_base]. */
-/* The same exchange with a 16-bit parameter message (half the all-gather bytes).  After updating its shard a rank
- * encodes it: bf16 (round to nearest even, the rounding of the operand shadows) of the shard's `cnt` elements,
- * followed by the bucket's bias elements as fp32 (a rank fills those it owns, zeroes the rest);
- * rv_shard_msg_slots gives the message length in 16-bit slots (a multiple of 8).  An all-gather of that many slots
- * per rank lets rv_shadows_from_msg rebuild every bf16 weight shadow and, exactly, every bias (fp32 shadow and the
- * parameter arena) of the `descs` tensors from the rank-major gathered buffer.  fp32 weight masters then stay current
- * on their owner rank only (gather them before a checkpoint, like the moments).  Tensors with an fp8 shadow are
- * refused: their shadow is derived from the fp32 value. */
-long rv_shard_msg_slots(const rv_param_desc* descs, int n_desc, long cnt);
-int rv_shard_encode(const rv_param_desc* descs, int n_desc, const float* param, long own, long n, long cnt, void* msg,
-                    void* stream);
-int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg, long lo, long cnt, long slots,
-                        float* param, void* stream);
-int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
-                 float grad_scale, const long long* step_counter, void* stream);
+/* Parameters (unless `param` is NULL: shadows only; `flat` may then be the parameter arena itself, which is how
+ * rv_plan_refresh_shadows rebuilds all shadows in one launch) AND every operand shadow of the `descs` tensors from a flat
+ * fp32 source: arena element o is flat[o - flat_base]. */
 int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
                         void* stream);
 
@@ -569,36 +550,15 @@ int rv_plan_step_frames(rv_plan*, int phases, const float* audio, const void* au
  * no host synchronisation, capturable in a hipGraph.  Needs a grad arena and a non-default stream. */
 typedef int (*rv_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
                                void* comm, void* stream);
-/* Sharded mode of rv_plan_step_ddp (optimizer state and update sharded over the ranks): per gradient bucket
- * (0: fc4 = arena elements [offset of fc4.weight, n_params); 1: everything before it) the flat fp32 gradients are
- * REDUCE-SCATTERED (each rank receives the sum of its `rv_plan_shard_count` elements), the rank runs Adam on its shard
- * only (rv_adam_flat), the updated parameters are ALL-GATHERED and every rank rebuilds its operand shadows from the
- * gathered buffer.  Per rank: 1/world of Adam's 30 B/param instead of all of it, the same bytes on the links as an
- * all-reduce.  exp_avg / exp_avg_sq are valid on their owner rank only.  `reduce_scatter` / `all_gather` have RCCL's
- * ncclReduceScatter / ncclAllGather signatures. */
-typedef int (*rv_reduce_scatter_fn)(const void* sendbuf, void* recvbuf, size_t recvcount, int dtype, int op, void* comm,
-                                    void* stream);
-typedef int (*rv_all_gather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, void* stream);
-/* Elements per rank of a bucket's shard (msg_slots == 0; host arithmetic only: a bucket is cut into `world` equal
- * shards of a multiple of 4 elements, so the last shard can overhang its bucket), or the length in 16-bit slots of
- * that shard's parameter message (msg_slots != 0, bound plan; see rv_shard_encode). */
-long rv_plan_shard_count(const rv_plan*, int bucket, int world, int msg_slots);
 /* Everything rv_plan_step_ddp needs from the caller, in one descriptor (copied; attach again to change a field,
- * comm == NULL detaches and keeps only comm_stream).  All-reduce mode: `allreduce`; sharded mode: `reduce_scatter` AND
- * `all_gather` with rs_buf / ag_buf. */
+ * comm == NULL detaches and keeps only comm_stream).  (Rounds 3-5 also carried a sharded-optimizer schedule -- reduce-scatter,
+ * Adam on a rank's 1 / world of the arenas, all-gather of parameters or of a 16-bit parameter message; it won no row of the
+ * 8-rank model (a second collective's start-up for an update that is 13 us to begin with) and was
+ * removed in round 6.) */
 typedef struct rv_comm_desc {
   void* comm; int world; int rank;
   rv_allreduce_fn allreduce;
-  rv_reduce_scatter_fn reduce_scatter;
-  rv_all_gather_fn all_gather;
-  float* rs_buf;   /* sharded: sum over the buckets of rv_plan_shard_count floats, 16-byte aligned                  */
-  float* ag_buf;   /*          `world` times that; the caller's param / grad arenas extend 4 * world past n_params   */
-  void* msg_send;  /* sharded, optional: the 16-bit parameter message (rv_shard_encode / rv_shadows_from_msg) instead */
-  void* msg_recv;  /*   of the fp32 all-gather -- half the bytes of the exchange nothing hides.  msg_send holds the    */
-                   /*   sum over the buckets of rv_plan_shard_count(.., 1) slots, msg_recv `world` times that; weight  */
-                   /*   shadows and biases are bit-identical to the fp32 route on every rank, fp32 weight masters are  */
-                   /*   current on their owner rank only.  NULL, NULL: fp32 all-gather.  Not with the fp8 forward.     */
-  void* grad_bf16; /* all-reduce, optional: bf16 payload -- each rank's summed gradient rounded to bf16 into this arena */
+  void* grad_bf16; /* optional: bf16 payload -- each rank's summed gradient rounded to bf16 into this arena */
                    /*   (as many 2-byte elements as the fp32 arenas hold floats) and summed by the collective in bf16;  */
                    /*   NULL: fp32, the exact mean of the ranks' fp32 gradients                                         */
   void* comm_stream; /* the stream the collectives are issued on, or NULL: one high-priority stream per process,     */

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RV_LIB", os.path.join(_HERE, "librawvae_hip.so"))  # RV_LIB: experiment builds
+LIB_PATH = os.path.join(_HERE, "librawvae_hip.so")
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 c_u64, c_i64 = C.c_ulonglong, C.c_longlong
@@ -35,8 +35,7 @@ class PlanBuffers(C.Structure):
 class CommDesc(C.Structure):
     """rv_comm_desc: everything rv_plan_step_ddp needs from the caller."""
     _fields_ = [("comm", c_void_p), ("world", c_int), ("rank", c_int), ("allreduce", c_void_p),
-                ("reduce_scatter", c_void_p), ("all_gather", c_void_p), ("rs_buf", c_void_p), ("ag_buf", c_void_p),
-                ("msg_send", c_void_p), ("msg_recv", c_void_p), ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
+                ("grad_bf16", c_void_p), ("comm_stream", c_void_p)]
 
 
 OPT_LATENT_FUSED, OPT_FP8, OPT_SLAB_DTYPE, OPT_ROCTX, OPT_DDP_SIGNAL, OPT_DDP_W1_WIDE, OPT_DDP_WAIT_MS = 0, 1, 2, 3, 4, 5, 6
@@ -125,11 +124,7 @@ _SIGS = {
                              c_float, c_int, c_u64, c_void_p]),
     "rv_plan_step_frames": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_int, c_u64, c_void_p]),
-    "rv_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_float, c_float, c_void_p, c_void_p]),
     "rv_params_from_flat": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_void_p, c_void_p]),
-    "rv_shard_msg_slots": (c_long, [C.POINTER(ParamDesc), c_int, c_long]),
-    "rv_shard_encode": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
-    "rv_shadows_from_msg": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_void_p]),
     "rv_plan_ddp_flush": (c_int, [c_void_p, c_void_p]),
     "rv_plan_step_ddp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_u64, c_void_p]),
     "rv_plan_buffer": (c_void_p, [c_void_p, C.c_char_p, C.POINTER(c_long)]),
@@ -148,7 +143,6 @@ _SIGS = {
     "rv_grad_finalize": (c_int, [C.POINTER(ParamDesc), c_int, c_void_p, c_int, c_void_p]),
     "rv_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "rv_plan_attach_comm": (c_int, [c_void_p, C.POINTER(CommDesc)]),
-    "rv_plan_shard_count": (c_long, [c_void_p, c_int, c_int, c_int]),
 }
 
 EXPORTED = tuple(_SIGS)
@@ -169,10 +163,7 @@ def _wrap(fn, name):
 class _Lib:
     def __init__(self, path):
         self._cdll = C.CDLL(path)
-        lax = os.environ.get("RV_LIB_LAX") == "1"   # A/B runs against an older experiment build (RV_LIB)
         for name, (res, args) in _SIGS.items():
-            if lax and not hasattr(self._cdll, name):
-                continue
             fn = getattr(self._cdll, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args

@@ -171,11 +171,8 @@ __global__ void __launch_bounds__(256) k_fp8_wmax(const unsigned char* __restric
   }
 }
 
-// store policy of the cast's bf16 output: the plan's (common.h rv_store_wt); RV_CAST_WT=0 keeps plain stores (A/B)
-static inline int cast_wt() {
-  static const int off = [] { const char* e = getenv("RV_CAST_WT"); return e && e[0] == '0'; }();
-  return off ? 0 : rv::rv_store_wt;
-}
+// store policy of the cast's bf16 output: the plan's (common.h rv_store_wt; A/B: profiles/r05_ab_cast_wt.txt)
+static inline int cast_wt() { return rv::rv_store_wt; }
 
 __global__ void __launch_bounds__(256) k_cast_pad_bf16(const float* __restrict__ src, long rows,
                                                        long cols, long ld_src,
@@ -635,65 +632,6 @@ k_gather_frames(const float* __restrict__ audio, long n_samples, const long long
 }
 
 
-// ---- sharded data-parallel optimizer (rv_plan_step_ddp, sharded mode) ----
-// Adam on one rank's contiguous shard [lo, lo + n) of the flat arenas; the gradient comes from the reduce-scatter's
-// output buffer (element i of the shard at grad_shard[i]).  Same arithmetic, in the same order, as adam_block.
-struct MsgBias { long offset, n, side; };            // arena offset, elements, first index in the side region
-struct MsgBiasTable { MsgBias b[4]; int n; };
-
-__global__ void __launch_bounds__(256)
-k_adam_flat(float* __restrict__ param, float* __restrict__ m_arena, float* __restrict__ v_arena,
-            const float* __restrict__ grad_shard, const long lo, const long n, const float lr, const float grad_scale,
-            const long long* __restrict__ step_counter, unsigned short* __restrict__ msg, const long cnt,
-            const MsgBiasTable bt) {
-  // msg != null: the updated shard also goes out as this rank's 16-bit parameter message (k_shard_encode's layout and
-  // rounding: bf16 of element i at slot i, then the bucket's bias rows as fp32 -- only the owned ones are written,
-  // the rest of the caller's zero-initialised message is never read)
-  auto emit_bias = [&](long o, float w) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < bt.n && o >= bt.b[t].offset && o < bt.b[t].offset + bt.b[t].n)
-        reinterpret_cast<float*>(msg + cnt)[bt.b[t].side + (o - bt.b[t].offset)] = w;
-  };
-  float step_size, bc2s;   // bc2s: 1 / sqrt(1 - beta2^t)
-  adam_step_consts(step_counter, lr, &step_size, &bc2s);
-  const bool vec = (lo & 3) == 0 && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m_arena) |
-                                      reinterpret_cast<uintptr_t>(v_arena) | reinterpret_cast<uintptr_t>(grad_shard)) & 15) == 0;
-  const long n4 = vec ? n >> 2 : 0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float4 g4 = reinterpret_cast<const float4*>(grad_shard)[i];
-    float4 m4 = reinterpret_cast<float4*>(m_arena + lo)[i], v4 = reinterpret_cast<float4*>(v_arena + lo)[i];
-    float4 w4 = reinterpret_cast<float4*>(param + lo)[i];
-    float gv[4] = {g4.x * grad_scale, g4.y * grad_scale, g4.z * grad_scale, g4.w * grad_scale};
-    float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) adam_update(mv[j], vv[j], wv[j], gv[j], step_size, bc2s);
-    reinterpret_cast<float4*>(m_arena + lo)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
-    reinterpret_cast<float4*>(v_arena + lo)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    reinterpret_cast<float4*>(param + lo)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
-    if (msg) {
-      const bf16x4 o = {(bf16_t)wv[0], (bf16_t)wv[1], (bf16_t)wv[2], (bf16_t)wv[3]};
-      *reinterpret_cast<bf16x4*>(msg + 4 * i) = o;
-      if (bt.n)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) emit_bias(lo + 4 * i + j, wv[j]);
-    }
-  }
-  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float g = grad_shard[i] * grad_scale;
-    float m_ = m_arena[lo + i], v_ = v_arena[lo + i], w_ = param[lo + i];
-    adam_update(m_, v_, w_, g, step_size, bc2s);
-    m_arena[lo + i] = m_;
-    v_arena[lo + i] = v_;
-    param[lo + i] = w_;
-    if (msg) {
-      const bf16_t o = (bf16_t)w_;
-      msg[i] = *reinterpret_cast<const unsigned short*>(&o);
-      emit_bias(lo + i, w_);
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256)
 k_params_from_flat(const DescTable tab, const float* flat, const long flat_base, float* param) {
   refresh_block(tab, (long)blockIdx.x, (int)threadIdx.x, flat, flat_base, param);
@@ -707,80 +645,7 @@ inline unsigned grid_for(long n_threads, long cap = 2048) {
 }
 
 
-// ------------------------------------------------------------------ sharded optimizer: 16-bit parameter message
-// What a rank sends after updating its shard [own, own + n) of a bucket [lo, hi) cut into shards of `cnt` elements:
-//   slots [0, cnt)              bf16 (round to nearest even, the rounding of every operand shadow) of param[own + i]
-//   slots [cnt, cnt + 2 nbias)  the bucket's bias elements as fp32 (two slots each, in arena order over the bucket's
-//                               bias tensors); a rank fills the ones it owns and zeroes the others
-// so that an all-gather of cnt + 2 nbias 16-bit slots per rank (half the bytes of the fp32 parameters) lets every rank
-// rebuild every bf16 weight shadow and -- exactly -- every bias.  fp32 weight masters stay current on their owner.
-
-
-__global__ void __launch_bounds__(256)
-k_shard_encode(const float* __restrict__ param, const long own, const long n, const long cnt, const MsgBiasTable bt,
-               const long nbias, unsigned short* __restrict__ msg) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < cnt) {
-    bf16_t v = (bf16_t)(i < n ? param[own + i] : 0.f);
-    msg[i] = *reinterpret_cast<unsigned short*>(&v);
-  }
-  if (i < nbias) {
-    float v = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < bt.n && i >= bt.b[t].side && i < bt.b[t].side + bt.b[t].n) {
-        const long o = bt.b[t].offset + (i - bt.b[t].side);
-        if (o >= own && o < own + n) v = param[o];
-      }
-    }
-    reinterpret_cast<float*>(msg + cnt)[i] = v;
-  }
-}
-
-struct MsgTensor { long offset, rows, cols; bf16_t* shadow_bf16; float* shadow_f32; long shadow_ld; long side; };
-struct MsgTable { MsgTensor t[8]; long blk_start[9]; int n; };
-
-// Every operand shadow of the table's tensors from the gathered messages (rank-major, `slots` 16-bit slots per
-// rank); bias tensors (shadow_f32 != null) also refresh the fp32 parameter arena.  256 threads x 4 elements.
-__global__ void __launch_bounds__(256)
-k_shadows_from_msg(const MsgTable tab, const unsigned short* __restrict__ msg, const long lo, const long cnt,
-                   const long slots, float* __restrict__ param) {
-  const long vblock = blockIdx.x;
-  int t = 0;
-  while (t + 1 < tab.n && vblock >= tab.blk_start[t + 1]) ++t;
-  t = __builtin_amdgcn_readfirstlane(t);
-  const MsgTensor d = tab.t[t];
-  const long gpr = (d.cols + 3) / 4;
-  const long grp = (vblock - tab.blk_start[t]) * 256 + threadIdx.x;
-  if (grp >= gpr * d.rows) return;
-  const unsigned r32 = (unsigned)grp / (unsigned)gpr;
-  const long r = r32, c = (long)((unsigned)grp - r32 * (unsigned)gpr) * 4;
-  const int nvalid = (int)(d.cols - c < 4 ? d.cols - c : 4);
-  const long o = d.offset + r * d.cols + c;
-  if (d.shadow_f32) {   // a bias row: exact fp32 from its owner's side region
-    for (int j = 0; j < nvalid; ++j) {
-      const long rk = (o + j - lo) / cnt;
-      const float v = reinterpret_cast<const float*>(msg + rk * slots + cnt)[d.side + c + j];
-      d.shadow_f32[c + j] = v;
-      param[o + j] = v;
-    }
-    return;
-  }
-  bf16_t* sp = d.shadow_bf16 + r * d.shadow_ld + c;
-  const long rk = (o - lo) / cnt, idx = (o - lo) - rk * cnt;
-  if (nvalid == 4 && idx + 4 <= cnt && (idx & 3) == 0 && (d.shadow_ld & 3) == 0) {
-    *reinterpret_cast<uint2*>(sp) = *reinterpret_cast<const uint2*>(msg + rk * slots + idx);
-  } else {
-    for (int j = 0; j < nvalid; ++j) {
-      const long rj = (o + j - lo) / cnt, ij = (o + j - lo) - rj * cnt;
-      reinterpret_cast<unsigned short*>(sp)[j] = msg[rj * slots + ij];
-    }
-  }
-}
-
 }  // namespace
-
-static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* bt, long* nbias);
 
 extern "C" {
 
@@ -1123,36 +988,6 @@ int rv_adam_multi(const rv_param_desc* descs, int n_desc, float* param, float* e
                                nullptr, stream);
 }
 
-int rv_adam_flat(float* param, float* exp_avg, float* exp_avg_sq, const float* grad_shard, long lo, long n, float lr,
-                 float grad_scale, const long long* step_counter, void* stream) {
-  RV_REQUIRE(param && exp_avg && exp_avg_sq && grad_shard && step_counter, RV_ERR_NULL, "rv_adam_flat: null pointer");
-  RV_REQUIRE(lo >= 0 && n >= 0, RV_ERR_SHAPE, "rv_adam_flat: bad range %ld + %ld", lo, n);
-  if (n == 0) return RV_OK;
-  hipLaunchKernelGGL(k_adam_flat, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, param, exp_avg,
-                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter, (unsigned short*)nullptr, 0L, MsgBiasTable{});
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-// rv_adam_flat that also emits the rank's 16-bit parameter message for the bucket made of `descs` (what rv_shard_encode
-// would produce from the updated parameters, bit for bit; `msg` zero-initialised by the caller once): one pass less.
-int rv_adam_flat_msg(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
-                     const float* grad_shard, long lo, long n, long cnt, float lr, float grad_scale,
-                     const long long* step_counter, void* msg, void* stream) {
-  RV_REQUIRE(descs && param && exp_avg && exp_avg_sq && grad_shard && step_counter && msg, RV_ERR_NULL, "rv_adam_flat_msg: null pointer");
-  RV_REQUIRE(lo >= 0 && n >= 0 && n <= cnt && cnt % 4 == 0 && ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE,
-             "rv_adam_flat_msg: shard of %ld in slots of %ld", n, cnt);
-  if (n == 0) return RV_OK;
-  MsgBiasTable bt;
-  long nbias = 0;
-  int rc = msg_bias_table(descs, n_desc, &bt, &nbias);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_adam_flat, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, param, exp_avg,
-                     exp_avg_sq, grad_shard, lo, n, lr, grad_scale, step_counter, (unsigned short*)msg, cnt, bt);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
 int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* flat, long flat_base, float* param,
                         void* stream) {
   RV_REQUIRE(flat, RV_ERR_NULL, "rv_params_from_flat: null pointer");
@@ -1163,69 +998,6 @@ int rv_params_from_flat(const rv_param_desc* descs, int n_desc, const float* fla
     RV_REQUIRE(descs[i].offset >= flat_base, RV_ERR_SHAPE, "rv_params_from_flat: tensor %d starts before the flat source", i);
   hipLaunchKernelGGL(k_params_from_flat, dim3((unsigned)tab.blk_start[n_desc]), dim3(256), 0, (hipStream_t)stream, tab,
                      flat, flat_base, param);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-// ---- sharded optimizer, 16-bit parameter message (see k_shard_encode)
-}  // extern "C"
-static int msg_bias_table(const rv_param_desc* descs, int n_desc, MsgBiasTable* bt, long* nbias) {
-  bt->n = 0;
-  *nbias = 0;
-  for (int i = 0; i < n_desc; ++i) {
-    if (!descs[i].shadow_f32) continue;   // bias tensors carry a padded fp32 shadow, weights a bf16 one
-    RV_REQUIRE(descs[i].rows == 1 && bt->n < 4, RV_ERR_SHAPE, "shard message: at most four bias rows per bucket");
-    bt->b[bt->n++] = MsgBias{descs[i].offset, descs[i].cols, *nbias};
-    *nbias += descs[i].cols;
-  }
-  return RV_OK;
-}
-extern "C" {
-
-long rv_shard_msg_slots(const rv_param_desc* descs, int n_desc, long cnt) {
-  MsgBiasTable bt;
-  long nbias = 0;
-  if (!descs || msg_bias_table(descs, n_desc, &bt, &nbias)) return -1;
-  return (cnt + 2 * nbias + 7) / 8 * 8;
-}
-
-int rv_shard_encode(const rv_param_desc* descs, int n_desc, const float* param, long own, long n, long cnt, void* msg,
-                    void* stream) {
-  RV_REQUIRE(descs && param && msg, RV_ERR_NULL, "rv_shard_encode: null pointer");
-  RV_REQUIRE(cnt > 0 && cnt % 4 == 0 && n >= 0 && n <= cnt && ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE,
-             "rv_shard_encode: shard of %ld in slots of %ld", n, cnt);
-  MsgBiasTable bt;
-  long nbias = 0;
-  int rc = msg_bias_table(descs, n_desc, &bt, &nbias);
-  if (rc) return rc;
-  const long total = cnt > nbias ? cnt : nbias;
-  hipLaunchKernelGGL(k_shard_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, own, n, cnt,
-                     bt, nbias, (unsigned short*)msg);
-  RV_CHECK_LAUNCH();
-  return RV_OK;
-}
-
-int rv_shadows_from_msg(const rv_param_desc* descs, int n_desc, const void* msg, long lo, long cnt, long slots, float* param,
-                        void* stream) {
-  RV_REQUIRE(descs && msg && param, RV_ERR_NULL, "rv_shadows_from_msg: null pointer");
-  RV_REQUIRE(n_desc >= 1 && n_desc <= 8 && cnt > 0 && cnt % 4 == 0 && slots >= cnt && slots % 8 == 0 &&
-                 ((uintptr_t)msg & 15) == 0, RV_ERR_SHAPE, "rv_shadows_from_msg: bad extents");
-  MsgTable tab;
-  tab.n = n_desc;
-  long blk = 0, side = 0;
-  for (int i = 0; i < n_desc; ++i) {
-    const rv_param_desc& d = descs[i];
-    RV_REQUIRE(d.rows > 0 && d.cols > 0 && d.offset >= lo && (d.shadow_bf16 || d.shadow_f32) && !d.shadow_fp8, RV_ERR_SHAPE,
-               "rv_shadows_from_msg: tensor %d has no shadow to write (or an fp8 one: gather fp32 parameters instead)", i);
-    RV_REQUIRE(d.rows * ((d.cols + 3) / 4) < 0x7fffffffL, RV_ERR_SHAPE, "rv_shadows_from_msg: tensor %d too large", i);
-    tab.t[i] = MsgTensor{d.offset, d.rows, d.cols, (bf16_t*)d.shadow_bf16, d.shadow_f32, d.shadow_ld, side};
-    if (d.shadow_f32) side += d.cols;
-    tab.blk_start[i] = blk;
-    blk += (d.rows * ((d.cols + 3) / 4) + 255) / 256;
-  }
-  tab.blk_start[n_desc] = blk;
-  hipLaunchKernelGGL(k_shadows_from_msg, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, tab, (const unsigned short*)msg, lo,
-                     cnt, slots, param);
   RV_CHECK_LAUNCH();
   return RV_OK;
 }

@@ -565,13 +565,9 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
     if (descs[i].grad_half) stream_mode = 0;
   // Share of the riders' table the GEMM blocks take over behind their tiles (percent of its virtual blocks; update mode
   // with plain-load riders only).  The riders stream at a per-CU rate whatever the GEMM does, so the share is what evens
-  // the two halves out: measured per operand type at C2; RV_WGRAD_TAIL_PCT overrides.
+  // the two halves out: measured per operand type at C2 (the sweep: profiles/r04_tail_sweep.txt).
   int tail_vb = 0;
-  if (!fin_f32 && !fin_bf16 && !stream_mode) {
-    static const int env_pct = [] { const char* e = getenv("RV_WGRAD_TAIL_PCT"); return e ? atoi(e) : -1; }();
-    const int pct = env_pct >= 0 ? (env_pct > 50 ? 50 : env_pct) : (fp8 ? TAIL_PCT_FP8 : TAIL_PCT_BF16);
-    tail_vb = (int)(tab.blk_start[n_desc] * pct / 100);
-  }
+  if (!fin_f32 && !fin_bf16 && !stream_mode) tail_vb = (int)(tab.blk_start[n_desc] * (fp8 ? TAIL_PCT_FP8 : TAIL_PCT_BF16) / 100);
   const bool pp = g.k_tiles % 2 == 0;
   const int which = fp8 ? 2 : (pp ? 1 : 0);
   auto kern = fp8 ? gemm_wgrad_adam_kernel<8, true> : (pp ? gemm_wgrad_adam_kernel<8, false> : gemm_wgrad_adam_kernel<2, false>);

@@ -50,12 +50,6 @@ RV_INTERNAL int rv_decode_out_loss_fwd_frames(const void* h3, long ldh, const vo
                                               long first_frame, long hop, float* recon, long ld_recon, void* dP4_bf16,
                                               long ld_dp4, void* dP4_fp8, long ld_dp4q, const float* dp4_scale,
                                               float* mse_partial, float* db4_partial, void* stream);
-// rv_adam_flat that also emits the rank's 16-bit parameter message for the bucket `descs` (rv_shard_encode's output from
-// the updated parameters, bit for bit; the caller zero-initialises `msg` once): the sharded step's update and encode in
-// one pass.
-RV_INTERNAL int rv_adam_flat_msg(const rv_param_desc* descs, int n_desc, float* param, float* exp_avg, float* exp_avg_sq,
-                                 const float* grad_shard, long lo, long n, long cnt, float lr, float grad_scale,
-                                 const long long* step_counter, void* msg, void* stream);
 // max|W1|, max|W4| of the fp8 weight shadows (n1 / n4 bytes) into the 2 x 1024 slots behind the fp8 state block
 // (RV_OPT_FP8): the plan runs it behind the optimizer, the next step's first kernel turns it into the weight scales.
 RV_INTERNAL int rv_fp8_wmax(const void* w1q, long n1, const void* w4q, long n4, float* fp8_state, void* stream);

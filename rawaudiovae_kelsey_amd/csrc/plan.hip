@@ -107,16 +107,8 @@ struct rv_plan {
   int world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
-  // sharded optimizer (rv_plan_attach_comm with reduce_scatter + all_gather)
-  rv_reduce_scatter_fn reduce_scatter = nullptr;
-  rv_all_gather_fn all_gather = nullptr;
   int rank = 0;
-  float* rs_buf = nullptr;
-  float* ag_buf = nullptr;
-  // 16-bit parameter message instead of the fp32 all-gather (rv_comm_desc.msg_send / msg_recv): send / receive buffers
-  unsigned short* msg_send = nullptr;
-  unsigned short* msg_recv = nullptr;
-  hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_gath[2] = {nullptr, nullptr};
+  hipEvent_t ev_flush = nullptr;   // rv_plan_step behind a deferred data-parallel update on another stream
   int fp8 = 0;                 // fc1 / fc4 forward on fp8 operands (RV_OPT_FP8)
   int n_amax_cap = 4096;       // entries of the workspace buffer "h3_amax" for h3's maxima
   int n_amax_dp1 = 0;          // ... and for dP1's behind them (fp8 weight gradient of fc1)
@@ -330,10 +322,7 @@ void rv_plan_destroy(rv_plan* p) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_done)
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->ev_upd)
-    if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->ev_gath)
-    if (e) (void)hipEventDestroy(e);
+  if (p->ev_flush) (void)hipEventDestroy(p->ev_flush);
   // p->comm_stream is the process-wide collective stream (helper_stream below): not destroyed here
   delete p;
 }
@@ -683,8 +672,16 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
                  unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step: plan not bound");
   if (p->tail_pending) {   // a data-parallel step left its last update to "the next call": this is it
+    void* ts = p->tail_stream;
     const int frc = rv_plan_ddp_flush(p, nullptr);   // (on the stream that step was enqueued on)
     if (frc) return frc;
+    if (ts != stream) {
+      // ... and this step's kernels read the parameters and shadows that update writes: an edge from that stream to this
+      // one (round-5 advisor: without it the forward could start while the deferred Adam was still running)
+      if (!p->ev_flush) RV_HIP(hipEventCreateWithFlags(&p->ev_flush, hipEventDisableTiming));
+      RV_HIP(hipEventRecord(p->ev_flush, (hipStream_t)ts));
+      RV_HIP(hipStreamWaitEvent((hipStream_t)stream, p->ev_flush, 0));
+    }
   }
   WtScope wt_scope;
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
@@ -940,39 +937,15 @@ int rv_plan_step_frames(rv_plan* p, int phases, const float* audio, const void* 
 }
 
 // ------------------------------------------------------------ data-parallel step
-static long shard_count(long lo, long hi, int world) { return ((hi - lo + world - 1) / world + 3) / 4 * 4; }
-
-long rv_plan_shard_count(const rv_plan* p, int bucket, int world, int msg_slots) {
-  if (!p || world < 1 || bucket < 0 || bucket > 1) return msg_slots ? -1 : 0;
-  const long cnt = bucket == 0 ? shard_count(p->off[8], p->n_params, world) : shard_count(0, p->off[8], world);
-  if (!msg_slots) return cnt;
-  if (!p->bound) return -1;
-  return bucket == 0 ? rv_shard_msg_slots(p->d_slab + 8, 2, cnt) : rv_shard_msg_slots(p->d_slab, 8, cnt);
-}
-
 int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
   RV_REQUIRE(p && c, RV_ERR_NULL, "rv_plan_attach_comm: null argument");
   if (!c->comm) {   // detach: the stream choice is the one field that may be set ahead of a communicator
-    p->allreduce = nullptr; p->reduce_scatter = nullptr; p->all_gather = nullptr; p->comm = nullptr;
+    p->allreduce = nullptr; p->comm = nullptr;
     p->comm_stream = (hipStream_t)c->comm_stream;
     return RV_OK;
   }
-  const bool sharded = c->reduce_scatter || c->all_gather;
   RV_REQUIRE(c->world >= 1 && c->rank >= 0 && c->rank < c->world, RV_ERR_SHAPE, "rv_plan_attach_comm: rank %d of %d", c->rank, c->world);
-  if (sharded) {
-    RV_REQUIRE(c->reduce_scatter && c->all_gather && !c->allreduce, RV_ERR_NULL,
-               "rv_plan_attach_comm: sharded mode takes reduce_scatter AND all_gather (and no allreduce)");
-    RV_REQUIRE(c->rs_buf && c->ag_buf, RV_ERR_NULL, "rv_plan_attach_comm: sharded mode needs rs_buf and ag_buf");
-    RV_REQUIRE((((uintptr_t)c->rs_buf | (uintptr_t)c->ag_buf) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm: buffers must be 16-byte aligned");
-    RV_REQUIRE((c->msg_send == nullptr) == (c->msg_recv == nullptr), RV_ERR_NULL, "rv_plan_attach_comm: both message buffers or neither");
-    RV_REQUIRE((((uintptr_t)c->msg_send | (uintptr_t)c->msg_recv) & 15) == 0, RV_ERR_SHAPE, "rv_plan_attach_comm: message buffers must be 16-byte aligned");
-    RV_REQUIRE(!(c->msg_send && p->fp8), RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the fp8 shadows are derived from fp32 parameters; "
-               "use the fp32 all-gather with the fp8 forward");
-    RV_REQUIRE(!c->grad_bf16, RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the bf16 gradient payload belongs to the all-reduce mode");
-  } else {
-    RV_REQUIRE(c->allreduce, RV_ERR_NULL, "rv_plan_attach_comm: no collective given");
-    RV_REQUIRE(!c->msg_send && !c->msg_recv, RV_ERR_UNSUPPORTED, "rv_plan_attach_comm: the parameter message belongs to the sharded mode");
-  }
+  RV_REQUIRE(c->allreduce, RV_ERR_NULL, "rv_plan_attach_comm: no collective given");
   p->comm_stream = (hipStream_t)c->comm_stream;   // NULL: the library's own
   if (!p->comm_stream) {
     const int src = helper_stream(true, &p->comm_stream);
@@ -983,16 +956,8 @@ int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
     for (hipEvent_t& e : p->ev_ready) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_done) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  if (sharded && !p->ev_upd[0]) {
-    for (hipEvent_t& e : p->ev_upd) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t& e : p->ev_gath) RV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  p->allreduce = sharded ? nullptr : c->allreduce;
-  p->reduce_scatter = sharded ? c->reduce_scatter : nullptr;
-  p->all_gather = sharded ? c->all_gather : nullptr;
+  p->allreduce = c->allreduce;
   p->comm = c->comm; p->world = c->world; p->rank = c->rank;
-  p->rs_buf = c->rs_buf; p->ag_buf = c->ag_buf;
-  p->msg_send = (unsigned short*)c->msg_send; p->msg_recv = (unsigned short*)c->msg_recv;
   p->grad_bf16 = c->grad_bf16; p->payload_bf16 = c->grad_bf16 ? 1 : 0;
   return RV_OK;
 }
@@ -1010,82 +975,6 @@ int rv_plan_attach_comm(rv_plan* p, const rv_comm_desc* c) {
 //     (measured); two of the four edges are on the critical path;
 //   * cutting fc1's gradient into halves buys nothing once each collective pays its own start-up latency, and an early
 //     small bucket (heads + fc3) only delays the last one (modelled: tools/ddp_model.py).
-// The sharded schedule below keeps round 3's shape: fc4's whole bucket behind the fork, the second bucket's collectives
-// on the compute stream behind a join.
-
-// this rank's shard of a bucket [lo, hi) cut into shards of cnt: [own, own + n) with n clipped to the bucket's end
-static void own_shard(long lo, long hi, long cnt, int rank, long* own, long* n) {
-  *own = lo + (long)rank * cnt;
-  *n = hi - *own;
-  if (*n > cnt) *n = cnt;
-  if (*n < 0) *n = 0;
-}
-
-// One sharded data-parallel step (see rv_comm_desc in the header): RS(fc4) on the collective stream
-// behind the rest of backward, RS(rest), Adam on the own shards, AG(fc4), AG(rest) on the caller's stream.
-static int step_ddp_sharded(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
-                            unsigned long long seed, void* stream) {
-  const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
-  void* xb = p->ws("xb"); void* dP1 = p->ws("dP1");
-  const float* eps_used = eps ? eps : (float*)p->ws("eps");
-  hipStream_t s0 = (hipStream_t)stream, sc = p->comm_stream;
-  const float scale = 1.0f / (float)p->world;
-  const long lo_b[2] = {p->off[8], 0}, hi_b[2] = {p->n_params, p->off[8]};
-  const int t0_b[2] = {8, 0}, nt_b[2] = {2, 8};
-  const long cnt[2] = {shard_count(lo_b[0], hi_b[0], p->world), shard_count(lo_b[1], hi_b[1], p->world)};
-  float* rs[2] = {p->rs_buf, p->rs_buf + cnt[0]};
-  float* ag[2] = {p->ag_buf, p->ag_buf + (long)p->world * cnt[0]};
-  int rc;
-#define RV_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
-  auto scatter_bucket = [&](int b, hipStream_t on) -> int {
-    const int nrc = p->reduce_scatter(p->b.grad + lo_b[b], rs[b], (size_t)cnt[b], /*ncclFloat32*/ 7, /*ncclSum*/ 0, p->comm, (void*)on);
-    if (nrc != 0) return rv_fail(RV_ERR_HIP, "reduce-scatter of gradient bucket %d failed (collective library code %d)", b, nrc);
-    return RV_OK;
-  };
-  RV_TRY(rv_plan_step(p, RV_PHASE_FWD, x, eps, recon_out, kl_beta, lr, 1.f, 0, seed, stream));
-  RV_TRY(fc4_backward(p, stream));
-  // What follows a bucket's reduce-scatter -- Adam on the own shard, the parameter exchange, the shadow rebuild -- on
-  // stream `on` (bucket 0: the collective stream, behind the rest of backward; nothing there reads fc4's parameters).
-  const bool use_msg = p->msg_send && !p->fp8;
-  const long slots[2] = {use_msg ? rv_shard_msg_slots(p->d_slab + t0_b[0], nt_b[0], cnt[0]) : 0,
-                         use_msg ? rv_shard_msg_slots(p->d_slab + t0_b[1], nt_b[1], cnt[1]) : 0};
-  unsigned short* snd[2] = {p->msg_send, p->msg_send + slots[0]};
-  unsigned short* rcv[2] = {p->msg_recv, p->msg_recv + (long)p->world * slots[0]};
-  auto update_bucket = [&](int b, hipStream_t on) -> int {
-    long own, n;
-    own_shard(lo_b[b], hi_b[b], cnt[b], p->rank, &own, &n);
-    if (use_msg) {
-      // 16-bit parameter message: bf16 of the shard + the bucket's biases in fp32 (half the all-gather bytes), written
-      // by the update itself
-      RV_REQUIRE(own == lo_b[b] + (long)p->rank * cnt[b], RV_ERR_STATE, "sharded step: shard origin");
-      RV_TRY(rv_adam_flat_msg(p->d_slab + t0_b[b], nt_b[b], p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, cnt[b], lr,
-                              scale, p->b.step_counter, snd[b], (void*)on));
-      const int nrc = p->all_gather(snd[b], rcv[b], (size_t)slots[b] * 2, /*ncclUint8*/ 1, p->comm, (void*)on);
-      if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter message %d failed (collective library code %d)", b, nrc);
-      return rv_shadows_from_msg(p->d_slab + t0_b[b], nt_b[b], rcv[b], lo_b[b], cnt[b], slots[b], p->b.param, (void*)on);
-    }
-    RV_TRY(rv_adam_flat(p->b.param, p->b.exp_avg, p->b.exp_avg_sq, rs[b], own, n, lr, scale, p->b.step_counter, (void*)on));
-    const int nrc = p->all_gather(p->b.param + lo_b[b] + (long)p->rank * cnt[b], ag[b], (size_t)cnt[b], /*ncclFloat32*/ 7, p->comm, (void*)on);
-    if (nrc != 0) return rv_fail(RV_ERR_HIP, "all-gather of parameter bucket %d failed (collective library code %d)", b, nrc);
-    return rv_params_from_flat(p->d_slab + t0_b[b], nt_b[b], ag[b], lo_b[b], p->b.param, (void*)on);
-  };
-  RV_HIP(hipEventRecord(p->ev_ready[0], s0));                 // the fork
-  RV_HIP(hipStreamWaitEvent(sc, p->ev_ready[0], 0));
-  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[0], nt_b[0], p->b.grad, 0, (void*)sc));
-  RV_TRY(scatter_bucket(0, sc));                              // fc4's slab sum, exchange and update travel behind the
-  RV_TRY(update_bucket(0, sc));                               // rest of backward
-  RV_HIP(hipEventRecord(p->ev_done[0], sc));
-  RV_TRY(latent_heads_bwd(p, eps_used, kl_beta, nullptr, nullptr, stream));
-  RV_TRY(rv_linear_wgrad(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, w1_tile(p), p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, stream));
-  RV_TRY(rv_grad_finalize(p->d_slab + t0_b[1], nt_b[1], p->b.grad, 0, stream));
-  RV_HIP(hipStreamWaitEvent(s0, p->ev_done[0], 0));           // the join: a communicator's collectives never fly on two streams
-  RV_TRY(scatter_bucket(1, s0));
-  RV_TRY(update_bucket(1, s0));
-  RV_TRY(fp8_after_update(p, stream));
-#undef RV_TRY
-  return RV_OK;
-}
-
 // The deferred half of an all-reduce step (RV_OPT_DDP_DEFER_TAIL): wait for the second exchange, update its bucket.
 // The step number comes from the copy edge 1's flag kernel latched (ddp_flags[16..17]): the device counter itself may
 // already have been bumped by the next step's cast launch.
@@ -1119,7 +1008,7 @@ int rv_plan_ddp_flush(rv_plan* p, void* stream) {
 int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_out, float kl_beta, float lr,
                      unsigned long long seed, void* stream) {
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
-  RV_REQUIRE((p->allreduce || p->reduce_scatter) && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
+  RV_REQUIRE(p->allreduce && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
   WtScope wt_scope;
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
@@ -1136,15 +1025,16 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
       RV_REQUIRE(cap0 == hipStreamCaptureStatusNone, RV_ERR_STATE,
                  "rv_plan_step_ddp: a deferred update is pending and the stream is capturing (rv_plan_ddp_flush before the capture)");
     }
-    if (!p->reduce_scatter && !p->fp8 && !(p->skip & 1)) {
+    if (!p->fp8 && !(p->skip & 1)) {
       const int crc = rv_cast_pad_bf16(x, p->B, p->S, p->S, p->ws("xb"), p->Bp, p->Sp, p->Sp, p->b.step_counter, stream);
       if (crc) return crc;
       p->cast_done = 1;
     }
+    // (a failure here leaves cast_done set: the cast HAS run and bumped the device step counter, so a retried call must not
+    // run it -- and count the step -- again; round-5 advisor)
     const int frc = ddp_finish_tail(p);
-    if (frc) { p->cast_done = 0; return frc; }
+    if (frc) return frc;
   }
-  if (p->reduce_scatter) return step_ddp_sharded(p, x, eps, recon_out, kl_beta, lr, seed, stream);
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
   void* xb = p->ws("xb"); void* dP1 = p->ws("dP1");
   const float* eps_used = eps ? eps : (float*)p->ws("eps");

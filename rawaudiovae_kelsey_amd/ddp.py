@@ -7,12 +7,13 @@ of the global-batch mean loss (the reference's loss is a mean, rawvae/model.py:3
 
 Two routes, same arithmetic:
   * `NativeDdpRunner` (the product path; train.py, bench.py): the LIBRARY issues the collectives --
-    `rv_plan_step_ddp` gets the communicator handle and the addresses of ncclAllReduce / ncclReduceScatter /
-    ncclAllGather, and runs the whole step from one host call on two streams (the caller's and a collective stream
-    chosen by `pick_comm_stream`): buckets fc4 | the rest, each exchanged as soon as its gradients exist, bf16 payload
-    by default (`DEFAULT_PAYLOAD`; "fp32" = the exact mean), device-side flags between the two streams, fc4's Adam
-    beside the second exchange.  `sharded=True` is the reduce-scatter / sharded-Adam / all-gather schedule.
-    DESIGN.md 5 has the schedule, its one-GPU model of 8 ranks and the one-rank RCCL rehearsal.
+    `rv_plan_step_ddp` gets the communicator handle and the address of ncclAllReduce, and runs the whole step from one
+    host call on two streams (the caller's and a collective stream chosen by `pick_comm_stream`): buckets fc4 | the rest,
+    each exchanged as soon as its gradients exist, fp32 payload by default (`DEFAULT_PAYLOAD`: the exact mean; "bf16" is
+    opt-in and the bench's named choice), device-side flags between the two streams, fc4's Adam beside the second
+    exchange.  DESIGN.md 5 has the schedule, its one-GPU model of 8 ranks and the one-rank RCCL rehearsal.  (The
+    sharded-optimizer schedule of rounds 3-5 -- reduce-scatter, Adam on a shard, all-gather -- won no row of that model
+    and was removed in round 6.)
   * `DdpRunner` + `GradSync`: the phases of `rv_plan_step` with `torch.distributed` all-reduces between them
     (works with any backend, gloo on CPU included): the route the CPU tests and the startup cross-check use.
 """
@@ -80,83 +81,7 @@ DEFAULT_PAYLOAD = "fp32"
 # what bench.py exchanges at N > 1 unless RV_DDP_PAYLOAD says otherwise: named in its JSON line, fp32 timed beside it
 BENCH_PAYLOAD = "bf16"
 
-ARENA_SLACK = 1024   # elements every flat arena extends past n_params (shards of 4-element multiples can overhang)
-
-
-class ShardPlan:
-    """Who owns what in the sharded optimizer (`rv_plan_step_ddp`, sharded mode; include/rawvae_hip.h).
-
-    The flat arena is exchanged in two buckets, in the order backward completes them: bucket 0 = fc4
-    ([offset of fc4.weight, n_params)), bucket 1 = everything before it.  A bucket is cut into `world` equal
-    shards of `count` elements, count = ceil(len / world) rounded up to a multiple of 4 (16-byte vector
-    accesses), so the last shards can be ragged or empty and the last one can overhang its bucket: collectives
-    move `count` elements per rank, the optimizer touches only [own_lo, own_hi)."""
-
-    def __init__(self, fc4_offset, n_params, world):
-        self.world = int(world)
-        self.buckets = [(int(fc4_offset), int(n_params)), (0, int(fc4_offset))]
-        self.counts = [self.shard_count(lo, hi, self.world) for lo, hi in self.buckets]
-        if self.world * 4 > ARENA_SLACK:
-            raise ValueError("world %d needs more arena slack than %d elements" % (world, ARENA_SLACK))
-
-    @staticmethod
-    def shard_count(lo, hi, world):
-        return ((hi - lo + world - 1) // world + 3) // 4 * 4
-
-    def own(self, bucket, rank):
-        """(lo, hi) of rank's shard of `bucket`, clipped to the bucket (hi == lo: empty)."""
-        lo, hi = self.buckets[bucket]
-        a = lo + rank * self.counts[bucket]
-        return min(a, hi), min(a + self.counts[bucket], hi)
-
-    @property
-    def rs_elems(self):
-        return sum(self.counts)
-
-    @property
-    def ag_elems(self):
-        return self.world * sum(self.counts)
-
-    def gather_offset(self, bucket):
-        """Start of `bucket`'s gathered parameters in the all-gather buffer."""
-        return 0 if bucket == 0 else self.world * self.counts[0]
-
-
-def gather_sharded_moments(engine, group=None):
-    """Sharded optimizer: exp_avg / exp_avg_sq are current on their owner rank only.  Before a checkpoint every
-    rank calls this; afterwards each rank's arenas hold the complete, current moments (an all-gather of the
-    shards over torch.distributed -- any backend; a few MB, checkpoint time only)."""
-    sp = getattr(engine, "shard_plan", None)
-    if sp is None or sp.world == 1 or not dist.is_initialized():
-        return
-    rank = dist.get_rank(group)
-    for arena in (engine._arena_full[1], engine._arena_full[2]):
-        for b in (0, 1):
-            lo, hi = sp.buckets[b]
-            cnt = sp.counts[b]
-            mine = arena[lo + rank * cnt: lo + (rank + 1) * cnt].clone()
-            parts = [torch.empty_like(mine) for _ in range(sp.world)]
-            dist.all_gather(parts, mine, group=group)
-            arena[lo:hi].copy_(torch.cat(parts)[:hi - lo])
-
-
-def gather_sharded_params(engine, group=None):
-    """Sharded optimizer with the 16-bit parameter message: fp32 WEIGHT masters are current on their owner rank only
-    (operand shadows and biases are current everywhere).  Before a checkpoint, an exact-fp32 evaluation or a
-    comparison of replicas every rank calls this; afterwards each rank's parameter arena is complete and current
-    (an all-gather of the shards over torch.distributed -- any backend; checkpoint time only)."""
-    sp = getattr(engine, "shard_plan", None)
-    if sp is None or sp.world == 1 or not dist.is_initialized() or getattr(engine, "shard_gather", "fp32") != "bf16":
-        return
-    rank = dist.get_rank(group)
-    arena = engine._arena_full[0]
-    for b in (0, 1):
-        lo, hi = sp.buckets[b]
-        cnt = sp.counts[b]
-        mine = arena[lo + rank * cnt: lo + (rank + 1) * cnt].clone()
-        parts = [torch.empty_like(mine) for _ in range(sp.world)]
-        dist.all_gather(parts, mine, group=group)
-        arena[lo:hi].copy_(torch.cat(parts)[:hi - lo])
+ARENA_SLACK = 1024   # elements every flat arena extends past n_params (16-byte accesses of the last tensor's tail)
 
 
 def engine_buckets(engine):
@@ -309,10 +234,6 @@ class RcclComm:
             cnt = C.c_int(self.world)
         self.rccl_count = int(cnt.value)
         self.allreduce_addr = C.cast(self._lib.ncclAllReduce, C.c_void_p)
-        self.reduce_scatter_addr = C.cast(self._lib.ncclReduceScatter, C.c_void_p)
-        self.all_gather_addr = C.cast(self._lib.ncclAllGather, C.c_void_p)
-        self._lib.ncclReduceScatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        self._lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         self._lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
     def _check(self, rc, what):
@@ -333,18 +254,6 @@ class RcclComm:
         want = self.world * (self.world + 1) / 2.0
         if not bool((t == want).all()):
             raise RuntimeError("RCCL self-test: expected %g everywhere, got [%g, %g]" % (want, t.min().item(), t.max().item()))
-        # the sharded optimizer's two collectives: reduce-scatter (rank r receives the sum of slice r) and all-gather
-        n = 1 << 12
-        src = torch.arange(self.world * n, dtype=torch.float32, device=device) + float(self.rank)
-        out = torch.empty(n, dtype=torch.float32, device=device)
-        s = torch.cuda.current_stream().cuda_stream or None
-        self._check(self._lib.ncclReduceScatter(src.data_ptr(), out.data_ptr(), n, 7, 0, self.handle, s), "ncclReduceScatter")
-        gat = torch.empty(self.world * n, dtype=torch.float32, device=device)
-        self._check(self._lib.ncclAllGather(out.data_ptr(), gat.data_ptr(), n, 7, self.handle, s), "ncclAllGather")
-        torch.cuda.synchronize(device)
-        base = torch.arange(self.world * n, dtype=torch.float32, device=device) * self.world + want - self.world
-        if not bool((gat == base).all()):
-            raise RuntimeError("RCCL self-test: reduce-scatter + all-gather returned wrong sums")
 
     def destroy(self):
         if getattr(self, "handle", None):
@@ -439,27 +348,24 @@ class NativeDdpRunner:
     """The data-parallel step as ONE host call per batch (`rv_plan_step_ddp`, collectives included);
     with `use_graph` each distinct batch buffer's step is captured once into a hipGraph and replayed."""
 
-    def __init__(self, engine, comm, stream, use_graph=False, payload=None, sharded=False, gather=None, defer=False):
-        """payload (all-reduce schedule): "fp32" (default, `DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in).
+    def __init__(self, engine, comm, stream, use_graph=False, payload=None, defer=False):
+        """payload: "fp32" (default, `DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in).
         defer: every step leaves its last wait and update to the next one, whose cast launch goes out first
         (`TrainEngine.set_ddp_defer`); the loop calls `flush()` before it reads anything back."""
         self.engine, self.comm, self.stream, self.use_graph = engine, comm, stream, use_graph
-        self.sharded = bool(sharded)
-        self.defer = bool(defer) and not self.sharded and not use_graph
+        self.defer = bool(defer) and not use_graph
         if stream is not None:
             # before any collective of the step and before any capture: the choice times a few launches and is
             # agreed between the ranks (pick_comm_stream)
             engine._pick_comm_stream(stream)
-        engine.attach_comm(comm, sharded=self.sharded, gather=gather, payload=payload)
+        engine.attach_comm(comm, payload=payload)
         if self.defer:
             engine.set_ddp_defer(True)
         self._graphs = {}
-        self.payload = "fp32" if self.sharded else engine.ddp_payload
+        self.payload = engine.ddp_payload
 
     def set_payload(self, payload):
         """"fp32" or "bf16" gradient exchange (captured graphs are dropped: the payload is baked in)."""
-        if self.sharded:
-            raise RuntimeError("the sharded optimizer exchanges fp32 gradients and parameters only")
         self.engine.set_ddp_payload(payload)
         self.payload = payload
         self._graphs = {}

@@ -72,8 +72,7 @@ class TrainEngine:
             self.step_counter, self.loss_ring, self.ring = share.step_counter, share.loss_ring, share.ring
             self._shared = share._shared
         else:
-            # every arena extends ARENA_SLACK elements past n_params: the sharded data-parallel optimizer cuts
-            # buckets into equal shards of 4-element multiples, so a collective's last shard can overhang
+            # every arena extends ARENA_SLACK elements past n_params (16-byte accesses of the last tensor's tail)
             from .ddp import ARENA_SLACK
             self._arena_full = [torch.zeros(o + ARENA_SLACK, **f32) for _ in range(4 if grad_arena else 3)]
             self.param, self.exp_avg, self.exp_avg_sq = (t[:o] for t in self._arena_full[:3])
@@ -208,25 +207,10 @@ class TrainEngine:
         return self.buffer("fp8_state", torch.float32, (-1,))[:16].tolist()
 
     def refresh_shadows(self, stream=None):
-        """Rebuild this engine's bf16/padded weight shadows from the fp32 arena.  If an engine sharing the arena
-        runs the sharded optimizer with the 16-bit parameter message, the fp32 weight masters are current on their
-        owner rank only: they are gathered first (a collective -- every rank reaches this point together, because
-        the engines of all ranks step in the same order), or this engine would compute with stale weights for
-        (world - 1) / world of the arena."""
+        """Rebuild this engine's bf16/padded weight shadows from the fp32 arena."""
         self.ddp_flush()              # a deferred data-parallel update writes parameters and shadows: before anything else
         self._await_init(stream)      # first: the parameters may have been written on another stream, and everything
-                                      # below (the masters' gather, the fp8 maxima, the shadow rebuild) reads them on `stream`
-        owner = self._shared.get("bf16_gather_engine")
-        if owner is not None:
-            # the gather is torch.distributed collectives plus arena copies: they must run ON `stream`, behind the
-            # previous step's update / all-gather there (with torch's current stream elsewhere nothing would order
-            # them), and never inside a hipGraph capture (a host collective cannot be captured)
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.RvError("refresh_shadows: the fp32 masters must be gathered from their owner ranks first, which "
-                                   "cannot happen during a hipGraph capture; step this engine once before capturing")
-            from . import ddp
-            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
-                ddp.gather_sharded_params(owner)
+                                      # below (the fp8 maxima, the shadow rebuild) reads them on `stream`
         if self.fp8:
             with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
                 st = self.buffer("fp8_state", torch.float32, (-1,))[:16]
@@ -317,60 +301,27 @@ class TrainEngine:
             self._shadow_version = self._shared["version"]
             _ops_invalidate()
 
-    def attach_comm(self, comm, sharded=False, gather=None, payload=None):
+    def attach_comm(self, comm, payload=None):
         """Data-parallel mode with the collectives issued by the library itself: `comm` is a `ddp.RcclComm`
-        (RCCL communicator + the addresses of its collectives).  sharded: optimizer state and update sharded
-        over the ranks (reduce-scatter gradients, Adam on the own shard, all-gather parameters) instead of an
-        all-reduce followed by the full update on every rank.  gather (sharded only): "bf16" (default without
-        the fp8 forward) all-gathers a 16-bit message -- bf16 of the updated weights plus the biases in fp32,
-        half the bytes; every rank's operand shadows and biases are bit-identical to the "fp32" route, but fp32
-        weight masters are then current on their owner rank only (`ddp.gather_sharded_params` before a
-        checkpoint); "fp32" all-gathers the fp32 parameters.  payload (all-reduce schedule only): "fp32" (the
-        default, `ddp.DEFAULT_PAYLOAD`: the exact mean) or "bf16" (opt-in: half the bytes on the links) -- `set_ddp_payload`."""
-        if sharded:
-            from .ddp import ShardPlan
-            self.shard_plan = ShardPlan(self.offsets["fc4.weight"], self.n_params, comm.world)
-            for b in (0, 1):
-                if lib().rv_plan_shard_count(self._plan, b, comm.world, 0) != self.shard_plan.counts[b]:
-                    raise _lib.RvError("shard bookkeeping of ddp.ShardPlan and the library disagree")
-            f32 = dict(dtype=torch.float32, device=self.device)
-            self._rs_buf = torch.zeros(self.shard_plan.rs_elems, **f32)
-            self._ag_buf = torch.zeros(self.shard_plan.ag_elems, **f32)
-            d = self._comm_desc = _lib.CommDesc(comm=comm.handle, world=comm.world, rank=comm.rank,
-                                                reduce_scatter=comm.reduce_scatter_addr, all_gather=comm.all_gather_addr,
-                                                rs_buf=ptr(self._rs_buf), ag_buf=ptr(self._ag_buf),
-                                                comm_stream=self._comm_stream_ptr())
-            gather = gather or ("fp32" if self.fp8 else "bf16")
-            if gather not in ("bf16", "fp32") or (gather == "bf16" and self.fp8):
-                raise _lib.RvError("attach_comm: gather=%r (expected 'bf16' or 'fp32'; 'bf16' not with the fp8 forward)" % (gather,))
-            self.shard_gather = gather
-            if gather == "bf16":
-                slots = [lib().rv_plan_shard_count(self._plan, b, comm.world, 1) for b in (0, 1)]
-                if min(slots) <= 0:
-                    raise _lib.RvError("rv_plan_shard_count(msg_slots) failed")
-                i16 = dict(dtype=torch.int16, device=self.device)
-                self._msg_send = torch.zeros(sum(slots), **i16)
-                self._msg_recv = torch.zeros(comm.world * sum(slots), **i16)
-                self.msg_slots = slots
-                d.msg_send, d.msg_recv = ptr(self._msg_send), ptr(self._msg_recv)
-                self._shared["bf16_gather_engine"] = self   # refresh_shadows of every engine on this arena gathers first
-        else:
-            d = self._comm_desc = _lib.CommDesc(comm=comm.handle, world=comm.world, rank=getattr(comm, "rank", 0),
-                                                allreduce=comm.allreduce_addr, comm_stream=self._comm_stream_ptr())
+        (RCCL communicator + the address of its all-reduce).  payload: "fp32" (the default, `ddp.DEFAULT_PAYLOAD`: the
+        exact mean) or "bf16" (opt-in: half the bytes on the links; error model in DESIGN.md section 5) --
+        `set_ddp_payload`."""
+        d = self._comm_desc = _lib.CommDesc(comm=comm.handle, world=comm.world, rank=getattr(comm, "rank", 0),
+                                            allreduce=comm.allreduce_addr, comm_stream=self._comm_stream_ptr())
         lib().rv_plan_attach_comm(self._plan, C.byref(d))
         self._comm = comm   # keep the communicator alive as long as the plan can use it
-        # cross-stream edges of the all-reduce schedule: device-side flags (default) or HIP events (RV_DDP_SIGNAL=event)
-        lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 0 if os.environ.get("RV_DDP_SIGNAL") == "event" else 1)
+        # cross-stream edges of the all-reduce schedule: device-side flags (HIP events under stream capture; the A/B:
+        # DESIGN.md section 5)
+        lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_SIGNAL, 1)
         # how long a flag wait behind a collective -- i.e. behind the slowest peer -- may last (default: thirty seconds)
         if os.environ.get("RV_DDP_WAIT_MS"):
             lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_WAIT_MS, int(os.environ["RV_DDP_WAIT_MS"]))
-        # RV_DDP_W1_WIDE=1 / set_ddp_w1_wide(True): fc1's weight gradient on all CUs in the all-reduce schedule (twice the
-        # local step's K splits) -- faster only beside a collective whose workgroups leave room on their CUs
-        self.set_ddp_w1_wide(os.environ.get("RV_DDP_W1_WIDE", "0") == "1")
+        # set_ddp_w1_wide(True): fc1's weight gradient on all CUs in the all-reduce schedule (twice the local step's K
+        # splits) -- faster only beside a collective whose workgroups leave room on their CUs; off by default
+        self.set_ddp_w1_wide(False)
         self.ddp_payload = "fp32"
-        if not sharded:
-            from .ddp import DEFAULT_PAYLOAD
-            self.set_ddp_payload(payload or DEFAULT_PAYLOAD)
+        from .ddp import DEFAULT_PAYLOAD
+        self.set_ddp_payload(payload or DEFAULT_PAYLOAD)
 
     def set_ddp_w1_wide(self, enable):
         lib().rv_plan_set_option(self._plan, _lib.OPT_DDP_W1_WIDE, int(bool(enable)))
@@ -449,9 +400,9 @@ class TrainEngine:
     def _pick_comm_stream(self, stream):
         """The collectives' stream is chosen per compute stream by measurement (ddp.pick_comm_stream: two streams
         that wait on each other must not share one of the runtime's hardware queues); once per compute stream,
-        never during a capture.  RV_COMM_STREAM=library keeps the library's own stream."""
+        never during a capture."""
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        if st.cuda_stream == getattr(self, "_comm_pick_for", None) or os.environ.get("RV_COMM_STREAM", "pick") != "pick":
+        if st.cuda_stream == getattr(self, "_comm_pick_for", None):
             return
         if torch.cuda.is_current_stream_capturing():
             return
@@ -518,7 +469,7 @@ class TrainEngine:
         if n:
             raise _lib.RvError("data-parallel step: %d cross-stream flag wait(s) timed out -- no optimizer update has been "
                                "applied since the first one (the parameters are those of the last complete step); a peer rank "
-                               "is more than RV_DDP_WAIT_MS behind or gone (RV_DDP_SIGNAL=event selects HIP events)" % n)
+                               "is more than RV_DDP_WAIT_MS behind or gone" % n)
 
     def ddp_timeouts(self):
         """Count of flag waits that ran out (0 = healthy; synchronises).  Does not raise: for callers that must first

@@ -222,15 +222,26 @@ class FusedLoss(torch.Tensor):
     ten gradients into `.grad` itself.  Same kernels, same gradients; what it skips is the autograd engine's hand-over to
     its device worker thread and back for a graph of one node (~80 us of the loop's ~140 us backward at C2,
     profiles/r05_api_breakdown.txt).  Anything the shortcut does not cover -- a `gradient` / `inputs` argument,
-    `create_graph`, hooks on a parameter or on the loss, gradients disabled -- goes to `Tensor.backward` unchanged."""
+    `create_graph`, hooks on a parameter or on the loss, gradients disabled -- goes to `Tensor.backward` unchanged.
+    LIMIT (round-5 advisor): hooks registered on the parameters' AccumulateGrad NODES (what torch's DistributedDataParallel
+    reducer, Horovod and FSDP-style wrappers use) and global autograd hooks cannot be seen from here and never fire on the
+    shortcut.  So it is taken only while no torch.distributed process group exists -- a gradient-synchronising wrapper
+    needs one -- unless the module says `fused_backward_shortcut = True` explicitly; `= False` always takes the engine's
+    route.  Like autograd, a second `.backward()` on the same loss raises unless the first passed `retain_graph=True`."""
     __torch_function__ = torch._C._disabled_torch_function_impl      # ops on it return plain tensors
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         rec = getattr(self, "_rv_rec", None)
         if (rec is None or gradient is not None or inputs is not None or create_graph or not torch.is_grad_enabled()
-                or self._backward_hooks or not _plain_leaves(rec.params)):
+                or self._backward_hooks or not _plain_leaves(rec.params) or not _shortcut_allowed(rec)):
             return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
+        if getattr(rec, "shortcut_consumed", False):
+            raise RuntimeError("Trying to backward through the graph a second time: the fused step's activations were "
+                               "consumed by the first .backward(); pass retain_graph=True to the first call if a second "
+                               "one is needed.")
         pieces = FusedLossFn.run_backward(rec, self._rv_kl, _one(rec.eng.device))
+        if not retain_graph:
+            rec.shortcut_consumed = True
         with torch.no_grad():
             for q, g in zip(rec.params, pieces):
                 if q.grad is None:
@@ -247,6 +258,17 @@ def _one(dev):
     if t is None:
         t = _ONES[dev] = torch.ones((), dtype=torch.float32, device=dev)
     return t
+
+
+def _shortcut_allowed(rec):
+    """`module.fused_backward_shortcut`: True / False decide; unset (None): only while no torch.distributed process group
+    exists (see FusedLoss)."""
+    module = rec.module()
+    flag = getattr(module, "fused_backward_shortcut", None) if module is not None else False
+    if flag is not None:
+        return bool(flag)
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized())
 
 
 def _plain_leaves(params):

@@ -2,16 +2,15 @@
 
 `rv_plan_step_ddp` -- the library-driven data-parallel step -- runs here with world > 1 and rank > 0, which RCCL cannot
 do on a one-GPU box (it refuses two ranks on one device).  The collectives are the functional stand-ins of
-tools/fake_collective.hip (`shm_*`: same C signatures as ncclAllReduce / ncclReduceScatter / ncclAllGather, a real
-exchange through shared memory and the host), so everything around them is the product path: bucket boundaries, the
-1/world mean, the bf16 payload, shard ownership of rank > 0, the 16-bit parameter message, fork / join ordering.
+tools/fake_collective.hip (`shm_allreduce`: ncclAllReduce's C signature, a real exchange through shared memory and the
+host), so everything around it is the product path: bucket boundaries, the 1/world mean, the bf16 payload, fork / join
+ordering.
 
 Checked per mode, after 3 steps from the same weights on per-rank batches:
   * every rank ends with identical parameters and operand shadows;
   * they equal the torch.distributed path's (ddp.DdpRunner over gloo: six host calls and three all-reduces per step --
     the route that HAS run on several ranks before), bit for bit where the arithmetic is the same (fp32 payload at
-    world 2: a + b is one rounding in any order; sharded Adam = full Adam by construction), within a fraction of lr
-    for the bf16 payload.
+    world 2: a + b is one rounding in any order), within a fraction of lr for the bf16 payload.
 Prints DDP_SHM_OK on rank 0.
 """
 import ctypes as C
@@ -84,11 +83,10 @@ def main():
         # (RV_OPT_DDP_DEFER_TAIL, what bench.py runs at N > 1); the loop flushes before it reads back
         modes = (("allreduce", "fp32", None, False, False), ("allreduce", "fp32", None, True, False),
                  ("allreduce", "bf16", None, True, False), ("allreduce", "fp32", None, False, True),
-                 ("allreduce", "bf16", None, False, True), ("sharded", None, "fp32", True, False),
-                 ("sharded", None, "bf16", True, False))
+                 ("allreduce", "bf16", None, False, True))
         for mode, payload, gather, wide, defer in modes:
             ea = fresh()
-            ra = ddp.NativeDdpRunner(ea, comm, st, sharded=mode == "sharded", payload=payload, gather=gather, defer=defer)
+            ra = ddp.NativeDdpRunner(ea, comm, st, payload=payload, defer=defer)
             assert ra.defer == defer
             ea.set_ddp_w1_wide(wide)
             with torch.cuda.stream(st):
@@ -96,8 +94,6 @@ def main():
                     ra.step(x)
                 ra.flush()
             torch.cuda.synchronize()
-            if mode == "sharded" and gather == "bf16":
-                ddp.gather_sharded_params(ea)   # fp32 weight masters live on their owner ranks
             tag = "%r %s payload=%s gather=%s wide=%s defer=%s" % ((S, H, L, B), mode, payload, gather, wide, defer)
             shadows = [ea.buffer(n, torch.bfloat16, (-1,)) for n in ("W1b", "Whb", "W3b", "W4b")]
             if not agree(same_on_all_ranks(ea.param, *shadows)):
@@ -111,7 +107,7 @@ def main():
                 ok = float(d.max()) <= 0.01 * LR
             else:
                 ok = bool(torch.equal(ea.param, eb.param))
-                if ok and not (mode == "sharded"):   # sharded: moments are valid on their owner rank only
+                if ok:
                     ok = bool(torch.equal(ea.exp_avg, eb.exp_avg)) and bool(torch.equal(ea.exp_avg_sq, eb.exp_avg_sq))
             for a, b in zip(ea.losses(3), eb.losses(3)):
                 ok = ok and abs(a - b) <= 1e-4 * abs(b)

@@ -85,111 +85,6 @@ def test_gradsync_rejects_bad_buckets_and_is_noop_single_rank():
     assert s.grad_scale == 1.0 and torch.equal(flat, torch.arange(10, dtype=torch.float32))
 
 
-def _sharded_worker(rank, world, port, q, shape):
-    """Sharded optimizer bookkeeping over gloo: reduce-scatter (emulated: gloo has none, so all-reduce and take the
-    rank's slice -- the slice arithmetic is what is under test), Adam on the own shard, all-gather of `count`
-    elements per rank, unpack -- against oracle.adam_step on the global-batch gradient."""
-    sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-    from oracle import vae_oracle as O
-    from oracle.inputs import PARAM_NAMES, make_eps, make_frames, make_params
-    from rawaudiovae_kelsey_amd.ddp import ARENA_SLACK, ShardPlan
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        S, H, L, B = shape
-        p = O.cast_params(make_params(S, H, L, 0), np.float64)
-        sizes = [p[k].size for k in PARAM_NAMES]
-        n, off8 = sum(sizes), sum(sizes[:8])
-        plan = ShardPlan(off8, n, world)
-        flat_p = np.zeros(n + ARENA_SLACK)
-        flat_p[:n] = np.concatenate([p[k].reshape(-1) for k in PARAM_NAMES])
-        m, v = np.zeros_like(flat_p), np.zeros_like(flat_p)
-        ref_p = {k: p[k].copy() for k in PARAM_NAMES}
-        ref_st = O.adam_init(ref_p)
-        lr = 1e-3
-        for step in range(1, 3):
-            x = make_frames(B * world, S, 3 + step).astype(np.float64)
-            eps = make_eps(B * world, L, 4 + step).astype(np.float64)
-            cur = {}
-            o = 0
-            for k, sz in zip(PARAM_NAMES, sizes):
-                cur[k] = flat_p[o:o + sz].reshape(p[k].shape)
-                o += sz
-            sl = slice(rank * B, (rank + 1) * B)
-            g = O.backward(cur, O.forward(cur, x[sl], eps[sl]), 1e-4)
-            grad = np.zeros(n + ARENA_SLACK)
-            grad[:n] = np.concatenate([g[k].reshape(-1) for k in PARAM_NAMES])
-            gathered = np.zeros(plan.ag_elems)
-            for b in (0, 1):
-                lo, hi = plan.buckets[b]
-                cnt = plan.counts[b]
-                send = torch.from_numpy(grad[lo:lo + world * cnt].copy())   # may overhang the bucket: slack / next bucket
-                dist.all_reduce(send)
-                shard = send.numpy()[rank * cnt:(rank + 1) * cnt] / world   # what reduce-scatter hands this rank
-                a, e = plan.own(b, rank)
-                gs = shard[:e - a]
-                m[a:e] = 0.9 * m[a:e] + 0.1 * gs
-                v[a:e] = 0.999 * v[a:e] + 0.001 * gs * gs
-                bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
-                flat_p[a:e] -= (lr / bc1) * (m[a:e] / (np.sqrt(v[a:e]) / np.sqrt(bc2) + 1e-8))
-                own_lo = lo + rank * cnt
-                mine = torch.from_numpy(flat_p[own_lo:own_lo + cnt].copy())     # `count` elements, overhang included
-                outs = [torch.zeros(cnt, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(outs, mine)
-                go = plan.gather_offset(b)
-                gathered[go:go + world * cnt] = torch.cat(outs).numpy()
-                flat_p[lo:hi] = gathered[go:go + (hi - lo)]                     # rv_params_from_flat
-            # reference: one Adam step on the global-batch gradient
-            gf = O.backward(ref_p, O.forward(ref_p, x, eps), 1e-4)
-            O.adam_step(ref_p, gf, ref_st, lr)
-        ref_flat = np.concatenate([ref_p[k].reshape(-1) for k in PARAM_NAMES])
-        err = float(np.abs(flat_p[:n] - ref_flat).max())
-        q.put((rank, err, plan.counts, [plan.own(b, rank) for b in (0, 1)]))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,shape", [(2, (32, 48, 4, 8)), (3, (30, 41, 5, 6))])
-def test_sharded_optimizer_bookkeeping_equals_global_adam(world, shape):
-    """ddp.ShardPlan (ragged shard sizes, overhanging last shard) drives reduce-scatter / Adam-on-shard / all-gather /
-    unpack to the same parameters as torch.optim.Adam's arithmetic (oracle.adam_step) on the global-batch gradient."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, shape)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    for rank, err, counts, own in res:
-        assert err < 1e-12, (rank, err)
-        assert all(c % 4 == 0 for c in counts)
-
-
-def test_shard_plan_matches_library():
-    """The C side's shard arithmetic (rv_plan_shard_count; host-only code) equals ddp.ShardPlan's."""
-    import ctypes as C
-    from rawaudiovae_kelsey_amd import _lib
-    from rawaudiovae_kelsey_amd.ddp import ShardPlan
-    L = _lib.lib()
-    for (S, H, Ld, B) in ((1024, 2048, 64, 4096), (100, 200, 5, 37), (512, 2048, 8, 32)):
-        plan = C.c_void_p()
-        L.rv_plan_create(C.byref(plan), B, S, H, Ld)
-        sizes = [H * S, H, Ld * H, Ld, Ld * H, Ld, H * Ld, H, S * H, S]
-        for world in (1, 2, 3, 8):
-            sp = ShardPlan(sum(sizes[:8]), sum(sizes), world)
-            assert [L.rv_plan_shard_count(plan, b, world, 0) for b in (0, 1)] == sp.counts
-            for b in (0, 1):   # the shards tile the bucket exactly
-                lo, hi = sp.buckets[b]
-                spans = [sp.own(b, r) for r in range(world)]
-                assert spans[0][0] == lo and spans[-1][1] == hi
-                assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
-        L.rv_plan_destroy(plan)
-
-
 def _check_worker(rank, world, port):
     """One rank of train.py's health check: rank 1 reports a flag wait that ran out, rank 0 is healthy."""
     sys.path.insert(0, REPO)

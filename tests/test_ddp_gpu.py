@@ -63,8 +63,8 @@ def test_two_rank_bench_flow_with_the_library_driven_step_through_standins():
 def test_native_ddp_step_two_processes_one_gpu(world):
     """`rv_plan_step_ddp` with world = 2 and 4 (every rank a process of its own on this one GPU): RCCL refuses two ranks on a
     device, so the collectives are the functional stand-ins of tools/fake_collective.hip (`shm_*`, RCCL's signatures, a
-    real exchange through shared memory) -- everything else is the product path.  All four exchange modes (all-reduce
-    with fp32 / bf16 payload, sharded optimizer with fp32 all-gather / 16-bit parameter message), small shape and C2:
+    real exchange through shared memory) -- everything else is the product path.  Both payloads of the all-reduce schedule
+    (fp32 / bf16), both forms of fc1's weight gradient, with and without the deferred tail, small shape and C2:
     replicas identical, and equal to the torch.distributed route (tests/ddp_shm_worker.py) -- bit for bit with two
     ranks, to fp32 summation order with four (the two routes add the ranks' gradients in different orders); with and
     without the deferred tail; and the native step against the ORACLE on the concatenated batch of all ranks."""
@@ -191,34 +191,6 @@ assert not torch.equal(bf.param, ref.param)
 for a, b in zip(bf.losses(4), ref.losses(4)):
     assert abs(a - b) <= 1e-4 * abs(b)
 bf.set_ddp_payload("fp32")
-# sharded optimizer (reduce-scatter / Adam on the own shard / all-gather / rebuild parameters and shadows) with the
-# one-rank communicator: the shard is the whole bucket and both collectives are copies, so eager and graph-replayed
-# it must equal the local fused step bit for bit -- parameters, both moments, and the loss ring
-ref = fresh()
-with torch.cuda.stream(st):
-    for _ in range(5):
-        ref.step(x, stream=st)
-st.synchronize()
-for gather in ("bf16", "fp32"):      # the 16-bit parameter message (default) and the fp32 all-gather
-    sh = fresh(); sh.attach_comm(comm, sharded=True, gather=None if gather == "bf16" else gather)
-    assert sh.shard_gather == gather
-    with torch.cuda.stream(st):
-        for _ in range(5):
-            sh.step_ddp(x, stream=st)
-    st.synchronize()
-    assert torch.equal(sh.param, ref.param) and torch.equal(sh.exp_avg, ref.exp_avg) and torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
-    assert sh.losses(5) == ref.losses(5)
-    for name in ("W1b", "Whb", "W3b", "W4b", "b1p", "bhp", "b3p", "b4p"):
-        dt = torch.bfloat16 if name.startswith("W") else torch.float32
-        a, b = sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))
-        assert torch.equal(a, b), (gather, name)
-shg = fresh()
-run = ddp.NativeDdpRunner(shg, comm, st, use_graph=True, sharded=True)
-with torch.cuda.stream(st):
-    for _ in range(5):
-        run.step(x)
-st.synchronize()
-assert torch.equal(shg.param, ref.param), "graph-replayed sharded step differs"
 # deferred tail (RV_OPT_DDP_DEFER_TAIL): each step leaves its last wait + update to the next call, whose cast launch goes
 # out first; different batches per step (the early cast must not disturb the previous step's weight gradient), both
 # payloads; flushed by the runner, by the health check, by a local step and by the state-dict readers -- always the
@@ -266,152 +238,6 @@ print("NATIVE_OK")
 ''' % (REPO, _free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0 and "NATIVE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
-
-
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_sharded_16bit_message_rebuilds_shadows_and_biases(world):
-    """The sharded optimizer's 16-bit parameter message (rv_shard_encode -> all-gather -> rv_shadows_from_msg), all
-    ranks emulated one after the other on this GPU: every bf16 weight shadow and every fp32 bias shadow / bias
-    parameter rebuilt from the gathered messages alone must equal the fp32 route's, bit for bit (C2-shaped and an
-    odd-sized model whose shards cut through tensors and 4-element groups)."""
-    from oracle.inputs import make_params
-    from rawaudiovae_kelsey_amd import _lib as P
-    from rawaudiovae_kelsey_amd import engine as E
-    from rawaudiovae_kelsey_amd._lib import lib, ptr, stream_ptr
-    from rawaudiovae_kelsey_amd.ddp import ShardPlan
-    L_ = lib()
-    names = (("W1b", torch.bfloat16), ("Whb", torch.bfloat16), ("W3b", torch.bfloat16), ("W4b", torch.bfloat16),
-             ("b1p", torch.float32), ("bhp", torch.float32), ("b3p", torch.float32), ("b4p", torch.float32))
-    for (S, H, Ld, B) in ((256, 512, 16, 128), (100, 200, 5, 37)):
-        ref = E.TrainEngine(S, H, Ld, B, seed=3); ref.load_params(make_params(S, H, Ld, 1))   # its shadows = truth
-        sh = E.TrainEngine(S, H, Ld, B, seed=3); sh.load_params(make_params(S, H, Ld, 1))
-        sp = ShardPlan(sh.offsets["fc4.weight"], sh.n_params, world)
-        descs = sh.plan_descs()
-        truth = sh.param.clone()
-        for name, dt in names:
-            sh.buffer(name, dt, (-1,)).zero_()           # everything must come back from the messages
-        sh.param.zero_()
-        for b, (t0, nt) in ((0, (8, 2)), (1, (0, 8))):
-            arr = (P.ParamDesc * nt)(*descs[t0:t0 + nt])
-            lo, hi = sp.buckets[b]
-            cnt = sp.counts[b]
-            slots = L_.rv_shard_msg_slots(arr, nt, cnt)
-            assert slots == L_.rv_plan_shard_count(sh._plan, b, world, 1) and slots % 8 == 0 and slots >= cnt
-            gathered = torch.zeros(world * slots, dtype=torch.int16, device="cuda")
-            for r in range(world):
-                a, e = sp.own(b, r)
-                # a rank only knows its own shard's fp32 values: poison the rest while it encodes
-                local = torch.full((sh._arena_full[0].numel(),), float("nan"), device="cuda")
-                local[a:e] = truth[a:e]
-                L_.rv_shard_encode(arr, nt, ptr(local), lo + r * cnt, e - a, cnt, gathered[r * slots:].data_ptr(), stream_ptr())
-                torch.cuda.synchronize()
-            L_.rv_shadows_from_msg(arr, nt, ptr(gathered), lo, cnt, slots, ptr(sh.param), stream_ptr())
-        torch.cuda.synchronize()
-        for name, dt in names:
-            assert torch.equal(sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))), (name, world, (S, H, Ld, B))
-        for k in E.PARAM_NAMES:        # biases come back exactly; weight masters are not part of the message
-            got, want = sh.view(sh.param, k), ref.view(ref.param, k)
-            if k.endswith("bias"):
-                assert torch.equal(got, want), k
-            else:
-                assert float(got.abs().max()) == 0.0, k
-
-
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_sharded_adam_kernels_equal_full_adam(world):
-    """rv_adam_flat on every rank's shard (ragged, overhanging: ddp.ShardPlan) + rv_params_from_flat, all ranks
-    emulated one after the other on this GPU, against rv_adam_multi over the whole arena: bit-equal parameters,
-    moments, bf16 shadows and padded bias shadows (C2-shaped and an odd-sized model)."""
-    import numpy as np
-    from oracle.inputs import make_frames, make_params
-    from rawaudiovae_kelsey_amd import engine as E
-    from rawaudiovae_kelsey_amd._lib import lib, ptr, stream_ptr
-    from rawaudiovae_kelsey_amd.ddp import ARENA_SLACK, ShardPlan
-    L_ = lib()
-    for (S, H, Ld, B) in ((256, 512, 16, 128), (100, 200, 5, 37)):
-        x = torch.from_numpy(make_frames(B, S, 1)).cuda()
-        ph = E.PHASE_FWD | E.PHASE_BWD_A | E.PHASE_BWD_B | E.PHASE_FINALIZE_A | E.PHASE_FINALIZE_B
-        ref = E.TrainEngine(S, H, Ld, B, seed=3); ref.load_params(make_params(S, H, Ld, 0))
-        sh = E.TrainEngine(S, H, Ld, B, seed=3); sh.load_params(make_params(S, H, Ld, 0))
-        sp = ShardPlan(sh.offsets["fc4.weight"], sh.n_params, world)
-        for step in range(2):
-            ref.step(x)                      # forward, backward, Adam over the slabs
-            sh.step(x, phases=ph)            # forward, backward, gradients summed into the flat arena
-            gathered = torch.zeros(sp.ag_elems, device="cuda")
-            full_grad = sh._arena_full[3]
-            for b in (0, 1):
-                lo, hi = sp.buckets[b]
-                cnt = sp.counts[b]
-                for r in range(world):
-                    a, e = sp.own(b, r)
-                    shard = full_grad[lo + r * cnt: lo + (r + 1) * cnt].clone()   # reduce-scatter output of rank r
-                    L_.rv_adam_flat(ptr(sh.param), ptr(sh.exp_avg), ptr(sh.exp_avg_sq), ptr(shard), a, e - a, sh.lr, 1.0,
-                                    ptr(sh.step_counter), stream_ptr())
-                    go = sp.gather_offset(b) + r * cnt
-                    gathered[go:go + cnt] = sh._arena_full[0][lo + r * cnt: lo + (r + 1) * cnt]   # all-gather
-            torch.cuda.synchronize()
-            sh.param.zero_()                 # the parameters must come back from the gathered buffer alone
-            from rawaudiovae_kelsey_amd import _lib as P
-            descs = sh.plan_descs()
-            for b, (t0, nt) in ((0, (8, 2)), (1, (0, 8))):
-                arr = (P.ParamDesc * nt)(*descs[t0:t0 + nt])
-                L_.rv_params_from_flat(arr, nt, gathered[sp.gather_offset(b):].data_ptr(), sp.buckets[b][0], ptr(sh.param),
-                                       stream_ptr())
-            torch.cuda.synchronize()
-        diag = {k: (float((sh.view(sh.exp_avg, k) - ref.view(ref.exp_avg, k)).abs().max()),
-                    float((sh.view(sh.param, k) - ref.view(ref.param, k)).abs().max())) for k in E.PARAM_NAMES}
-        diag = str({k: v for k, v in diag.items() if v != (0.0, 0.0)}) + " world %d shape %r" % (world, (S, H, Ld, B))
-        assert torch.equal(sh.exp_avg, ref.exp_avg), diag
-        assert torch.equal(sh.param, ref.param), diag
-        assert torch.equal(sh.exp_avg_sq, ref.exp_avg_sq)
-        for name, dt in (("W1b", torch.bfloat16), ("Whb", torch.bfloat16), ("W3b", torch.bfloat16),
-                         ("W4b", torch.bfloat16), ("b1p", torch.float32), ("bhp", torch.float32), ("b4p", torch.float32)):
-            assert torch.equal(sh.buffer(name, dt, (-1,)), ref.buffer(name, dt, (-1,))), name
-
-
-def test_engines_sharing_an_arena_gather_the_masters_before_rebuilding_shadows(monkeypatch):
-    """Sharded optimizer with the 16-bit parameter message, two engines on one arena (train.py's full-batch engine and
-    its ragged-tail engine): after a step of one engine the fp32 weight masters are current on their owner rank only,
-    so the OTHER engine must gather them before it rebuilds its operand shadows from the arena.  Emulated here on
-    one GPU: engine A is marked as the bf16-gather owner, the half of the arena another rank would own is poisoned
-    with NaN behind A's back, and the gather (monkeypatched to what the all-gather would deliver: the true masters)
-    must run before engine B's refresh -- B then steps on finite, correct weights."""
-    from oracle.inputs import make_frames, make_params
-    from rawaudiovae_kelsey_amd import ddp
-    from rawaudiovae_kelsey_amd.engine import TrainEngine
-    S, H, L = 256, 512, 16
-    a = TrainEngine(S, H, L, 128, kl_beta=1e-4, lr=1e-4)
-    b = TrainEngine(S, H, L, 64, kl_beta=1e-4, lr=1e-4, share=a)
-    a.load_params(make_params(S, H, L, 0))
-    xa = torch.from_numpy(make_frames(128, S, 1)).cuda()
-    xb = torch.from_numpy(make_frames(64, S, 2)).cuda()
-    a.step(xa)
-    torch.cuda.synchronize()
-    truth = a.param.clone()
-    a._shared["bf16_gather_engine"] = a                 # what attach_comm(sharded=True, gather="bf16") records
-    half = a.n_params // 2
-    a.param[half:].fill_(float("nan"))                  # masters another rank owns: stale / unusable here
-    calls = []
-
-    def fake_gather(engine, group=None):
-        calls.append(engine)
-        engine.param.copy_(truth)                       # the all-gather of every owner's shard
-
-    monkeypatch.setattr(ddp, "gather_sharded_params", fake_gather)
-    b.step(xb)                                          # version moved: B refreshes its shadows first
-    torch.cuda.synchronize()
-    assert calls == [a]
-    loss = b.last_loss()[0]
-    assert loss == loss and 0 < loss < 1
-    assert torch.isfinite(b.buffer("W4b", torch.bfloat16, (-1,)).float()).all()
-    # the same step without the poisoning gives the same loss bit for bit
-    c = TrainEngine(S, H, L, 128, kl_beta=1e-4, lr=1e-4)
-    d = TrainEngine(S, H, L, 64, kl_beta=1e-4, lr=1e-4, share=c)
-    c.load_params(make_params(S, H, L, 0))
-    c.step(xa)
-    d.step(xb)
-    torch.cuda.synchronize()
-    assert d.last_loss() == b.last_loss()
 
 
 def test_flag_wait_behind_a_slow_collective_times_out_loudly_only_when_the_bound_is_short():

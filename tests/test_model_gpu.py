@@ -307,6 +307,34 @@ def test_loss_function_on_fused_outputs_is_one_node_on_the_plan(S, H, L, B):
     recon, mu, logvar = m3(x, eps=eps)
     loss_function(recon, x, mu, logvar, KLB, S).backward()
     assert len(seen) == 1 and torch.equal(seen[0], ga["fc3.bias"]) and torch.equal(m3.fc1.weight.grad, ga["fc1.weight"])
+    # the shortcut consumes the step's activations like autograd frees a graph: a second .backward() on the same loss raises
+    # unless the first kept the graph; and `fused_backward_shortcut = False` sends .backward() through the autograd engine
+    # (whose node hooks -- DistributedDataParallel's reducer, Horovod -- the shortcut cannot see): same bits
+    m4 = _model(S, H, L)
+    recon, mu, logvar = m4(x, eps=eps)
+    l4 = loss_function(recon, x, mu, logvar, KLB, S)
+    l4.backward()
+    with pytest.raises(RuntimeError, match="second time"):
+        l4.backward()
+    recon, mu, logvar = m4(x, eps=eps)
+    l4 = loss_function(recon, x, mu, logvar, KLB, S)
+    for p_ in m4.parameters():
+        p_.grad = None
+    l4.backward(retain_graph=True)
+    l4.backward()
+    for k, p_ in m4.named_parameters():
+        assert torch.equal(p_.grad, 2.0 * ga[k]), k
+    m5 = _model(S, H, L)
+    m5.fused_backward_shortcut = False
+    fired = []
+    recon, mu, logvar = m5(x, eps=eps)
+    l5 = loss_function(recon, x, mu, logvar, KLB, S)
+    node = l5.grad_fn.next_functions[0][0]
+    node.register_hook(lambda gi, go: fired.append(1))        # a hook on an autograd NODE: only the engine's route fires it
+    l5.backward()
+    assert fired == [1]
+    for k, p_ in m5.named_parameters():
+        assert torch.equal(p_.grad, ga[k]), k
     # an upstream factor reaches the gradients on the device (no host read of it)
     _, _, g3 = run(True, scale=2.5)
     for k in PARAM_NAMES:

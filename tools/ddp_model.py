@@ -41,8 +41,6 @@ class Comm:
         self.cfg = FakeComm(blocks, threads, lds, world, latency_us, bus)
         self.handle = C.cast(C.pointer(self.cfg), C.c_void_p)
         self.allreduce_addr = C.cast(lib.fake_allreduce, C.c_void_p)
-        self.reduce_scatter_addr = C.cast(lib.fake_reduce_scatter, C.c_void_p)
-        self.all_gather_addr = C.cast(lib.fake_all_gather, C.c_void_p)
         self.world, self.rank = world, 0
 
 

@@ -25,7 +25,6 @@ for i in 1 2; do
   RV_FORCE_DDP=1 RV_DDP_ALT=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, all-reduce, bf16 payload (bench)" $O/tmp_b.json
   RV_FORCE_DDP=1 RV_DDP_ALT=0 RV_DDP_DEFER=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "... every step completing itself (RV_DDP_DEFER=0)" $O/tmp_b.json
   RV_FORCE_DDP=1 RV_DDP_ALT=0 RV_DDP_PAYLOAD=fp32 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, all-reduce, fp32 payload (library default)" $O/tmp_b.json
-  RV_FORCE_DDP=1 RV_DDP_MODE=sharded RV_DDP_ALT=0 $B > $O/tmp_b.json 2>$O/tmp_b.err; line "one-rank RCCL, sharded optimizer" $O/tmp_b.json
 done
 } 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ddp_one_rank.txt
 tail -3 $O/tmp_b.err

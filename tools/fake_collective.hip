@@ -56,14 +56,6 @@ extern "C" int fake_allreduce(const void*, void*, size_t count, int dtype, int, 
   const double w = c->world > 1 ? c->world : 1;
   return hold(c, 2.0 * (w - 1.0) / w * (double)count * dtype_bytes(dtype), stream);
 }
-extern "C" int fake_reduce_scatter(const void*, void*, size_t recvcount, int dtype, int, void* comm, void* stream) {
-  const FakeComm* c = (const FakeComm*)comm;
-  return hold(c, (double)(c->world - 1) * recvcount * dtype_bytes(dtype), stream);
-}
-extern "C" int fake_all_gather(const void*, void*, size_t sendcount, int dtype, void* comm, void* stream) {
-  const FakeComm* c = (const FakeComm*)comm;
-  return hold(c, (double)(c->world - 1) * sendcount * dtype_bytes(dtype), stream);
-}
 
 // ------------------------------------------------------------------------------------------------ functional
 struct ShmHdr {
@@ -209,28 +201,4 @@ extern "C" int shm_allreduce(const void* send, void* recv, size_t count, int dty
   return 0;
 }
 
-extern "C" int shm_reduce_scatter(const void* send, void* recv, size_t recvcount, int dtype, int op, void* comm, void* stream) {
-  ShmComm* c = (ShmComm*)comm;
-  const size_t es = dtype_bytes(dtype), bytes = recvcount * es * c->world;
-  if (op != 0 || (dtype != 7 && dtype != 9) || bytes > c->cap) return 3;
-  SHM_TRY(hipStreamSynchronize((hipStream_t)stream));
-  SHM_TRY(hipMemcpy(c->slots + c->rank * c->cap, send, bytes, hipMemcpyDeviceToHost));
-  if (shm_barrier(c)) return 1;
-  reduce_into(c, (size_t)c->rank * recvcount, recvcount, dtype, c->tmp.data(), recvcount * c->world);
-  if (shm_barrier(c)) return 1;
-  SHM_TRY(hipMemcpy(recv, c->tmp.data(), recvcount * es, hipMemcpyHostToDevice));
-  return 0;
-}
 
-extern "C" int shm_all_gather(const void* send, void* recv, size_t sendcount, int dtype, void* comm, void* stream) {
-  ShmComm* c = (ShmComm*)comm;
-  const size_t bytes = sendcount * dtype_bytes(dtype);
-  if (bytes > c->cap) return 3;
-  SHM_TRY(hipStreamSynchronize((hipStream_t)stream));
-  SHM_TRY(hipMemcpy(c->slots + c->rank * c->cap, send, bytes, hipMemcpyDeviceToHost));
-  if (shm_barrier(c)) return 1;
-  for (int r = 0; r < c->world; ++r)
-    SHM_TRY(hipMemcpy((char*)recv + (size_t)r * bytes, c->slots + r * c->cap, bytes, hipMemcpyHostToDevice));
-  if (shm_barrier(c)) return 1;
-  return 0;
-}

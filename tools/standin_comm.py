@@ -1,8 +1,8 @@
 """Communicator objects over the stand-in collectives of tools/fake_collective.hip (tools/libfakecoll.so), for
 rehearsals on ONE GPU -- never on the product path.
 
-`ShmComm`: the FUNCTIONAL stand-ins (`shm_allreduce` / `shm_reduce_scatter` / `shm_all_gather`: RCCL's C signatures, a
-real exchange between processes through shared memory and the host).  It quacks like `ddp.RcclComm` as far as
+`ShmComm`: the FUNCTIONAL stand-in (`shm_allreduce`: RCCL's C signature, a real exchange between processes through shared
+memory and the host).  It quacks like `ddp.RcclComm` as far as
 `TrainEngine.attach_comm` / `ddp.NativeDdpRunner` / `bench.py` look: `handle`, `world`, `rank`, the three `*_addr`,
 `self_test`, `destroy`.  Used by tests/ddp_shm_worker.py and by `bench.py` under RV_DDP_REHEARSAL=shm (the N > 1 branch of
 the bench with the library-driven step, which RCCL itself cannot run on a one-GPU box: it refuses two ranks on a device).
@@ -29,8 +29,6 @@ class ShmComm:
             raise RuntimeError("shm_comm_create failed")
         self._lib, self.handle, self.world, self.rank = lib, C.c_void_p(h), world, rank
         self.allreduce_addr = C.cast(lib.shm_allreduce, C.c_void_p)
-        self.reduce_scatter_addr = C.cast(lib.shm_reduce_scatter, C.c_void_p)
-        self.all_gather_addr = C.cast(lib.shm_all_gather, C.c_void_p)
 
     def set_bf16_ring(self, on):
         """bf16 payloads summed hop by hop in bf16, in ring order (world - 1 roundings per element: what a ring all-reduce

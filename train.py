@@ -92,7 +92,6 @@ class DataParallel:
         self.active = self.world > 1
         self.device = device
         self.comm = None
-        self.sharded = False
         self.engines = []      # every engine the exchange is attached to (the full-batch one and the ragged tail's)
         if self.active:
             backend = os.environ.get("RV_DIST_BACKEND", "nccl")
@@ -166,30 +165,17 @@ class DataParallel:
             return engine.step
         self.engines.append(engine)
         if self.comm is not None:
-            # RV_DDP_MODE=allreduce (default): all-reduce and the full update on every rank;
-            # RV_DDP_MODE=sharded: reduce-scatter the gradients, Adam on this rank's 1/world of the arena,
-            # all-gather the parameters; =allreduce: all-reduce and the full update on every rank
-            self.sharded = os.environ.get("RV_DDP_MODE", "allreduce") == "sharded"
-            # sharded: fp32 parameters are all-gathered by default here (every rank's masters stay current for the
-            # per-epoch histograms and evaluation); RV_SHARD_GATHER=bf16 selects the 16-bit message (half the bytes,
-            # masters gathered at checkpoints by sync_optimizer_state)
-            engine.attach_comm(self.comm, sharded=self.sharded,
-                               gather=os.environ.get("RV_SHARD_GATHER", "fp32") if self.sharded else None,
-                               payload=os.environ.get("RV_DDP_PAYLOAD"))   # all-reduce: fp32 (the exact mean) by default, bf16 opt-in
+            # all-reduce of two gradient buckets and the full update on every rank; payload fp32 (the exact mean) by
+            # default, RV_DDP_PAYLOAD=bf16 opts into the half-size payload (DESIGN.md section 5 has its error model)
+            engine.attach_comm(self.comm, payload=os.environ.get("RV_DDP_PAYLOAD"))
+            # RV_DDP_DEFER=1 (what bench.py times at N > 1): a step's last wait + update go out behind the next step's cast
+            # launch; the engine's readers, its health check and the checkpoint path flush it themselves
+            if os.environ.get("RV_DDP_DEFER", "0") == "1":
+                engine.set_ddp_defer(True)
             return lambda x: engine.step_ddp(x, stream=torch.cuda.current_stream())
         from rawaudiovae_kelsey_amd import ddp
         sync = ddp.GradSync(engine.grad, ddp.engine_buckets(engine))
         return lambda x: ddp.ddp_step(engine, sync, x)
-
-    def sync_optimizer_state(self, engine):
-        """Before a checkpoint or an evaluation (every rank calls it): with the sharded optimizer the Adam moments
-        -- and, with the 16-bit parameter message, the fp32 weight masters -- live on their owner ranks; gather
-        them so that rank 0's state_dict() / optimizer_state_dict() are complete."""
-        if self.active and self.sharded:
-            from rawaudiovae_kelsey_amd import ddp
-            torch.cuda.synchronize(self.device)
-            ddp.gather_sharded_moments(engine)
-            ddp.gather_sharded_params(engine)
 
     def mean(self, value):
         """Mean over ranks of a host scalar."""
@@ -439,8 +425,6 @@ def main(argv=None):
             for name, param in model.named_parameters():
                 writer.add_histogram(name, param, epoch)
 
-        if epoch % checkpoint_interval == 0 and epoch != 0:
-            dp.sync_optimizer_state(engine)      # every rank: the sharded optimizer's moments travel to rank 0
         if epoch % checkpoint_interval == 0 and epoch != 0 and dp.main:
             print('Checkpoint - Epoch {}'.format(epoch))
             if generate_test:
@@ -458,7 +442,6 @@ def main(argv=None):
             dp.rendezvous()     # every rank: nobody starts the next epoch's steps while rank 0 is still writing
         final_loss = train_loss
 
-    dp.sync_optimizer_state(engine)
     dp.check_replicas(engine)
     if dp.main:
         print('Last Checkpoint - Epoch {}'.format(epoch))
