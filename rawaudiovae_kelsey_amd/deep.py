@@ -4,7 +4,8 @@ encoder/decoder, latent 256): `depth` Linear+ReLU layers on each side instead of
 The reference has no such model -- this is a build extension that shows the
 kernel family is not specialised to the five-Linear topology.  The training step is sequenced
 from Python over the same C-ABI entry points the fused plan uses (`rv_linear_fwd`,
-`rv_linear_dgrad_wgrad` -- paired 256x256 launch for every H x H layer --, `rv_reparam_*`,
+`rv_linear_dgrad_wgrad` -- paired 256x256 launch for every H x H layer --, `rv_latent_fwd` / `rv_latent_bwd`
+(the latent-sized GEMMs with the reparameterisation in their epilogues, round 6),
 `rv_decode_out_loss_fwd`, `rv_adam_multi`); capture it in a hipGraph (`engine.Graph`) to remove
 the per-launch host cost.  With depth=1 it computes exactly what `TrainEngine` computes.
 
@@ -101,8 +102,6 @@ class DeepTrainEngine:
         self.xb = z_(Bp, Sp, **bf)
         self.enc_act = [z_(Bp, Hp, **bf) for _ in range(d)]
         self.dec_act = [z_(Bp, Hp, **bf) for _ in range(d)]
-        self.s_heads = gemm_pick(Bp, 2 * Lp, Hp)[2]
-        self.mulv_slabs = z_(self.s_heads, Bp, 2 * Lp, **f32)
         self.mulv = z_(Bp, 2 * Lp, **f32)
         self.eps = z_(Bp * Lp, **f32)
         self.z = z_(Bp, Lp, **bf)
@@ -116,8 +115,6 @@ class DeepTrainEngine:
         self.d_dec = [z_(Bp, Hp, **bf) for _ in range(d)]
         self.d_enc = [z_(Bp, Hp, **bf) for _ in range(d)]
         self.dmulv = z_(Bp, 2 * Lp, **bf)
-        self.s_dz = gemm_pick(Bp, Lp, Hp)[2]
-        self.dz_slabs = z_(self.s_dz, Bp, Lp, **f32)
         # per-tensor shadows, gradient slabs and bias-gradient partials
         self.shadow, self.slabs, self.splits, self.bias_part = {}, {}, {}, {}
         self.unscale = {}      # name -> [splits, rows_p / 32, cols_p / 32] fp32: 2^-e per granule of an fp16 slab
@@ -165,7 +162,9 @@ class DeepTrainEngine:
             if kt % sp0 == 0:
                 self.tile_enc0 = TILE_256x256
         slab("enc.0.weight", sp0, Hp, Sp, True)
-        slab("heads.weight", self.plan_heads[2], 2 * Lp, Hp)
+        # (the heads' eight [2 Lp, Hp] slabs are block-floating-point fp16 too where their backward is the paired 256 x 256
+        # launch -- round 6, as TrainEngine at the reference's latent width: 32 MB as fp32, written there and read by Adam)
+        slab("heads.weight", self.plan_heads[2], 2 * Lp, Hp, bool(self.plan_heads[0]))
         # bias-gradient partial rows: produced by the kernel that creates the layer's dY
         self.bias_part["fc4.bias"] = z_(Bp // bm_o, Sp, **f32)
         self.bias_part["dec.%d.bias" % (d - 1)] = z_(Bp // self.plan_out[1], Hp, **f32)
@@ -250,7 +249,7 @@ class DeepTrainEngine:
             sb, sf, ld = self._shadow_of(k)
             if k in ("fc21.weight", "fc22.weight"):
                 sl = self.slabs["heads.weight"]
-                base = sl.data_ptr() + (4 * Lp * Hp if k == "fc22.weight" else 0)
+                base = sl.data_ptr() + (sl.element_size() * Lp * Hp if k == "fc22.weight" else 0)
                 g = (base, Hp, 2 * Lp * Hp, self.splits["heads.weight"])
             elif k in ("fc21.bias", "fc22.bias"):
                 base = self.dbh_part.data_ptr() + (4 * Lp if k == "fc22.bias" else 0)
@@ -262,9 +261,10 @@ class DeepTrainEngine:
                 bp = self.bias_part[k]
                 g = (bp.data_ptr(), bp.shape[1], bp.shape[1], bp.shape[0])
             descs[i] = ParamDesc(self.offsets[k], rows, cols, g[0], g[1], g[2], g[3], sb, sf, ld)
-            us = self.unscale.get(k)
+            us = self.unscale.get("heads.weight" if k in ("fc21.weight", "fc22.weight") else k)
             if us is not None:     # fp16 slabs: the optimizer multiplies each slab value by its granule's 2^-e
-                descs[i].grad_half, descs[i].grad_unscale = 1, us.data_ptr()
+                descs[i].grad_half = 1
+                descs[i].grad_unscale = us.data_ptr() + (4 * (Lp // 32) * us.shape[2] if k == "fc22.weight" else 0)
                 descs[i].us_ld, descs[i].us_split_stride = us.shape[2], us.shape[1] * us.shape[2]
         return descs
 
@@ -295,12 +295,14 @@ class DeepTrainEngine:
             L_.rv_linear_fwd(ptr(a), ka, W("enc.%d.weight" % i), ka, W("enc.%d.bias" % i), Bp, Hp, ka, ACT_RELU,
                              ptr(self.enc_act[i]), Hp, st)
             a, ka = self.enc_act[i], Hp
-        L_.rv_linear_fwd_f32(ptr(a), Hp, ptr(self.Whb), Hp, ptr(self.bhp), Bp, 2 * Lp, Hp, self.s_heads,
-                             ptr(self.mulv_slabs), 2 * Lp, st)
-        L_.rv_reparam_fwd(ptr(self.mulv_slabs), self.s_heads, Bp, Lp, B, L, ptr(eps), ptr(self.eps), self.seed, ctr,
-                          ptr(self.mulv), ptr(self.z), ptr(self.kl_part), st)
-        a, ka = self.z, Lp
-        for i in range(d):
+        # heads + reparameterisation + KL partials + the first decoder layer: rv_latent_fwd (round 6: at this variant's
+        # latent width of 256 the heads GEMM with the reparameterisation in its epilogue, then dec.0's forward GEMM --
+        # no fp32 slabs of mu | logvar, no reparameterisation launch; csrc/latent.hip)
+        L_.rv_latent_fwd(ptr(a), Hp, ptr(self.Whb), Hp, ptr(self.bhp), W("dec.0.weight"), Lp, W("dec.0.bias"), Bp, Hp, Lp,
+                         B, L, ptr(eps), ptr(self.eps), self.seed, ctr, ptr(self.mulv), ptr(self.z), ptr(self.kl_part),
+                         ptr(self.dec_act[0]), Hp, st)
+        a, ka = self.dec_act[0], Hp
+        for i in range(1, d):
             L_.rv_linear_fwd(ptr(a), ka, W("dec.%d.weight" % i), ka, W("dec.%d.bias" % i), Bp, Hp, ka, ACT_RELU,
                              ptr(self.dec_act[i]), Hp, st)
             a, ka = self.dec_act[i], Hp
@@ -316,13 +318,13 @@ class DeepTrainEngine:
                                      ptr(self.slabs[wname]), Hp, self.splits[wname], *self._slab_args(wname), st)
             dy, kd, wname = self.d_dec[i], Hp, "dec.%d.weight" % i
         # dec.0: input is z (no ReLU): dz as fp32 slabs, weight gradient separately
-        L_.rv_linear_dgrad_wgrad_f32(ptr(dy), Hp, W("dec.0.weight"), Lp, ptr(self.z), Lp, Bp, Lp, Hp,
-                                     ptr(self.dz_slabs), Lp, self.s_dz, ptr(self.slabs["dec.0.weight"]), Lp,
-                                     self.splits["dec.0.weight"], st)
-        L_.rv_reparam_bwd(ptr(self.dz_slabs), self.s_dz, Bp, Lp, B, L, S, ptr(self.mulv),
-                          ptr(eps if eps is not None else self.eps), self.kl_beta, None, None, ptr(self.dmulv),
-                          ptr(self.dbh_part), ptr(self.mse_part), self.n_mse, ptr(self.kl_part), self.n_kl,
-                          ptr(self.loss_ring), ctr, self.ring, st)
+        # (rv_latent_bwd: dz tiles with the reparameterisation backward and the loss scalar in their launch, dec.0's weight
+        # gradient on the same launch's extra workgroups -- no dz slabs, no rv_reparam_bwd launch)
+        L_.rv_latent_bwd(ptr(dy), Hp, W("dec.0.weight"), Lp, Bp, Hp, Lp, B, L, S, ptr(self.mulv),
+                         ptr(eps if eps is not None else self.eps), self.kl_beta, None, None, ptr(self.dmulv),
+                         ptr(self.dbh_part), ptr(self.mse_part), self.n_mse, ptr(self.kl_part), self.n_kl,
+                         ptr(self.loss_ring), ctr, self.ring, ptr(self.z), Lp, ptr(self.slabs["dec.0.weight"]), Lp,
+                         self.splits["dec.0.weight"], st)
         # backward: heads and encoder
         dy, kd, wptr, wname = self.dmulv, 2 * Lp, ptr(self.Whb), "heads.weight"
         for i in range(d - 1, -1, -1):

@@ -103,7 +103,8 @@ def fusable(module, x2):
 
 class _FwdRecord:
     """What `loss_function` needs to recognise the untouched outputs of one fused forward (FusedLossFn below)."""
-    __slots__ = ("eng", "tick", "eps", "x_ptr", "x_numel", "x_version", "params", "module", "loss_taken", "mu", "logvar")
+    __slots__ = ("eng", "tick", "eps", "x_ptr", "x_numel", "x_version", "params", "module", "loss_taken", "mu", "logvar",
+                 "shortcut_consumed")
 
 
 class VaeFn(torch.autograd.Function):
