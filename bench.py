@@ -104,13 +104,15 @@ def step_launches(eng):
     riders = ", ".join(dict.fromkeys(names[rf:]))
     tail = ", ".join(dict.fromkeys(names[:rf]))
     dims = "%dx%dx%d" % (B, H, S)
-    rowlocal = Lp == 64
+    riders_on = Hp % 256 == 0 and Sp % 256 == 0 and (Hp // 256) * (Sp // 256) * s_w1 <= 192   # plan.hip's full-local schedule
+    rowlocal = Lp == 64 and Hp % 512 == 0 and Hp <= 2048 and Bp <= 8192   # csrc/latent.hip rv_latent_rowlocal
     rows = [
         ("k_cast_pad_bf16 (frames fp32 -> padded bf16 operand)", 0.0, B * S * 4 + Bp * Sp * 2),
         ("fc1 forward GEMM: relu(x W1^T + b1) %s" % dims, 2.0 * B * S * H,
          Bp * Sp * 2 + Hp * Sp * 2 + Bp * Hp * 2),
         (("k_latent_fwd: heads GEMM + reparameterisation + KL partials + fc3 (row-local)" if rowlocal else
-          "k_heads_reparam_gemm (heads GEMM, 64x128 tiles, reparameterisation + KL partials in the epilogue) + fc3 forward GEMM"),
+          "k_heads_reparam_gemm (heads GEMM, 64x128 tiles -- 256x128 at large batches --, reparameterisation + KL partials in the "
+          "epilogue) + fc3 forward GEMM"),
          2.0 * B * H * 2 * L + 2.0 * B * L * H,
          Bp * Hp * 2 + Bp * Hp * 2 + (2 * Lp * Hp + Hp * Lp) * 2 + Bp * 2 * Lp * 4 + Bp * Lp * (4 + 2) + (0 if rowlocal else Bp * Lp * 2)),
         ("fc4 forward GEMM + tanh + MSE partials + dP4: %dx%dx%d" % (B, S, H), 2.0 * B * H * S,
@@ -119,17 +121,20 @@ def step_launches(eng):
          "allow)" % (dims, S, H, B, s_w4, eng.slab_dtype), 4.0 * B * H * S,
          Bp * Sp * 2 + Sp * Hp * 2 + Bp * Hp * 2 + Bp * Hp * 2 + s_w4 * Sp * Hp * sb),
         (("k_latent_bwd: dz = dP3 W3 + reparameterisation backward + dW3 (co-resident workgroups)" if rowlocal else
-          "k_dz_reparam_gemm: dz = dP3 W3 on 64x128 tiles with the reparameterisation backward in the epilogue + dW3 on 128x128 "
-          "tiles, one launch"), 4.0 * B * H * L,
+          "k_dz_reparam_gemm: dz = dP3 W3 on 64x64 tiles (256x128 at large batches) with the reparameterisation backward in the "
+          "epilogue + dW3 on 128x128 tiles, one launch"), 4.0 * B * H * L,
          Bp * Hp * 2 + Hp * Lp * 2 + Bp * Lp * 2 + Bp * 2 * Lp * (4 + 2) + Bp * Lp * 4 + descs[6].grad_splits * Hp * Lp * 4),
         (("k_heads_bwd: dP1 = relu'(dmulv Wh) + dWh, one pass over h1" if rowlocal else
           "heads backward: dP1 = relu'(dmulv Wh) + dWh = dmulv^T h1"), 4.0 * B * H * 2 * L,
          Bp * Hp * 2 + Bp * 2 * Lp * 2 + Bp * Hp * 2 + descs[2].grad_splits * 2 * Lp * Hp * (2 if descs[2].grad_half else 4)),
-        ("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs) + Adam of %s beside it (rider blocks)" % (
-            H, S, B, s_w1, eng.slab_dtype, riders), 2.0 * B * S * H,
-         Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + adam_bytes(descs[rf:10])),
-        ("k_adam<true> Adam of %s (sums the gradient slabs, %d of dW1; refreshes the bf16 shadows)" % (tail, s_w1), 0.0,
-         adam_bytes(descs[0:rf])),
+        # (the rider blocks exist where fc1's weight gradient leaves CUs idle: 256 x 256 tiles x K splits <= 192 blocks; at large
+        # batches it fills the chip and the whole optimizer is the last launch)
+        (("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs) + Adam of %s beside it (rider blocks)" % (
+            H, S, B, s_w1, eng.slab_dtype, riders)) if riders_on else
+         ("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs), 256x256 tiles on all CUs" % (H, S, B, s_w1, eng.slab_dtype)),
+         2.0 * B * S * H, Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + (adam_bytes(descs[rf:10]) if riders_on else 0)),
+        ("k_adam<true> Adam of %s (sums the gradient slabs, %d of dW1; refreshes the bf16 shadows)" % (
+            tail if riders_on else "all ten tensors", s_w1), 0.0, adam_bytes(descs[0:rf] if riders_on else descs[0:10])),
     ]
     return rows
 
