@@ -99,10 +99,11 @@ def step_launches(eng):
             n += el * (26 if d.shadow_bf16 else 28) + el * d.grad_splits * (2 if d.grad_half else 4)
         return n
     s_w1, s_w4 = descs[0].grad_splits, descs[8].grad_splits
-    rf = eng.rider_first()   # tensors [rf, 10) are updated beside fc1's weight gradient, [0, rf) by the last launch
+    rf, rl = eng.riders()   # tensors [rf, rl) are updated beside fc1's weight gradient, the others by the last launch
     names = ["fc1", "fc1", "fc21", "fc21", "fc22", "fc22", "fc3", "fc3", "fc4", "fc4"]
-    riders = ", ".join(dict.fromkeys(names[rf:]))
-    tail = ", ".join(dict.fromkeys(names[:rf]))
+    riders = ", ".join(dict.fromkeys(names[rf:rl]))
+    tail = ", ".join(dict.fromkeys(names[:rf] + names[rl:]))
+    d_riders, d_tail = list(descs[rf:rl]), list(descs[:rf]) + list(descs[rl:])
     dims = "%dx%dx%d" % (B, H, S)
     riders_on = Hp % 256 == 0 and Sp % 256 == 0 and (Hp // 256) * (Sp // 256) * s_w1 <= 192   # plan.hip's full-local schedule
     rowlocal = Lp == 64 and Hp % 512 == 0 and Hp <= 2048 and Bp <= 8192   # csrc/latent.hip rv_latent_rowlocal
@@ -132,9 +133,9 @@ def step_launches(eng):
         (("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs) + Adam of %s beside it (rider blocks)" % (
             H, S, B, s_w1, eng.slab_dtype, riders)) if riders_on else
          ("fc1 weight gradient dW=dY^T X %dx%dx%d split-K %d (%s slabs), 256x256 tiles on all CUs" % (H, S, B, s_w1, eng.slab_dtype)),
-         2.0 * B * S * H, Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + (adam_bytes(descs[rf:10]) if riders_on else 0)),
+         2.0 * B * S * H, Bp * Hp * 2 + Bp * Sp * 2 + s_w1 * Hp * Sp * sb + (adam_bytes(d_riders) if riders_on else 0)),
         ("k_adam<true> Adam of %s (sums the gradient slabs, %d of dW1; refreshes the bf16 shadows)" % (
-            tail if riders_on else "all ten tensors", s_w1), 0.0, adam_bytes(descs[0:rf] if riders_on else descs[0:10])),
+            tail if riders_on else "all ten tensors", s_w1), 0.0, adam_bytes(d_tail if riders_on else descs[0:10])),
     ]
     return rows
 

@@ -512,12 +512,12 @@ int rv_plan_set_loss_grad(rv_plan*, const float* d_loss_dev, float* grad_out);
  * bound flat gradient arena (1), and the operand shadows Adam must refresh.  For callers that drive
  * rv_adam_multi / rv_params_from_flat themselves. */
 int rv_plan_descs(const rv_plan*, rv_param_desc* out10, int from_flat);
-/* How the full local step divides the optimizer (train.py:193) between its last two launches: tensors [first, 10) of the
- * descriptor table are updated by rider blocks beside fc1's weight gradient (rv_linear_wgrad_adam), tensors [0, first) by
- * the step's last launch (rv_adam_multi).  first = 2 at a latent width of 64 (only fc1 is left for the last launch);
- * 6 at the reference's own latent_dim = 256 (default.ini:18), where the heads' tensors would otherwise make the riders
- * twice as long as the GEMM beside them.  Returns -1 for an unbound plan. */
-long rv_plan_rider_first(const rv_plan*);
+/* How the full local step divides the optimizer (train.py:193) between its last two launches: tensors [*first, *last) of
+ * the descriptor table are updated by rider blocks beside fc1's weight gradient (rv_linear_wgrad_adam), all others by the
+ * step's last launch (rv_adam_multi).  [2, 10) at a latent width of 64 (only fc1 is left for the last launch); [2, 8) --
+ * the heads and fc3 -- at the reference's own latent_dim = 256 (default.ini:18), where everything but fc1 would make the
+ * riders twice as long as the GEMM beside them.  RV_ERR_STATE for an unbound plan. */
+int rv_plan_riders(const rv_plan*, int* first, int* last);
 /* Rebuild every bf16 weight shadow from the fp32 param arena (after init / load). */
 int rv_plan_refresh_shadows(rv_plan*, void* stream);
 /* Enqueue the selected phases of one training step (train.py:184-193) on `stream`.

@@ -113,7 +113,7 @@ _SIGS = {
     "rv_plan_bind": (c_int, [c_void_p, C.POINTER(PlanBuffers)]),
     "rv_plan_refresh_shadows": (c_int, [c_void_p, c_void_p]),
     "rv_plan_descs": (c_int, [c_void_p, C.POINTER(ParamDesc), c_int]),
-    "rv_plan_rider_first": (c_long, [c_void_p]),
+    "rv_plan_riders": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "rv_plan_set_external_grads": (c_int, [c_void_p] * 6),
     "rv_plan_loss": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "rv_plan_set_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p]),

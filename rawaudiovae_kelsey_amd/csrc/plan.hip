@@ -508,26 +508,32 @@ int rv_plan_bind(rv_plan* p, const rv_plan_buffers* b) {
 }
 
 // Which tensors' optimizer updates ride beside fc1's weight gradient in the full local step (launch 7: the GEMM fills half
-// the chip for ~30 us, its rider blocks stream ~2.8 TB/s from the other half): tensors [first, 10) of the table, the rest
-// goes into the step's last launch, which runs on all CUs at ~4.8 TB/s.  first = 2 (everything but fc1, ~91 MB) at C2's
-// latent width of 64; at the reference's own latent_dim = 256 that set is 152 MB and made launch 7 twice as long as its
-// GEMM (60 us; profiles/r06_first_look.txt), so the heads' tensors move to the last launch: the smallest of {2, 6, 8}
-// whose bytes fit what the riders move in the GEMM's time.
+// the chip for ~30 us, its rider blocks stream ~2.8 TB/s from the other half): tensors [first, last) of the table, the
+// rest goes into the step's last launch, which runs on all CUs at ~4.8 TB/s.  [2, 10) (everything but fc1, ~91 MB) at C2's
+// latent width of 64.  At the reference's own latent_dim = 256 that set is 136-152 MB and made launch 7 twice as long as
+// its GEMM (60 us; profiles/r06_first_look.txt): there the heads and fc3 ride, [2, 8) = 65 MB, and the last launch takes
+// fc1 and fc4 -- the two tensors whose four fp16 slabs stream at the optimizer's best rate: 229-231 us per step against
+// 237 with fc3 + fc4 riding and 240-242 with everything but fc1 (one box, interleaved: profiles/r06_riders_ab.txt).
 static long desc_bytes(const rv_param_desc& d) {
   const long el = d.rows * d.cols;
   return el * (d.shadow_bf16 ? 26 : 28) + el * d.grad_splits * (d.grad_half ? 2 : 4);
 }
-static int rider_first(const rv_plan* p) {
+static void rider_range(const rv_plan* p, int* first, int* last) {
   const long budget = 100L * 1000 * 1000;
-  for (int first : {2, 6, 8}) {
+  const int cand[4][2] = {{2, 10}, {2, 8}, {6, 10}, {8, 10}};
+  for (const auto& c : cand) {
     long n = 0;
-    for (int i = first; i < 10; ++i) n += desc_bytes(p->d_slab[i]);
-    if (n <= budget) return first;
+    for (int i = c[0]; i < c[1]; ++i) n += desc_bytes(p->d_slab[i]);
+    if (n <= budget) { *first = c[0]; *last = c[1]; return; }
   }
-  return 8;
+  *first = 8; *last = 10;
 }
 
-long rv_plan_rider_first(const rv_plan* p) { return p && p->bound ? rider_first(p) : -1; }
+int rv_plan_riders(const rv_plan* p, int* first, int* last) {
+  RV_REQUIRE(p && p->bound && first && last, RV_ERR_STATE, "rv_plan_riders: plan not bound");
+  rider_range(p, first, last);
+  return RV_OK;
+}
 
 int rv_plan_descs(const rv_plan* p, rv_param_desc* out10, int from_flat) {
   RV_REQUIRE(p && p->bound && out10, RV_ERR_STATE, "rv_plan_descs: plan not bound");
@@ -815,7 +821,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     // complete on the other CUs (fc21, fc22, fc3, fc4); fc1's update is the step's last launch.  An optimizer block
     // streams ~25 GB/s from its CU, so half the chip moves ~3 TB/s -- about what the GEMM blocks take to finish.
     const int n_gemm = (int)((Hp / 256) * (Sp / 256) * p->s_w1);
-    int rf = 2;   // first tensor of the table whose update rides beside fc1's weight gradient (rider_first)
+    int rf = 2, rl = 10;   // tensors [rf, rl) of the table: their updates ride beside fc1's weight gradient (rider_range)
     {
       Range r(p->roctx, "rv:fc4-bwd");
       RV_K(4, fc4_backward(p, stream));
@@ -831,18 +837,23 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       // 194.8 us per step with only fc3 / fc4 riding, 196.3 with only fc4: profiles/r03_ab_step.txt)
       // (fp8 operands: only fc4's update riding here and the rest in the last launch was tried in round 5 -- 166.2-167.1 us
       // per step against 164.0-164.2 with the whole table riding and the GEMM blocks taking 15 % of it: profiles/r05_fp8_riders.txt)
-      rf = rider_first(p);
+      rider_range(p, &rf, &rl);
       if (f8_w1)
         RV_K(7, rv_linear_wgrad_adam_fp8(p->ws("dP1q"), Hp, p->ws("xq"), Sp, (float*)p->ws("fp8_state") + 15, Hp, Sp, Bp, p->s_w1,
-                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + rf, 10 - rf, p->b.param, p->b.exp_avg,
+                                         p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + rf, rl - rf, p->b.param, p->b.exp_avg,
                                          p->b.exp_avg_sq, lr, grad_scale, p->b.step_counter, 256 - n_gemm, stream));
       else
         RV_K(7, rv_linear_wgrad_adam(dP1, Hp, xb, Sp, Hp, Sp, Bp, p->s_w1, p->ws("dW1"), Sp, p->slab_dtype, p->us_w1, p->d_slab + rf,
-                                     10 - rf, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
+                                     rl - rf, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, lr, grad_scale,
                                      p->b.step_counter, 256 - n_gemm, stream));
     }
     Range r(p->roctx, "rv:adam");
-    RV_K(8, rv_adam_multi(p->d_slab, rf, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
+    // the last launch: everything that did not ride ([0, rf) and [rl, 10), one table)
+    rv_param_desc rest[10];
+    int n_rest = 0;
+    for (int i = 0; i < 10; ++i)
+      if (i < rf || i >= rl) rest[n_rest++] = p->d_slab[i];
+    RV_K(8, rv_adam_multi(rest, n_rest, p->b.param, p->b.exp_avg, p->b.exp_avg_sq, nullptr, nullptr, lr, grad_scale,
                           p->b.step_counter, stream));
     return fp8_after_update(p, stream);
   }

@@ -418,10 +418,12 @@ class TrainEngine:
         lib().rv_plan_descs(self._plan, arr, int(bool(from_flat)))
         return list(arr)
 
-    def rider_first(self):
-        """Tensors [first, 10) of the descriptor table are updated beside fc1's weight gradient, [0, first) by the step's
-        last launch (`rv_plan_rider_first`)."""
-        return int(lib().rv_plan_rider_first(self._plan))
+    def riders(self):
+        """(first, last): tensors [first, last) of the descriptor table are updated beside fc1's weight gradient, all others
+        by the step's last launch (`rv_plan_riders`)."""
+        a, b = C.c_int(), C.c_int()
+        lib().rv_plan_riders(self._plan, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def buffer(self, name, dtype, shape):
         """Typed view of a workspace buffer (tests / inspection)."""

@@ -27,7 +27,7 @@ int main() {
   fails += rv_linear_fp32(x, 1, x, 1, NULL, 0, 1, 1, 0, x, 1, NULL) == 0;
   rv_plan* pl = NULL;
   fails += rv_plan_create(&pl, 4096, 1024, 2048, 64) != 0;
-  fails += rv_plan_rider_first(pl) != -1;                              // needs a bound plan
+  { int a_ = 0, b_ = 0; fails += rv_plan_riders(pl, &a_, &b_) == 0; }  // needs a bound plan
   fails += rv_plan_set_option(pl, RV_OPT_FP8, 1) == 0;                 // not bound
   rv_comm_desc c; memset(&c, 0, sizeof c);
   c.comm = x; c.world = 2; c.rank = 2;

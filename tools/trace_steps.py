@@ -11,7 +11,8 @@ names = [r["Kernel_Name"] for r in rows]
 first = "k_cast_pad_bf16"
 idx = [i for i, n in enumerate(names) if first in n]
 seq = collections.defaultdict(list)
-for a, b in zip(idx[-60:-1], idx[-59:]):
+n_use = min(60, len(idx) - 1)
+for a, b in zip(idx[-n_use - 1:-1], idx[-n_use:]):
     for j, r in enumerate(rows[a:b]):
         seq[(j, r["Kernel_Name"][:100])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     seq[(99, "step (start to start)")].append((int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3)
