@@ -85,6 +85,9 @@ def decode(params, z, quant=None, fp8_scales=None):
     h3 = _q(h3f, quant)
     if quant == "fp8":
         h3q = _q8(h3f, fp8_scales["h3"])
+        # the image keeps the ReLU mask: a positive activation is held at the smallest e4m3 subnormal instead of
+        # quantising to zero (csrc/common.h fp8_keep_positive), so (h3q > 0) == (h3 > 0) for the fp8 backward's mask
+        h3q = np.where((h3f > 0) & (h3q == 0), 2.0 ** -9 / fp8_scales["h3"], h3q)
         pre = (h3q @ _q8(params["fc4.weight"], fp8_scales["w4"]).T).astype(z.dtype)
         recon = np.tanh(pre + params["fc4.bias"])
         return h3, recon, h3q.astype(z.dtype)

@@ -67,6 +67,13 @@ __device__ __forceinline__ void store_out16(V* dst, const V& v, const int wt) {
   else *dst = v;
 }
 
+// Scaled value of a post-ReLU activation on its way to its fp8 (e4m3) image: a POSITIVE activation never quantises to zero
+// (it is held at the smallest subnormal, 2^-9), so the image keeps the activation's ReLU mask exactly -- the fp8 fc4
+// backward reads its mask from the image (a positive byte) where the bf16 copy of h3 is not written.
+__device__ __forceinline__ float fp8_keep_positive(float v, float scaled) {
+  return v > 0.f ? fmaxf(scaled, 0.001953125f) : scaled;
+}
+
 // tanh(y) = 1 - 2/(1+exp(2y)); abs error ~2e-7 (v_exp_f32 and v_rcp_f32, 1 ulp each), saturates cleanly.
 // v_rcp_f32 directly: __frcp_rn is the correctly rounded reciprocal, a ten-instruction sequence per element.
 __device__ __forceinline__ float fast_tanh(float y) {

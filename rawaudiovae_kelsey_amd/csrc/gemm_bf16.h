@@ -68,6 +68,10 @@ struct GemmArgs {
   const float* bias;  // [N] (padded), may be null
   const bf16_t* mask;
   long ld_mask;
+  // fp8 (e4m3) operand path, 256 x 256 ping-pong dgrad only: non-zero = `mask` points at the fp8 image of the activation
+  // (one byte per element, ld_mask in BYTES): the ReLU mask is read from the image the forward already wrote for the next
+  // GEMM, and the bf16 copy of that activation need not exist (a positive e4m3 byte is a positive int8)
+  int mask_fp8;
   const float* x;  // EPI_TANH_LOSS target frames, exact [M_valid, N_valid]
   long ld_x;
   // ... or, when x_hop != 0, hop-strided frames of a waveform: `x` is the waveform (x_nsamples samples, zero past
@@ -664,18 +668,31 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   lds_char* mk_lds = smem + wave * (WTM * 128);              // chunks 1.. : the wave's 16 KiB of the ring (first 4 KiB unused)
   lds_char* mk_lds0 = smem + 2 * (BM + BN) * 128 + wave * MK_C0;   // chunk 0: behind the ring
   bool mask_lds = false;
-  const bf16_t* mk_g = nullptr;
+  const char* mk_g = nullptr;       // this lane's piece of row (lane >> 3) of the wave tile's mask, as a byte address
+  long mk_pitch8 = 0;               // bytes between DMA instructions (8 mask rows)
+  const bool mask8 = FP8 && MASK_LDS && p.mask_fp8;   // wave-uniform
   if constexpr (MASK_LDS) {
     if (p.mask) {
       mask_lds = true;
-      const int mrow = lane >> 3, mpc = (lane & 7) ^ (lane >> 3);
-      mk_g = p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8;
+      const int mrow = lane >> 3;
+      if (mask8) {
+        // fp8 image: a mask row of the wave tile is 64 bytes = four 16-byte pieces; LDS position s (0..3) of row r holds
+        // piece s ^ (r & 3), positions 4..7 of the 128-byte LDS row repeat them (never read: the instruction count, and
+        // with it the counted vmcnt waits of the epilogue, stay those of the bf16 mask)
+        const int mpc = ((lane & 3) ^ (mrow & 3));
+        mk_g = (const char*)p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 16;
+        mk_pitch8 = 8 * p.ld_mask;
+      } else {
+        const int mpc = (lane & 7) ^ (lane >> 3);
+        mk_g = (const char*)(p.mask + (m0 + wm * WTM + mrow) * p.ld_mask + n0 + wn * WTN + mpc * 8);
+        mk_pitch8 = 16 * p.ld_mask;
+      }
     }
   }
   auto mask_dma = [&](int i0, int i1, lds_char* base) {     // pieces [i0, i1) of the wave tile (8 rows each)
 #pragma unroll
     for (int i = i0; i < i1; ++i)
-      __builtin_amdgcn_global_load_lds((glb_cptr)(mk_g + (long)(8 * i) * p.ld_mask),
+      __builtin_amdgcn_global_load_lds((glb_cptr)(mk_g + (long)i * mk_pitch8),
                                        (__attribute__((address_space(3))) void*)(base + (i - i0) * 1024), 16, 0, 0);
   };
   if constexpr (PINGPONG) {
@@ -1053,7 +1070,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             amax = fmaxf(amax, fabsf(tt[e]));
-            q8[e] = tt[e] * qs;
+            q8[e] = p.relu ? fp8_keep_positive(tt[e], tt[e] * qs) : tt[e] * qs;
           }
           if (p.out_fp8) *(unsigned long long*)(p.out_fp8 + rowi[it] * p.ld_fp8 + coli[it]) = pack_fp8x8(q8);
         }
@@ -1233,7 +1250,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
           for (int it = 0; it < CH; ++it) {
             const int rl = (c0 + it / NP) * 16 + ej, pc = (it % NP) * 4 + (eq & 1) * 2 + (eq >> 1);
-            mk[it] = *(const __attribute__((address_space(3))) i32x4*)(mb + rl * 128 + ((pc ^ (rl & 7)) * 16));
+            if (mask8) {
+              // fp8 image: the item's 8 columns are 8 bytes, half (pc & 1) of 16-byte piece pc >> 1; turned into the bf16
+              // test's words: byte b is a positive e4m3 iff it is a positive int8 -- spread to 16 bits it keeps its sign
+              // and its "non-zero", which is all the test below reads
+              typedef int i32x2_ __attribute__((ext_vector_type(2)));
+              const i32x2_ b8 = *(const __attribute__((address_space(3))) i32x2_*)(mb + rl * 128 + (((pc >> 1) ^ (rl & 3)) * 16) + (pc & 1) * 8);
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const int two = (b8[w >> 1] >> (16 * (w & 1))) & 0xFFFF;                 // bytes 2w, 2w + 1
+                const int lo = (int)(signed char)(two & 0xFF), hi = (int)(signed char)(two >> 8);
+                mk[it][w] = (lo & 0xFFFF) | (hi << 16);                                  // sign-extended to 16 bits each
+              }
+            } else {
+              mk[it] = *(const __attribute__((address_space(3))) i32x4*)(mb + rl * 128 + ((pc ^ (rl & 7)) * 16));
+            }
           }
         } else if (PF_MASK && pf_on && c0 == 0) {
 #pragma unroll

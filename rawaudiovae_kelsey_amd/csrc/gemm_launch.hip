@@ -747,17 +747,19 @@ int rv_linear_dgrad_wgrad_f32(const void* dy, long lddy, const void* w, long ldw
 // one 256 x 256 ping-pong launch, every operand one byte per element -- dy_fp8 [Mp(batch), Kp(out)] (the fp8 image of
 // dP4 that the fc4 forward's epilogue wrote, K-major for the dgrad and MN-major for the wgrad), w_fp8 [Kp, Np] (the
 // fp8 weight shadow, MN-major through ds_read_b64_tr_b8), x_fp8 [Mp, Np] (the fp8 image of h3, the wgrad's MN-major
-// right operand); mask_bf16 is the bf16 h3 (ReLU').  dq_dgrad / dq_wgrad: device scalars 1 / (scale_dy * scale_w) and
+// right operand); mask is the bf16 h3 (ReLU'), or -- mask_is_fp8 -- its fp8 image again (ldmask in bytes): the bf16 copy of
+// h3 then need not exist.  dq_dgrad / dq_wgrad: device scalars 1 / (scale_dy * scale_w) and
 // 1 / (scale_dy * scale_x).  Same outputs, splits and slab formats as rv_linear_dgrad_wgrad.  Not in the public header.
 int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,
-                              const void* mask_bf16, long ldmask, const float* dq_dgrad, const float* dq_wgrad, long Mp, long Np,
-                              long Kp, void* dx_bf16, long lddx, float* colsum_partial, void* dw_slabs, long lddw, int splits,
-                              int slab_dtype, float* slab_unscale, void* stream) {
+                              const void* mask, long ldmask, int mask_is_fp8, const float* dq_dgrad, const float* dq_wgrad,
+                              long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial, void* dw_slabs,
+                              long lddw, int splits, int slab_dtype, float* slab_unscale, void* stream) {
+  const void* mask_bf16 = mask;
   RV_REQUIRE(dy_fp8 && w_fp8 && x_fp8 && mask_bf16 && dx_bf16 && dw_slabs && dq_dgrad && dq_wgrad, RV_ERR_NULL,
              "rv_linear_dgrad_wgrad_fp8: null operand");
   RV_REQUIRE(rv_dgrad_wgrad_fp8_fits(Mp, Np, Kp, splits), RV_ERR_SHAPE,
              "rv_linear_dgrad_wgrad_fp8: %ld x %ld x %ld / %d splits: extents must tile by 256 x 256 with an even number of 128-deep K tiles", Mp, Np, Kp, splits);
-  RV_REQUIRE(lddy % 16 == 0 && ldw % 16 == 0 && ldx % 16 == 0 && ldmask % 8 == 0, RV_ERR_SHAPE,
+  RV_REQUIRE(lddy % 16 == 0 && ldw % 16 == 0 && ldx % 16 == 0 && ldmask % (mask_is_fp8 ? 16 : 8) == 0, RV_ERR_SHAPE,
              "rv_linear_dgrad_wgrad_fp8: leading dims must be multiples of 16 bytes");
   RV_REQUIRE((((uintptr_t)dy_fp8 | (uintptr_t)w_fp8 | (uintptr_t)x_fp8 | (uintptr_t)mask_bf16) & 15) == 0, RV_ERR_SHAPE,
              "rv_linear_dgrad_wgrad_fp8: operands must be 16-byte aligned");
@@ -765,7 +767,8 @@ int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, 
   GemmArgs d{}, g{};
   d.A = (const bf16_t*)dy_fp8; d.lda = lddy / 2; d.B = (const bf16_t*)w_fp8; d.ldb = ldw / 2;
   d.k_tiles = (int)(Kp / 128); d.M_valid = (int)Mp; d.N_valid = (int)Np;
-  d.mask = (const bf16_t*)mask_bf16; d.ld_mask = ldmask; d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
+  d.mask = (const bf16_t*)mask_bf16; d.ld_mask = ldmask; d.mask_fp8 = mask_is_fp8 ? 1 : 0;
+  d.out_bf16 = (bf16_t*)dx_bf16; d.ld_bf16 = lddx; d.colsum = colsum_partial;
   d.tiles_m = (int)(Mp / BM); d.tiles_n = (int)(Np / BN); d.splits = 1; d.dq = dq_dgrad;
   g.A = (const bf16_t*)dy_fp8; g.lda = lddy / 2; g.B = (const bf16_t*)x_fp8; g.ldb = ldx / 2;
   g.k_tiles = (int)(Mp / 128 / splits); g.M_valid = (int)Kp; g.N_valid = (int)Np; g.dq = dq_wgrad;

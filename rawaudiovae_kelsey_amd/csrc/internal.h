@@ -106,7 +106,7 @@ RV_INTERNAL int rv_pair_stop_event(void* hip_event);
 // The paired fc4 backward on fp8 operands (gemm_launch.hip) and whether the extents allow it.
 RV_INTERNAL int rv_dgrad_wgrad_fp8_fits(long Mp, long Np, long Kp, int splits);
 RV_INTERNAL int rv_linear_dgrad_wgrad_fp8(const void* dy_fp8, long lddy, const void* w_fp8, long ldw, const void* x_fp8, long ldx,
-                                          const void* mask_bf16, long ldmask, const float* dq_dgrad, const float* dq_wgrad,
-                                          long Mp, long Np, long Kp, void* dx_bf16, long lddx, float* colsum_partial,
-                                          void* dw_slabs, long lddw, int splits, int slab_dtype, float* slab_unscale,
-                                          void* stream);
+                                          const void* mask, long ldmask, int mask_is_fp8, const float* dq_dgrad,
+                                          const float* dq_wgrad, long Mp, long Np, long Kp, void* dx_bf16, long lddx,
+                                          float* colsum_partial, void* dw_slabs, long lddw, int splits, int slab_dtype,
+                                          float* slab_unscale, void* stream);

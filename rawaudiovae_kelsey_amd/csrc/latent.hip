@@ -275,14 +275,14 @@ k_latent_fwd(const bf16_t* __restrict__ h1, const long ldh, const bf16_t* __rest
         o[e] = (bf16_t)lo[e];
         o[4 + e] = (bf16_t)hi[e];
       }
-      store_out16((bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
+      if (h3) store_out16((bf16x8*)(out + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8), o, wt);
       if (h3q || amax_part) {
         float q8[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           amax = fmaxf(amax, fmaxf(lo[e], hi[e]));   // post-ReLU: non-negative
-          q8[e] = lo[e] * qs;
-          q8[4 + e] = hi[e] * qs;
+          q8[e] = fp8_keep_positive(lo[e], lo[e] * qs);
+          q8[4 + e] = fp8_keep_positive(hi[e], hi[e] * qs);
         }
         if (h3q) *(unsigned long long*)(outq + walk(u) * 64 + (2 * t + (q & 1)) * 16 + (q >> 1) * 8) = pack_fp8x8(q8);
       }
@@ -878,7 +878,8 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
              "rv_latent_fwd: the fp8 output needs a scale and 8-byte aligned rows");
   // w3_bf16 == NULL: heads + reparameterisation only (z, mu | logvar, the KL partials); fc3 is then the caller's
   const bool heads_only = !w3_bf16;
-  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && mulv && z_bf16 && kl_partial && (heads_only || (bias3 && h3_bf16)), RV_ERR_NULL,
+  // (h3_bf16 may be NULL beside h3_fp8: the fp8 step whose only reader of h3 is the fp8 fc4 backward)
+  RV_REQUIRE(h_bf16 && wh_bf16 && bias_heads && mulv && z_bf16 && kl_partial && (heads_only || (bias3 && (h3_bf16 || h3_fp8))), RV_ERR_NULL,
              "rv_latent_fwd: null pointer");
   RV_REQUIRE(!heads_only || (!h3_fp8 && !amax_part), RV_ERR_UNSUPPORTED, "rv_latent_fwd: the fp8 outputs belong to fc3");
   RV_REQUIRE(eps_in || eps_out, RV_ERR_NULL, "rv_latent_fwd: need eps_in or eps_out");

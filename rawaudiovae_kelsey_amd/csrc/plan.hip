@@ -116,6 +116,7 @@ struct rv_plan {
   bool heads_half = false;     // the streaming heads' backward writes fp16 dWh slabs (heads_mode_apply)
   bool fwd_for_fp8_w1 = false; // set by rv_plan_step_ddp around its forward call (fp8_w1)
   bool last_fwd_f8_w1 = false; // what the most recent forward phase decided (fp8_w1): the backward follows IT, not its own phase mask
+  bool last_fwd_no_h3 = false; // ... and whether it left the bf16 h3 unwritten (fc4's dgrad then masks with the fp8 image)
   int ddp_seq = 0;             // data-parallel steps enqueued with device-side flags (their sequence number)
   int ddp_signal = 1;          // RV_OPT_DDP_SIGNAL: 1 device-side flags between the two streams (default), 0 HIP events
   long ddp_wait_ms = 30000;    // RV_OPT_DDP_WAIT_MS: bound of a flag wait whose setter sits behind a collective (peers)
@@ -612,9 +613,12 @@ static int fc4_backward(rv_plan* p, void* stream) {
   const long Bp = p->Bp, Sp = p->Sp, Hp = p->Hp;
   if (fp8_bwd(p)) {
     float* f8 = (float*)p->ws("fp8_state");
-    return rv_linear_dgrad_wgrad_fp8(p->ws("dP4q"), Sp, p->ws("W4q"), Hp, p->ws("h3q"), Hp, p->ws("h3"), Hp, f8 + 10, f8 + 11, Bp, Hp,
-                                     Sp, p->ws("dP3"), Hp, (float*)p->ws("db3p"), p->ws("dW4"), Hp, p->s_w4, p->slab_dtype,
-                                     p->us_w4, stream);
+    // the ReLU mask: the bf16 h3, or -- where the forward of this step did not write it (last_fwd_no_h3) -- the fp8 image
+    // of h3 that is this launch's weight-gradient operand anyway
+    const bool m8 = p->last_fwd_no_h3;
+    return rv_linear_dgrad_wgrad_fp8(p->ws("dP4q"), Sp, p->ws("W4q"), Hp, p->ws("h3q"), Hp, m8 ? p->ws("h3q") : p->ws("h3"), Hp,
+                                     m8 ? 1 : 0, f8 + 10, f8 + 11, Bp, Hp, Sp, p->ws("dP3"), Hp, (float*)p->ws("db3p"), p->ws("dW4"),
+                                     Hp, p->s_w4, p->slab_dtype, p->us_w4, stream);
   }
   return rv_linear_dgrad_wgrad(p->ws("dP4"), Sp, p->ws("W4b"), Hp, p->ws("h3"), Hp, Bp, Hp, Sp, p->ws("dP3"), Hp,
                                (float*)p->ws("db3p"), p->ws("dW4"), Hp, p->s_w4, p->slab_dtype, p->us_w4, stream);
@@ -712,6 +716,10 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     const bool f8_bwd = fp8_bwd_possible(p);
     const bool f8_w1 = fp8_w1(p, full_local);     // then nothing reads the frames' bf16 copy: it is not written
     p->last_fwd_f8_w1 = f8_w1;
+    // ... and nothing but fc4's dgrad reads the bf16 h3 then (its ReLU mask): the fp8 image serves (round 6: 16 MB less
+    // written by the latent forward, 8 MB less read by the pair)
+    const bool no_h3 = f8_w1 && f8_bwd && rv_latent_rowlocal(Bp, Hp, Lp);
+    p->last_fwd_no_h3 = no_h3;
     void* xb_out = f8_w1 ? nullptr : xb;
     const int n_amax2 = f8_w1 ? p->n_amax_dp1 : 0;
     int n_amax = 0;
@@ -760,7 +768,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
     {
       if (latent_fused)
         RV_K(2, rv_latent_fwd_ex(h1, Hp, p->ws("Whb"), Hp, (float*)p->ws("bhp"), p->ws("W3b"), Lp, (float*)p->ws("b3p"), Bp, Hp, Lp,
-                                B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, h3, Hp,
+                                B, L, eps, eps_buf, seed, p->b.step_counter, mulv, z, kl_part, no_h3 ? nullptr : h3, Hp,
                                 p->fp8 ? p->ws("h3q") : nullptr, Hp, p->fp8 ? f8 + 3 : nullptr,
                                 p->fp8 ? (float*)p->ws("h3_amax") : nullptr, stream));
       else
