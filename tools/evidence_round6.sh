@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-git rev-parse --short HEAD > $R/.evidence_commit 2>/dev/null || true
+# (.evidence_commit is written by the caller before the snapshot travels: the box has no .git)
 python -m pytest tests -m gpu -q -s > $O/r06_gpu_tests_full.txt 2>&1; grep -v "amdgpu.ids" $O/r06_gpu_tests_full.txt | grep "DDP_BF16\|passed\|failed" > $O/r06_gpu_tests.txt; cat $O/r06_gpu_tests.txt
 python bench.py > $O/r06_bench.json 2> $O/r06_bench.err; tail -c 400 $O/r06_bench.json; echo
 bash tools/prof_step.sh r06 > /dev/null 2>&1; head -14 $O/r06_kernel_summary.txt
@@ -15,6 +15,8 @@ bash tools/r06_prof_shape.sh r06_refini 1024 2048 256 4096 > $O/r06_refini_timel
 bash tools/r06_prof_shape.sh r06_default_ini 1024 2048 256 131072 > $O/r06_default_ini_timeline.txt 2>&1; head -16 $O/r06_default_ini_timeline.txt
 bash tools/pmc_round.sh r06 > /dev/null 2>&1; tail -12 $O/r06_traffic.txt
 bash tools/pmc_sq_step.sh r06 > $O/r06_pmc_sq.log 2>&1; head -14 $O/r06_pmc_sq_summary.txt
+bash tools/pmc_sq_shape.sh r06_refini 1024 2048 256 4096 > /dev/null 2>&1; head -16 $O/r06_refini_pmc_sq.txt
+bash tools/pmc_sq_shape.sh r06_default_ini 1024 2048 256 131072 > /dev/null 2>&1; head -16 $O/r06_default_ini_pmc_sq.txt
 bash tools/r06_sweep.sh > $O/r06_batch_sweep_table.txt 2>&1; cp $O/r06/batch_sweep.jsonl $O/r06_batch_sweep.jsonl; cat $O/r06_batch_sweep_table.txt
 python tools/big_batch_gemms.py 131072 2>&1 | grep -v amdgpu > $O/r06_big_batch_gemms.txt; cat $O/r06_big_batch_gemms.txt
 python tools/latent_k_sweep.py 2>&1 | grep -v amdgpu > $O/r06_latent_k_sweep.txt; cat $O/r06_latent_k_sweep.txt
