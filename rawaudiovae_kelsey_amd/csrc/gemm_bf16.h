@@ -359,22 +359,28 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // FP8: e4m3 operands (pointers typed bf16, leading dims in 2-byte units): a K tile is 128 deep, the LDS images hold the
 // same 16 KiB per half (K-major: 128 rows x 128 k-bytes; MN-major: 128 k-rows x 128 row-bytes, StageOffsets F8MN),
 // and a phase's 16 MFMAs of 16x16x32 become 8 of 16x16x128 -- the same matrix-pipe time for twice the contraction.
-template <bool A_KMAJ, bool B_KMAJ, bool FP8, typename Hook>
+// `b_rows` (anything but NoGather: K-major B only): element offset of row r (0..127) of B's first half tile from `Bg`,
+// `b_half_gather` the offset of the second half's row r from the first's -- the head-interleaved gather of EPI_REPARAM.
+struct NoGather {};
+template <bool A_KMAJ, bool B_KMAJ, bool FP8, typename Hook, typename BRows = NoGather>
 __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                   const long lda, const long ldb, const int nk, lds_char* smem,
-                                                  const int wave, const int lane, f32x4 (&acc)[8][4], Hook tail_hook) {
+                                                  const int wave, const int lane, f32x4 (&acc)[8][4], Hook tail_hook,
+                                                  BRows b_rows = BRows{}, const long b_half_gather = 0) {
+  constexpr bool GATHER_B = !std::is_same<BRows, NoGather>::value;
   constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k half tile
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
   const int wr = wave >> 2, wc = wave & 3;
   StageOffsets<128, A_KMAJ, 8, FP8 && !A_KMAJ> sa;
   StageOffsets<128, B_KMAJ, 8, FP8 && !B_KMAJ> sb;
   sa.init(lda, wave, lane);
-  sb.init(ldb, wave, lane);
+  if constexpr (GATHER_B) sb.init_rows(b_rows, wave, lane);
+  else sb.init(ldb, wave, lane);
   const int unit_scale = 0x7F7F7F7F;     // fp8: E8M0 block scales of 1.0 for both operands (held in one VGPR)
   constexpr int KROWS = FP8 ? 128 : 64;  // k-rows of an MN-major tile
   constexpr int MNH = FP8 ? 64 : 128;    // 128 operand rows of an MN-major image, in 2-byte units
   const long a_step = A_KMAJ ? 64 : KROWS * lda, b_step = B_KMAJ ? 64 : KROWS * ldb;
-  const long a_half = A_KMAJ ? 128 * lda : MNH, b_half = B_KMAJ ? 128 * ldb : MNH;
+  const long a_half = A_KMAJ ? 128 * lda : MNH, b_half = GATHER_B ? b_half_gather : (B_KMAJ ? 128 * ldb : MNH);
   auto stage_a = [&](int h, int t) {
     if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, smem + (t & 1) * BUF + h * HALF, wave);
   };
@@ -563,7 +569,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // the (row, 8-column) items  row = roww + 16 * mi,  col = colw + 32 * t.
   static_assert(NI % 2 == 0, "epilogue pairs column fragments");
   constexpr int NP = NI / 2;                       // column-block pairs per wave tile
-  constexpr int CM = NP >= 2 ? 2 : (MI >= 4 ? 4 : MI);  // fragment rows per chunk (bounds live registers)
+  // (the reparameterisation backward on the ping-pong tile keeps 128 accumulators and 32 column sums live and reads 24 operand
+  // registers per item: one fragment row per chunk there, or the epilogue spills)
+  constexpr int CM = (EPI == EPI_REPARAM_BWD && NSTAGE == 8) ? 1 : NP >= 2 ? 2 : (MI >= 4 ? 4 : MI);  // fragment rows per chunk (bounds live registers)
   static_assert(MI % CM == 0, "chunking must divide the wave tile");
   constexpr int CH = CM * NP;                      // (row, 8-column) items per chunk
   const int eq = lane >> 4, ej = lane & 15;
@@ -638,7 +646,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
 #pragma unroll
     for (int it = 0; it < RF_N; ++it) {
       const long b_ = m0 + wm * WTM + (it / (NI / 2)) * 16 + (lane & 15);
-      const long l_ = (long)tile_n * 64 + wn * (WTN / 2) + (it % (NI / 2)) * 16 + 4 * (lane >> 4);
+      const long l_ = (long)tile_n * (BN / 2) + wn * (WTN / 2) + (it % (NI / 2)) * 16 + 4 * (lane >> 4);
       rb_vec[it] = al && b_ < p.M_valid && l_ + 4 <= L_;
       rb_e[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (rb_vec[it]) rb_e[it][0] = *(const f32x4*)(p.eps_in + b_ * L_ + l_);
@@ -695,7 +703,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       __builtin_amdgcn_global_load_lds((glb_cptr)(mk_g + (long)i * mk_pitch8),
                                        (__attribute__((address_space(3))) void*)(base + (i - i0) * 1024), 16, 0, 0);
   };
-  if constexpr (PINGPONG) {
+  if constexpr (PINGPONG && EPI == EPI_REPARAM) {
+    // B's rows gathered head-interleaved, as on the ring loop below: row r of the 256-row tile is head (r >> 4) & 1, latent
+    // tile_n * 128 + (r >> 5) * 16 + (r & 15) -- the second half tile (rows 128..255) starts 64 latents after the first
+    static_assert(B_KMAJ && !FP8, "reparameterisation epilogue: bf16 K-major weights");
+    mainloop_pingpong<A_KMAJ, B_KMAJ, FP8>(Ag, p.B + k0, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc, [&]() {},
+        [&](int r) { return (((r >> 4) & 1) * p.lat_lp + (long)tile_n * (BN / 2) + (r >> 5) * 16 + (r & 15)) * p.ldb; }, 64 * p.ldb);
+  } else if constexpr (PINGPONG) {
     mainloop_pingpong<A_KMAJ, B_KMAJ, FP8>(Ag, Bg, p.lda, p.ldb, p.k_tiles, smem, wave, lane, acc, [&]() {
       if constexpr (MASK_LDS) {
         if (mask_lds) mask_dma(0, 2 * CM, mk_lds0);
@@ -721,9 +735,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   if (!gathered) sa.init(p.lda, wave, lane);
   const bf16_t* Bgr = Bg;
   if constexpr (EPI == EPI_REPARAM) {
-    static_assert(B_KMAJ && BN == 128 && WTN % 32 == 0, "reparameterisation epilogue: 128-column tiles (64 latents x 2 heads), wave tiles of whole (mu, logvar) fragment pairs");
+    static_assert(B_KMAJ && WTN % 32 == 0, "reparameterisation epilogue: tiles of BN / 2 latents x 2 heads, wave tiles of whole (mu, logvar) fragment pairs");
     Bgr = p.B + k0;
-    sb.init_rows([&](int r) { return (((r >> 4) & 1) * p.lat_lp + (long)tile_n * 64 + (r >> 5) * 16 + (r & 15)) * p.ldb; }, wave, lane);
+    sb.init_rows([&](int r) { return (((r >> 4) & 1) * p.lat_lp + (long)tile_n * (BN / 2) + (r >> 5) * 16 + (r & 15)) * p.ldb; }, wave, lane);
   } else {
     sb.init(p.ldb, wave, lane);
   }
@@ -915,10 +929,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     const int q = lane >> 4, j = lane & 15;
     const long Lp_ = p.lat_lp, L2p_ = 2 * Lp_, L_ = p.lat_l;
     const uint64_t step_ = p.step_counter ? (uint64_t)*p.step_counter : 0;
+    const bool eps_al = (L_ & 3) == 0 && (reinterpret_cast<uintptr_t>(p.eps_in ? (const void*)p.eps_in : (const void*)p.eps_out) & 15) == 0;
     float kl = 0.f;
 #pragma unroll
     for (int pr = 0; pr < NI / 2; ++pr) {
-      const long l = (long)tile_n * 64 + wn * (WTN / 2) + pr * 16 + 4 * q;
+      const long l = (long)tile_n * (BN / 2) + wn * (WTN / 2) + pr * 16 + 4 * q;
       const f32x4 bm = *(const f32x4*)(p.bias + l), bv = *(const f32x4*)(p.bias + Lp_ + l);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -927,16 +942,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
         float mua[4] = {0.f, 0.f, 0.f, 0.f}, lva[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
         if (b < p.M_valid && l < L_) {
           float ev[4];
-          if (!p.eps_in) normal4_fast(p.seed, (uint64_t)(b * (Lp_ >> 2) + (l >> 2)), step_, ev);
+          // (eps as one 16-byte access per item where the exact latent width allows it; the 64-row tiles fetched theirs before
+          // the main loop)
+          const bool v4 = eps_al && l + 4 <= L_;
+          bool have = false;
+          if (!p.eps_in) {
+            normal4_fast(p.seed, (uint64_t)(b * (Lp_ >> 2) + (l >> 2)), step_, ev);
+            if (v4) { *(f32x4*)(p.eps_out + b * L_ + l) = f32x4{ev[0], ev[1], ev[2], ev[3]}; have = true; }
+          } else if (rb_vec[it]) {
+#pragma unroll
+            for (int e_ = 0; e_ < 4; ++e_) ev[e_] = rb_e[it][0][e_];
+            have = true;
+          } else if (v4) {
+            const f32x4 t_ = *(const f32x4*)(p.eps_in + b * L_ + l);
+#pragma unroll
+            for (int e_ = 0; e_ < 4; ++e_) ev[e_] = t_[e_];
+            have = true;
+          }
 #pragma unroll
           for (int e_ = 0; e_ < 4; ++e_) {
             if (l + e_ < L_) {
               float e;
               if (p.eps_in) {
-                e = rb_vec[it] ? rb_e[it][0][e_] : p.eps_in[b * L_ + l + e_];
+                e = have ? ev[e_] : p.eps_in[b * L_ + l + e_];
               } else {
                 e = ev[e_];
-                p.eps_out[b * L_ + l + e_] = e;
+                if (!have) p.eps_out[b * L_ + l + e_] = e;
               }
               mua[e_] = acc[mi][2 * pr][e_] + bm[e_];
               lva[e_] = acc[mi][2 * pr + 1][e_] + bv[e_];
@@ -954,9 +985,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
     }
     float* red = (float*)smem_generic;
     const float s_ = block_sum<NW>(kl, red);
-    // one KL partial per 1024 elements of the padded [Mp, lat_lp] grid is what the loss reduction sums: this block's BM x 64
-    // elements own BM / 16 slots -- the sum goes into the first, zeros into the others
-    if (tid < BM / 16) p.kl_partial[(BM / 16) * (tile_m * tiles_n + tile_n) + tid] = tid == 0 ? s_ : 0.f;
+    // one KL partial per 1024 elements of the padded [Mp, lat_lp] grid is what the loss reduction sums: this block's
+    // BM x BN / 2 elements own BM * BN / 2048 slots -- the sum goes into the first, zeros into the others
+    constexpr int KL_SLOTS = BM * BN / 2048;
+    if (tid < KL_SLOTS) p.kl_partial[KL_SLOTS * (tile_m * tiles_n + tile_n) + tid] = tid == 0 ? s_ : 0.f;
     return;
   }
 

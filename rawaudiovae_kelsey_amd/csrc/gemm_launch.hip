@@ -656,7 +656,12 @@ int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, i
     const long t_d = (Mp / 256) * (Np / 256), t_w = (Kp / 256) * (Np / 256);
     // wgrad splits: even out the K work per block (dgrad blocks loop over Kp, wgrad blocks over Mp/sp)
     while (2 * sp <= 16 && (Mp / 64) % (2 * sp) == 0 && Mp / (2 * sp) >= Kp && Mp / (2 * sp) >= 128) sp *= 2;
-    if (g_force_tile == 5 || (t_d + t_w * sp >= 192 && t_d + t_w * sp <= 320)) { pr = 1; bm = 256; }
+    // one launch while its blocks fill one round of the chip's 256 CUs, or two to four rounds to at least three quarters (B = 8192:
+    // fc4's backward 104 -> 68 us, the heads' 65 -> 38 at L = 256; B = 16384: the heads' 127 -> 81; beyond four rounds the big-tile
+    // launches of choose_tile are as fast or faster -- profiles/r06_batch_sweep.jsonl)
+    const long tot = t_d + t_w * sp, rounds = (tot + 255) / 256;
+    const bool whole = rounds >= 2 && rounds <= 4 && 4 * tot >= 3 * 256 * rounds;
+    if (g_force_tile == 5 || whole || (tot >= 192 && tot <= 320)) { pr = 1; bm = 256; }
   }
   if (!pr) {
     int bn;

@@ -779,10 +779,23 @@ __global__ void __launch_bounds__(512) k_heads_reparam_gemm_big(const GemmArgs p
   gemm_body<256, 128, 4, 2, true, true, EPI_REPARAM, HGB_STAGES>(p, blockIdx.x, smem_dyn);
 }
 
+// From a padded latent width of 128 on (the heads' N = 2 Lp >= 256) large batches run on the 256 x 256 ping-pong loop: a tile then
+// covers 128 latents x both heads, the gathered B rows go through the loop's own staging (mainloop_pingpong's b_rows).  At
+// default.ini's shape the 256 x 128 ring above ran this GEMM at 0.25 of the MFMA peak (1.7 us per K tile of a tile, 444 us);
+// the ping-pong loop's 1.3 us per K tile covers twice the columns.
+constexpr int PP_LDS = 2 * 4 * 128 * 128;                // 128 KiB: two buffers of {A0, A1, B0, B1} half tiles
+__global__ void __launch_bounds__(512) k_heads_reparam_gemm_pp(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  gemm_body<256, 256, 2, 4, true, true, EPI_REPARAM, 8>(p, blockIdx.x, smem_dyn);
+}
+
 constexpr int DZ_STAGES = 5, DW3_STAGES = 2;
 constexpr int DZ_LDS = DZ_STAGES * (64 + 64) * 128;     // 80 KiB (the dW3 blocks use 64 of them): two workgroups per CU
 
-template <bool BIG>
+// FORM 0: 64 x 64 dz tiles, 128 x 128 dW3 tiles (two workgroups per CU).  1: large batches -- 256 x 128 dz tiles.  2: large
+// batches at a padded latent width of 256 -- dz on ONE 256 x 256 ping-pong tile per 256 rows (dP3 read once), dW3 on 256 x 256
+// ping-pong tiles as well (rv_latent_bwd_pp: the plan gives it enough K splits to fill the chip once).
+template <int FORM>
 __global__ void __launch_bounds__(512)
 k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, const int n_w3, const long B, const long L,
                   const long S, const float kl_beta, const float* __restrict__ mse_partial, const int n_mse,
@@ -795,12 +808,14 @@ k_dz_reparam_gemm(const GemmArgs dz, const GemmArgs w3grad, const int n_dz, cons
   // B = 131072, L = 64)
   if (bid < n_w3) {
     // (a padded latent width of 64 leaves no room for 128-column tiles: 128 x 64 there, three ring slots = 72 KiB)
-    if (w3grad.N_valid < 128) gemm_body<128, 64, 4, 2, false, false, EPI_F32, 3>(w3grad, bid, smem_dyn);
+    if constexpr (FORM == 2) gemm_body<256, 256, 2, 4, false, false, EPI_F32, 8>(w3grad, bid, smem_dyn);
+    else if (w3grad.N_valid < 128) gemm_body<128, 64, 4, 2, false, false, EPI_F32, 3>(w3grad, bid, smem_dyn);
     else gemm_body<128, 128, 2, 4, false, false, EPI_F32, DW3_STAGES>(w3grad, bid, smem_dyn);
     return;
   }
   if (bid < n_w3 + n_dz) {
-    if constexpr (BIG) gemm_body<256, 128, 4, 2, true, false, EPI_REPARAM_BWD, HGB_STAGES>(dz, bid - n_w3, smem_dyn);
+    if constexpr (FORM == 2) gemm_body<256, 256, 2, 4, true, false, EPI_REPARAM_BWD, 8>(dz, bid - n_w3, smem_dyn);
+    else if constexpr (FORM == 1) gemm_body<256, 128, 4, 2, true, false, EPI_REPARAM_BWD, HGB_STAGES>(dz, bid - n_w3, smem_dyn);
     else gemm_body<64, 64, 4, 2, true, false, EPI_REPARAM_BWD, DZ_STAGES>(dz, bid - n_w3, smem_dyn);
     return;
   }
@@ -834,7 +849,8 @@ int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const
   a.A = (const bf16_t*)h; a.lda = ldh; a.B = (const bf16_t*)wh; a.ldb = ldwh;
   a.k_tiles = (int)(Hp / 64); a.M_valid = (int)B; a.N_valid = (int)(2 * Lp);
   const bool big = (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
-  a.tiles_m = (int)(Bp / (big ? 256 : 64)); a.tiles_n = (int)(Lp / 64); a.splits = 1;
+  const bool pp = big && Lp >= 128;   // (Hp / 64 is even: the GEMM forms require Hp % 128 == 0)
+  a.tiles_m = (int)(Bp / (big ? 256 : 64)); a.tiles_n = (int)(Lp / (pp ? 128 : 64)); a.splits = 1;
   a.bias = bias_heads; a.lat_lp = Lp; a.lat_l = L; a.eps_in = eps_in; a.eps_out = eps_out; a.seed = seed;
   a.step_counter = step_counter; a.mulv = mulv; a.z = (bf16_t*)z; a.kl_partial = kl_partial;
   a.wt = rv_store_wt;
@@ -842,9 +858,11 @@ int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, HG_LDS);
     (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
+    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm_pp, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     attr_done = true;
   }
-  if (big) hipLaunchKernelGGL(k_heads_reparam_gemm_big, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HGB_LDS, st, a);
+  if (pp) hipLaunchKernelGGL(k_heads_reparam_gemm_pp, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), PP_LDS, st, a);
+  else if (big) hipLaunchKernelGGL(k_heads_reparam_gemm_big, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HGB_LDS, st, a);
   else hipLaunchKernelGGL(k_heads_reparam_gemm, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HG_LDS, st, a);
   RV_CHECK_LAUNCH();
   return RV_OK;
@@ -858,6 +876,12 @@ extern "C" {
 // width of 64 while the batch is small enough that filling the chip is the issue; the GEMM forms above that width and for
 // large batches.  One predicate for both directions and for the plan (internal.h).
 int rv_latent_rowlocal(long Bp, long Hp, long Lp) { return Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && Bp <= 8192; }
+
+// The latent backward's ping-pong form (k_dz_reparam_gemm<2>): a large batch at a padded latent width of 256.  Its dW3 blocks are
+// 256 x 256 tiles over Hp / 256 row tiles, so the plan splits K until they fill the chip once (even K tiles per block).
+int rv_latent_bwd_pp(long Bp, long Hp, long Lp) {
+  return Lp == 256 && Hp % 256 == 0 && (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
+}
 
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
@@ -945,15 +969,18 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     g.wt = rv_store_wt;
     if (!rowlocal) {   // (the GEMM form's dW3 blocks run on 128 x 128 tiles, 128 x 64 at a padded latent width of 64)
       g.tiles_m = (int)(Hp / 128); g.tiles_n = Lp >= 128 ? (int)(Lp / 128) : 1;
+      // (the ping-pong loop walks K tiles in pairs: a caller's odd split keeps the 256 x 128 form for the whole launch)
+      if (rv_latent_bwd_pp(Bp, Hp, Lp) && g.k_tiles % 2 == 0) { g.tiles_m = (int)(Hp / 256); g.tiles_n = 1; }
     }
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
   if (!rowlocal) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
     const bool big = Lp >= 128 && (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
+    const bool pp = rv_latent_bwd_pp(Bp, Hp, Lp) && (!z_bf16 || g.k_tiles % 2 == 0);
     GemmArgs d{};
     d.A = (const bf16_t*)dp3_bf16; d.lda = lddp; d.B = (const bf16_t*)w3_bf16; d.ldb = ldw3;
     d.k_tiles = (int)(Hp / 64); d.M_valid = (int)B; d.N_valid = (int)Lp;
-    d.tiles_m = (int)(Bp / (big ? 256 : 64)); d.tiles_n = (int)(Lp / (big ? 128 : 64)); d.splits = 1;
+    d.tiles_m = (int)(Bp / (big ? 256 : 64)); d.tiles_n = pp ? 1 : (int)(Lp / (big ? 128 : 64)); d.splits = 1;
     d.lat_lp = Lp; d.lat_l = L; d.mulv = const_cast<float*>(mulv); d.eps = eps; d.kl_beta = kl_beta;
     d.inv_nk = 1.0f / ((float)B * (float)L); d.dmu_ext = dmu_ext; d.dlv_ext = dlv_ext;
     d.dmulv = (bf16_t*)dmulv_bf16; d.dbh_partial = dbh_partial;
@@ -961,15 +988,19 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     const int n_dz = d.tiles_m * d.tiles_n;
     static bool attr_gemm = false;
     if (!attr_gemm) {
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
+      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
       attr_gemm = true;
     }
-    if (big)
-      hipLaunchKernelGGL(k_dz_reparam_gemm<true>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), HGB_LDS, (hipStream_t)stream, d, g,
+    if (pp)
+      hipLaunchKernelGGL(k_dz_reparam_gemm<2>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), PP_LDS, (hipStream_t)stream, d, g,
+                         n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
+    else if (big)
+      hipLaunchKernelGGL(k_dz_reparam_gemm<1>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), HGB_LDS, (hipStream_t)stream, d, g,
                          n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
     else
-      hipLaunchKernelGGL(k_dz_reparam_gemm<false>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), DZ_LDS, (hipStream_t)stream, d, g,
+      hipLaunchKernelGGL(k_dz_reparam_gemm<0>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), DZ_LDS, (hipStream_t)stream, d, g,
                          n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
     RV_CHECK_LAUNCH();
     return RV_OK;

@@ -231,6 +231,12 @@ int rv_plan_create(rv_plan** out, long B, long S, long H, long L) {
     const long tiles = (Hp / 128) * (Lp >= 128 ? Lp / 128 : 1), kt = Bp / 64;
     int s = 1;
     while (tiles * s < 256 && 2 * s <= 16 && kt % (2 * s) == 0 && kt / (2 * s) >= 8) s *= 2;
+    if (rv_latent_bwd_pp(Bp, Hp, Lp)) {   // 256 x 256 ping-pong tiles: Hp / 256 of them per split, an even number of K tiles each
+      s = 1;
+      // (half a round of them: 16 splits measured 394 us for the launch at default.ini's shape, 8 and 32: 464, 435 -- and every
+      // split is another 2 MB slab for Adam to read)
+      while ((Hp / 256) * s < 128 && 2 * s <= 64 && kt % (4 * s) == 0 && kt / (2 * s) >= 16) s *= 2;
+    }
     p->s_w3 = s;
   }
   {
@@ -573,10 +579,14 @@ int rv_plan_refresh_shadows(rv_plan* p, void* stream) {
   return RV_OK;
 }
 
-// Launches issued inside a plan call write their epilogue outputs through (common.h store_wt16): scope guard
+// Launches issued inside a plan call write their epilogue outputs through (common.h store_wt16) while the step's activations
+// are small enough for the next launch to find them in the L2s / MALL anyway: up to a padded batch of 8192.  Beyond that the
+// consumer reads from HBM either way, and write-back lets the L2 merge the epilogues' 64-byte row segments into whole lines
+// before they leave (same boxes, write-through against write-back per step: 178.8 / 185.8 us at B = 4096, 344 / 353 at 8192,
+// 588 / 580 at 16384, 1397 / 1340 at 32768, 4757 / 4663 at 131072; L = 256 alike).  Scope guard:
 struct WtScope {
   int prev;
-  WtScope() : prev(rv::rv_store_wt) { rv::rv_store_wt = 1; }
+  explicit WtScope(const rv_plan* p) : prev(rv::rv_store_wt) { rv::rv_store_wt = p->Bp <= 8192; }
   ~WtScope() { rv::rv_store_wt = prev; }
 };
 
@@ -693,7 +703,7 @@ int rv_plan_step(rv_plan* p, int phases, const float* x, const float* eps, float
       RV_HIP(hipStreamWaitEvent((hipStream_t)stream, p->ev_flush, 0));
     }
   }
-  WtScope wt_scope;
+  WtScope wt_scope(p);
   const long B = p->B, S = p->S, L = p->L, Bp = p->Bp, Sp = p->Sp, Hp = p->Hp, Lp = p->Lp, L2p = p->L2p;
   void* xb = p->ws("xb"); void* h1 = p->ws("h1"); void* z = p->ws("z"); void* h3 = p->ws("h3");
   void* dP4 = p->ws("dP4"); void* dP3 = p->ws("dP3"); void* dmulv = p->ws("dmulv"); void* dP1 = p->ws("dP1");
@@ -1020,7 +1030,7 @@ int rv_plan_ddp_flush(rv_plan* p, void* stream) {
   if (!p->tail_pending) return RV_OK;
   RV_REQUIRE(!stream || stream == p->tail_stream, RV_ERR_STATE,
              "rv_plan_ddp_flush: the deferred half of a step belongs on the stream that step was enqueued on (pass it, or NULL)");
-  WtScope wt_scope;
+  WtScope wt_scope(p);
   return ddp_finish_tail(p);
 }
 
@@ -1029,7 +1039,7 @@ int rv_plan_step_ddp(rv_plan* p, const float* x, const float* eps, float* recon_
   RV_REQUIRE(p && p->bound, RV_ERR_STATE, "rv_plan_step_ddp: plan not bound");
   RV_REQUIRE(p->allreduce && p->comm, RV_ERR_STATE, "rv_plan_step_ddp: no communicator attached (rv_plan_attach_comm)");
   RV_REQUIRE(p->b.grad, RV_ERR_STATE, "rv_plan_step_ddp: needs a grad arena (the all-reduce payload)");
-  WtScope wt_scope;
+  WtScope wt_scope(p);
   RV_REQUIRE(stream, RV_ERR_NULL, "rv_plan_step_ddp: needs a non-default stream");
   if (p->tail_pending) {
     // the previous step's deferred half: this step's cast first (it reads x and writes the bf16 frames, nothing else --
