@@ -366,8 +366,15 @@ template <bool A_KMAJ, bool B_KMAJ, bool FP8, typename Hook, typename BRows = No
 __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                   const long lda, const long ldb, const int nk, lds_char* smem,
                                                   const int wave, const int lane, f32x4 (&acc)[8][4], Hook tail_hook,
-                                                  BRows b_rows = BRows{}, const long b_half_gather = 0) {
+                                                  BRows b_rows = BRows{}, const long b_half_gather = 0,
+                                                  const bf16_t* __restrict__ Ag_next = nullptr,
+                                                  const bf16_t* __restrict__ Bg_next = nullptr, const bool resumed = false) {
+  // Tile lists (gemm_pp_persist_kernel): `Ag_next` / `Bg_next` are the operand origins of the workgroup's NEXT output tile.
+  // The loop then keeps staging across the tile boundary -- K tile t >= nk is K tile t - nk of the next tile (nk is even, so
+  // the buffer parity carries over) -- and ends in exactly the state its own prologue produces: K tile 0 landed and
+  // published, B-half 0 of K tile 1 in flight.  `resumed`: that state was left by the previous tile's loop, skip the prologue.
   constexpr bool GATHER_B = !std::is_same<BRows, NoGather>::value;
+  const bool has_next = Ag_next != nullptr;
   constexpr int HALF = 128 * 128;        // bytes of one 128-row x 64-k half tile
   constexpr int BUF = 4 * HALF;          // A0 A1 B0 B1
   const int wr = wave >> 2, wc = wave & 3;
@@ -383,9 +390,11 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
   const long a_half = A_KMAJ ? 128 * lda : MNH, b_half = GATHER_B ? b_half_gather : (B_KMAJ ? 128 * ldb : MNH);
   auto stage_a = [&](int h, int t) {
     if (t < nk) sa.stage(Ag + h * a_half + (long)t * a_step, smem + (t & 1) * BUF + h * HALF, wave);
+    else if (has_next) sa.stage(Ag_next + h * a_half + (long)(t - nk) * a_step, smem + (t & 1) * BUF + h * HALF, wave);
   };
   auto stage_b = [&](int h, int t) {
     if (t < nk) sb.stage(Bg + h * b_half + (long)t * b_step, smem + (t & 1) * BUF + (2 + h) * HALF, wave);
+    else if (has_next) sb.stage(Bg_next + h * b_half + (long)(t - nk) * b_step, smem + (t & 1) * BUF + (2 + h) * HALF, wave);
   };
   // fragment registers: bf16 -- [.][kk] 4-dword fragments; fp8 -- the 8 dwords of a fragment's two k halves live in ONE
   // tuple (elements [.][0] and [.][1] of these arrays are then the low and high half of that tuple's storage)
@@ -467,7 +476,7 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
     rd_a(cur, 1);
     stage_a(1, kt + 1);
     if constexpr (EARLY_B) {
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (kt + 1 < nk || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     mma(I1{}, I1{}, b1);
     // phase 3: (B(n0) of tile kt+1;)  stage B-half 0 of tile kt+2; all of tile kt+1 must have landed
@@ -475,17 +484,21 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
       if (kt + 1 < nk) rd_b(bn, nxt, 0);
     }
     stage_b(0, kt + 2);
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (kt + 2 < nk || has_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mma(I1{}, I0{}, bq);
   };
 
   // prologue: tile 0 complete, B-half 0 of tile 1 in flight
-  stage_a(0, 0); stage_a(1, 0); stage_b(0, 0); stage_b(1, 0);
-  stage_b(0, 1);
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!resumed) {
+    stage_a(0, 0); stage_a(1, 0); stage_b(0, 0); stage_b(1, 0);
+    stage_b(0, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // (resumed: the previous tile's last phase waited for this K tile and ran two barriers behind that wait; its B(n0) fragments
+  // are read here rather than in that phase -- the registers do not outlive the call)
   if constexpr (EARLY_B) rd_b(b0, smem, 0);
   if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
   __builtin_amdgcn_sched_barrier(0);
@@ -517,7 +530,8 @@ __device__ __forceinline__ void mainloop_pingpong(const bf16_t* __restrict__ Ag,
 // The barrier publishes every wave's share of tile kt+1 and orders the refill after all
 // reads of the vacated slot (each wave's fragment reads have returned before it arrives).
 template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, int NSTAGE, bool FP8 = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char* smem_generic, const int next_bid = -1,
+                                          const bool resumed = false) {
   static_assert(!FP8 || NSTAGE == 8 || (A_KMAJ && B_KMAJ), "fp8 operands: K-major (forward) GEMMs on the ring loop, any layout on the ping-pong loop");
   lds_char* smem = (lds_char*)smem_generic;
   constexpr int NW = WGM * WGN;
@@ -540,28 +554,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   // shares through its own L2 instead of every XCD streaming every panel.  Bijective for any
   // grid size; a different placement only changes speed.
   const int tiles_n = p.tiles_n, nt = p.tiles_n * p.tiles_m, nwg = nt * p.splits;
-  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  const int item = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int split = item / nt, tid_lin = item - split * nt;
   // within a split, tiles are enumerated in 4x4 super-tiles where the grid allows it, so that an XCD's
   // contiguous run of items is a near-square patch: fewer distinct A row panels + B column panels stream
   // through its private L2 than with row-major order (a 2 x 16 strip needs 1 + 4 MB at C2, a 4 x 8 patch 2 + 2)
-  int tile_m, tile_n;
-  if (((tiles_n | p.tiles_m) & 3) == 0) {
-    const int sn = tiles_n >> 2, s4 = tid_lin >> 4, w4 = tid_lin & 15;
-    tile_m = (s4 / sn) * 4 + (w4 >> 2);
-    tile_n = (s4 % sn) * 4 + (w4 & 3);
-  } else {
-    tile_m = tid_lin / tiles_n;
-    tile_n = tid_lin - tile_m * tiles_n;
-  }
+  auto locate = [&](const int b_, int& split_, int& tile_m_, int& tile_n_) {
+    const int xcd = b_ & 7, q = nwg >> 3, rr = nwg & 7;
+    const int item = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b_ >> 3);
+    split_ = item / nt;
+    const int tid_lin = item - split_ * nt;
+    if (((tiles_n | p.tiles_m) & 3) == 0) {
+      const int sn = tiles_n >> 2, s4 = tid_lin >> 4, w4 = tid_lin & 15;
+      tile_m_ = (s4 / sn) * 4 + (w4 >> 2);
+      tile_n_ = (s4 % sn) * 4 + (w4 & 3);
+    } else {
+      tile_m_ = tid_lin / tiles_n;
+      tile_n_ = tid_lin - tile_m_ * tiles_n;
+    }
+  };
+  int split, tile_m, tile_n;
+  locate(bid, split, tile_m, tile_n);
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const long k0 = (long)split * p.k_tiles * 64;
   // (fp8: one byte per element and pointers typed bf16 -- a K-major row advances by k0 two-byte units for 2 k0 bytes, an
   // MN-major image starts 2 k0 k-rows down and m0 / 2 two-byte units in)
   constexpr int F8S = FP8 ? 2 : 1;
-  const bf16_t* Ag = A_KMAJ ? p.A + m0 * p.lda + k0 : p.A + (F8S * k0) * p.lda + m0 / F8S;
-  const bf16_t* Bg = B_KMAJ ? p.B + n0 * p.ldb + k0 : p.B + (F8S * k0) * p.ldb + n0 / F8S;
+  auto a_origin = [&](const long m_, const long k_) { return A_KMAJ ? p.A + m_ * p.lda + k_ : p.A + (F8S * k_) * p.lda + m_ / F8S; };
+  auto b_origin = [&](const long n_, const long k_) { return B_KMAJ ? p.B + n_ * p.ldb + k_ : p.B + (F8S * k_) * p.ldb + n_ / F8S; };
+  const bf16_t* Ag = a_origin(m0, k0);
+  const bf16_t* Bg = b_origin(n0, k0);
+  // the workgroup's next output tile, when it walks a list of them (gemm_pp_persist_kernel)
+  const bf16_t *Ag_next = nullptr, *Bg_next = nullptr;
+  if (next_bid >= 0) {
+    int s2, tm2, tn2;
+    locate(next_bid, s2, tm2, tn2);
+    Ag_next = a_origin((long)tm2 * BM, (long)s2 * p.k_tiles * 64);
+    Bg_next = b_origin((long)tn2 * BN, (long)s2 * p.k_tiles * 64);
+  }
   const long a_step = A_KMAJ ? 64 : 64 * p.lda;
   const long b_step = B_KMAJ ? 64 : 64 * p.ldb;
 
@@ -714,7 +742,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
       if constexpr (MASK_LDS) {
         if (mask_lds) mask_dma(0, 2 * CM, mk_lds0);
       }
-    });
+    }, NoGather{}, 0, Ag_next, Bg_next, resumed);
   } else {
   StageOffsets<BM, A_KMAJ, NW> sa;
   StageOffsets<BN, B_KMAJ, NW> sb;
@@ -903,7 +931,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, char
   first_half(smem + slot * STAGE);
   second_half(F_{}, F_{}, kt, slot, slot);
   }
-  __syncthreads();  // every wave is done with the ring before the epilogue's reductions reuse LDS
+  // every wave is done with the ring before the epilogue's reductions reuse LDS -- not in a tile list's inner tiles: the ring
+  // already holds the next tile's first K tile (LDS-DMA still in flight: a __syncthreads() would drain it), and the
+  // epilogues that run there keep out of LDS (gemm_pp_persist_kernel)
+  if (next_bid < 0) __syncthreads();
   // ------------------------------ epilogue ------------------------------
   // The MFMAs are issued with the operands swapped (first operand = the B fragment), so the accumulator
   // of fragment (mi, ni) holds C^T: lane l owns row mi*16 + (l&15) of the wave tile and the FOUR CONSECUTIVE
@@ -1426,6 +1457,23 @@ template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI, i
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_bf16_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   gemm_body<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI, NSTAGE, FP8>(p, blockIdx.x, smem_dyn);
+}
+
+// A workgroup per CU walking a LIST of 256 x 256 output tiles (large batches: 16-32 tiles per CU).  Between two tiles of a
+// list the ping-pong loop never stops staging: the last K tile of tile i already pulls the first K tile (and a quarter) of
+// tile i + 1 into the ring, so tile i's epilogue runs while that LDS-DMA lands and tile i + 1 starts without a launch, a
+// cold first load or a ring fill (mainloop_pingpong, `Ag_next`).  The epilogues that run here keep out of LDS.  Virtual block
+// ids b, b + G, b + 2 G .. keep the XCD of the real block (G is a multiple of 8), so the XCD-aware item order holds.
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+__global__ void __launch_bounds__(512) gemm_pp_persist_kernel(const GemmArgs p) {
+  static_assert(EPI == EPI_BIAS_ACT_BF16, "tile lists: epilogues that do not use LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int nwg = p.tiles_m * p.tiles_n * p.splits, G = (int)gridDim.x;
+  bool resumed = false;
+  for (int vb = (int)blockIdx.x; vb < nwg; vb += G) {
+    gemm_body<256, 256, 2, 4, A_KMAJ, B_KMAJ, EPI, 8>(p, vb, smem_dyn, vb + G < nwg ? vb + G : -1, resumed);
+    resumed = true;
+  }
 }
 
 // Two independent GEMMs in ONE launch (blocks [0, n_first) run the first): neither of the

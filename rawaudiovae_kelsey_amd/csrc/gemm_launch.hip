@@ -53,6 +53,26 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   return RV_OK;
 }
 
+// The 256 x 256 ping-pong forward GEMM as tile lists (gemm_bf16.h gemm_pp_persist_kernel): one workgroup per CU
+template <bool AK, bool BK, int EPI>
+int launch_persist(const GemmArgs& a, long Mp, long Np, hipStream_t st) {
+  constexpr int smem = 2 * (256 + 256) * 128;
+  auto kern = gemm_pp_persist_kernel<AK, BK, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  GemmArgs g = a;
+  g.wt = rv_store_wt;
+  g.tiles_m = (int)(Mp / 256);
+  g.tiles_n = (int)(Np / 256);
+  g.splits = 1;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), smem, st, g);
+  RV_CHECK_LAUNCH();
+  return RV_OK;
+}
+
 // Smallest power-of-two split count that yields `target` blocks (each split costs a partial slab
 // that a later kernel re-reads, so no more than needed).
 int splits_for(long tiles, long k_tiles, int max_splits, long target = 256) {
@@ -93,6 +113,11 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
     case 5: return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
     case 7:
       if ((Kp / 64 / splits) % 2) return launch<256, 256, 2, 4, 2, AK, BK, EPI>(a, Mp, Np, splits, st);
+      if constexpr (EPI == EPI_BIAS_ACT_BF16) {
+        // more than two tiles per CU: tile lists (the fp8 forward's block maxima go through LDS: not there)
+        // (default.ini's shape, one box: 4592 -> 4546 us per step for fc1's and fc3's forward together, 741 -> 696 us)
+        if (splits == 1 && !a.amax_part && !a.a_hop && (Mp / 256) * (Np / 256) >= 512) return launch_persist<AK, BK, EPI>(a, Mp, Np, st);
+      }
       return launch<256, 256, 2, 4, 8, AK, BK, EPI>(a, Mp, Np, splits, st);
     default: return launch<256, 128, 2, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
   }

@@ -109,6 +109,27 @@ def test_all_tiles_all_layouts(L, tile, M, N, K, splits):
     np.testing.assert_allclose(out.sum(0).cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 128), (16640, 2048, 256), (8192, 4096, 512), (33024, 1024, 256)])
+def test_forward_gemm_tile_lists(L, M, N, K):
+    """Large batches: a forward GEMM with at least 512 tiles of 256 x 256 runs as tile lists -- one workgroup per CU, the
+    ping-pong loop staging across tile boundaries (gemm_pp_persist_kernel).  Same bits as the 128 x 128 tiles (the K order
+    of every output element is the same), ragged list lengths included (520 and 516 tiles over 256 workgroups)."""
+    rng = np.random.default_rng(31)
+    a = dev(rand_bf16(rng, (M, K), 0.5), torch.bfloat16); w = dev(rand_bf16(rng, (N, K), 0.1), torch.bfloat16)
+    bias = dev((rng.standard_normal(N) * 0.1).astype(np.float32))
+    o1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); o2 = torch.full_like(o1, 7.0)
+    L.rv_linear_fwd(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), M, N, K, 1, o1.data_ptr(), N, sp())
+    L.rv_gemm_force_tile(4)
+    try:
+        L.rv_linear_fwd(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), M, N, K, 1, o2.data_ptr(), N, sp())
+    finally:
+        L.rv_gemm_force_tile(-1)
+    assert torch.equal(o1, o2)
+    rows = rng.choice(M, 64, replace=False)
+    ref = np.maximum(a[rows].float().cpu().numpy().astype(np.float64) @ w.float().cpu().numpy().astype(np.float64).T + bias.cpu().numpy(), 0)
+    np.testing.assert_allclose(o1[rows].float().cpu().numpy(), ref, rtol=1e-2, atol=1e-3)
+
+
 def test_all_tiles_fused_epilogues(L, tile):
     """bias+ReLU, mask+colsum and tanh+loss epilogues under every tile configuration."""
     from rawaudiovae_kelsey_amd._lib import gemm_tile
