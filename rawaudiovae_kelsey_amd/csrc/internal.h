@@ -11,6 +11,7 @@ RV_INTERNAL int rv_gemm_tile(long Mp, long Np, int splits, int* bm, int* bn);
 // whether rv_latent_fwd / rv_latent_bwd run their row-local kernels on this shape (1) or the GEMM forms (0): csrc/latent.hip
 RV_INTERNAL int rv_latent_rowlocal(long Bp, long Hp, long Lp);
 RV_INTERNAL int rv_latent_bwd_pp(long Bp, long Hp, long Lp);
+RV_INTERNAL int rv_latent_bwd_tile_rows(long Bp, long Hp, long Lp);
 // ... of the fused loss forward on fp8 operands (never 256 x 256)
 RV_INTERNAL int rv_gemm_tile_fp8_loss(long Mp, long Np, int* bm, int* bn);
 RV_INTERNAL int rv_dgrad_wgrad_pick(long Mp, long Np, long Kp, int* paired, int* bm_dgrad, int* splits);

@@ -877,6 +877,13 @@ extern "C" {
 // large batches.  One predicate for both directions and for the plan (internal.h).
 int rv_latent_rowlocal(long Bp, long Hp, long Lp) { return Lp == 64 && Hp % 512 == 0 && Hp <= 2048 && Bp <= 8192; }
 
+// Batch rows behind one NON-ZERO row of rv_latent_bwd's bias partial table [Bp / 16][2 Lp] (the rows between are written as
+// zeros): 16 for the row-local kernel, the dz tile's rows for the GEMM forms.  The plan's optimizer descriptors skip the zeros.
+int rv_latent_bwd_tile_rows(long Bp, long Hp, long Lp) {
+  if (rv_latent_rowlocal(Bp, Hp, Lp)) return 16;
+  return (Lp >= 128 && (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0) ? 256 : 64;
+}
+
 // The latent backward's ping-pong form (k_dz_reparam_gemm<2>): a large batch at a padded latent width of 256.  Its dW3 blocks are
 // 256 x 256 tiles over Hp / 256 row tiles, so the plan splits K until they fill the chip once (even K tiles per block).
 int rv_latent_bwd_pp(long Bp, long Hp, long Lp) {
@@ -975,7 +982,7 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     n_w3 = g.tiles_m * g.tiles_n * g.splits;
   }
   if (!rowlocal) {   // GEMM form: dz tiles with the reparameterisation backward in their epilogue (k_dz_reparam_gemm)
-    const bool big = Lp >= 128 && (Bp / 64) * (Lp / 64) > LG_BIG_TILES && Bp % 256 == 0;
+    const bool big = rv_latent_bwd_tile_rows(Bp, Hp, Lp) == 256;
     const bool pp = rv_latent_bwd_pp(Bp, Hp, Lp) && (!z_bf16 || g.k_tiles % 2 == 0);
     GemmArgs d{};
     d.A = (const bf16_t*)dp3_bf16; d.lda = lddp; d.B = (const bf16_t*)w3_bf16; d.ldb = ldw3;

@@ -168,8 +168,19 @@ static bool heads_streaming(const rv_plan* p) {
   // GEMM forms take over with the other latent-sized launches)
   return p->latent_fused && p->hb_groups > 0 && rv_latent_rowlocal(p->Bp, p->Hp, p->Lp);
 }
+static bool latent_bwd_fused(const rv_plan* p);
 static void heads_mode_apply(rv_plan* p) {
   const bool st = heads_streaming(p);
+  {
+    // the head biases' partial rows [Bp / 16][2 Lp]: rv_reparam_bwd and the row-local backward fill every row, the GEMM forms of
+    // rv_latent_bwd one row per dz tile (64 or 256 batch rows) and zeros between -- the descriptors step over those (at
+    // default.ini's batch 8192 rows of which 512 count: the optimizer's cooperative reduction walked them all, 120 us)
+    const long rows = latent_bwd_fused(p) ? rv_latent_bwd_tile_rows(p->Bp, p->Hp, p->Lp) : 16;
+    for (int i : {3, 5}) {
+      p->d_slab[i].grad_splits = (int)(p->Bp / rows);
+      p->d_slab[i].grad_split_stride = (rows / 16) * p->L2p;
+    }
+  }
   p->s_wh = st ? p->hb_groups : p->s_wh_gen;
   p->n_mt1 = st ? p->hb_groups : p->n_mt1_gen;
   p->d_slab[1].grad_splits = p->n_mt1;
@@ -195,6 +206,7 @@ static void heads_mode_apply(rv_plan* p) {
   }
   if (!p->b.grad) {   // without a flat gradient arena d_flat mirrors the slab descriptors
     p->d_flat[1].grad_splits = p->n_mt1;
+    for (int i : {3, 5}) { p->d_flat[i].grad_splits = p->d_slab[i].grad_splits; p->d_flat[i].grad_split_stride = p->d_slab[i].grad_split_stride; }
     for (int i : {2, 4}) {
       p->d_flat[i].grad_splits = p->s_wh;
       p->d_flat[i].grad_half = p->d_slab[i].grad_half; p->d_flat[i].grad_unscale = p->d_slab[i].grad_unscale;
