@@ -20,6 +20,7 @@ bash tools/pmc_sq_shape.sh r06_default_ini 1024 2048 256 131072 > /dev/null 2>&1
 bash tools/r06_sweep.sh > $O/r06_batch_sweep_table.txt 2>&1; cp $O/r06/batch_sweep.jsonl $O/r06_batch_sweep.jsonl; cat $O/r06_batch_sweep_table.txt
 python tools/big_batch_gemms.py 131072 2>&1 | grep -v amdgpu > $O/r06_big_batch_gemms.txt; cat $O/r06_big_batch_gemms.txt
 python tools/latent_k_sweep.py 2>&1 | grep -v amdgpu > $O/r06_latent_k_sweep.txt; cat $O/r06_latent_k_sweep.txt
+python tools/large_batch_k_sweep.py 2>&1 | grep -v amdgpu > $O/r06_large_batch_k_sweep.txt; cat $O/r06_large_batch_k_sweep.txt
 { python tools/ddp_model.py; echo; echo "== the same reference point with stand-in workgroups that take their CUs whole (64 KB of LDS each)"; RV_MODEL_LDS=65536 python tools/ddp_model.py 8 300 15 bf16 | grep "^8\|^(stand"; } 2>/dev/null > $O/r06_ddp_model.txt; cat $O/r06_ddp_model.txt
 bash tools/ddp_one_rank.sh r06 > /dev/null 2>&1; cat $O/r06_ddp_one_rank.txt
 for i in 1 2 3; do python tools/deep_bench.py 2>/dev/null | tail -1; done > $O/r06_deep.txt; cat $O/r06_deep.txt
