@@ -189,7 +189,12 @@ int rv_heads_reparam_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long
  * of 512 up to 2048.  18.8 us against 21-22 us for the three launches at C2 (profiles/r03_*): the training plan's
  * default where it applies (rv_plan_set_option, RV_OPT_LATENT_FUSED).
  * w3_bf16 == NULL: heads + reparameterisation only (bias3, h3_bf16 unused; 576 KB per CU instead of 832); fc3 is then
- * the caller's (rv_linear_fwd). */
+ * the caller's (rv_linear_fwd).
+ * Padded latent widths 128 / 256 (the reference's own latent_dim = 256, default.ini:18), batches above 8192 and other
+ * hidden widths (multiples of 128): the same call runs its GEMM form -- the heads GEMM on 64 x 128 tiles (256-row tiles at
+ * large batches: 256 x 128, from Lp = 128 on 256 x 256 ping-pong) with bias, eps, exp, z and the KL partials in the
+ * epilogue, then fc3 as a forward GEMM.  Same outputs and eps draws; kl_partial [Bp Lp / 1024] then holds one non-zero
+ * slot per tile and zeros in the others (only the sum is defined). */
 int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, const float* bias_heads,
                   const void* w3_bf16, long ldw3, const float* bias3, long Bp, long Hp, long Lp, long B, long L,
                   const float* eps_in, float* eps_out, unsigned long long seed, const long long* step_counter,
@@ -201,7 +206,11 @@ int rv_latent_fwd(const void* h_bf16, long ldh, const void* wh_bf16, long ldwh, 
  * rv_reparam_bwd with dP3 [Bp, Hp] bf16 and W3 [Hp, Lp] bf16 ([out, in]) in place of the dz slabs; dz differs from the
  * split-K route by fp32 summation order only.  With z_bf16 != NULL the launch also computes fc3's weight gradient
  * dW3 [Hp, Lp] = dP3^T z as `dw3_splits` fp32 slabs (rv_linear_wgrad's result, bit for bit) on extra workgroups that
- * share the CUs with the dz workgroups (80 KiB of LDS each): the second read of dP3 fills the bubbles of the first. */
+ * share the CUs with the dz workgroups (80 KiB of LDS each): the second read of dP3 fills the bubbles of the first.
+ * GEMM form (same shapes as rv_latent_fwd's): dz tiles of 64 rows (256 at large batches; ONE 256 x 256 ping-pong tile per
+ * 256 rows at Lp = 256) with the reparameterisation backward in the epilogue, dW3 on the launch's first workgroups.
+ * dbh_partial [Bp / 16][2 Lp] keeps its layout: the row-local kernel fills every row, the GEMM forms the first row of each
+ * dz tile's rows and ZEROS in the rest (a reader may sum every row, or every (tile rows / 16)-th). */
 int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw3, long Bp, long Hp, long Lp, long B,
                   long L, long S, const float* mulv, const float* eps, float kl_beta, const float* dmu_ext,
                   const float* dlv_ext, void* dmulv_bf16, float* dbh_partial, const float* mse_partial, int n_mse,

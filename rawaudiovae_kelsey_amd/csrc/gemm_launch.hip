@@ -23,6 +23,7 @@ namespace {
 //   5: 256x256 2x4 waves of 128x64, 2 stages (128 KiB ring); only
 //      picked by the paired dgrad+wgrad launch (no single GEMM of the step has 256 such tiles)
 int g_force_tile = -1;   // test hook (include/rawvae_hip_diag.h): pin one tile configuration, -1 = the picker's choice
+int g_tile_lists = 1;    // test hook: 256 x 256 forward GEMMs with many tiles as tile lists (launch_tile, case 7)
 
 template <int BM, int BN, int WGM, int WGN, int NSTAGE, bool AK, bool BK, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
@@ -116,7 +117,7 @@ int launch_tile(int tile, const GemmArgs& a, long Mp, long Np, long Kp, int spli
       if constexpr (EPI == EPI_BIAS_ACT_BF16) {
         // more than two tiles per CU: tile lists (the fp8 forward's block maxima go through LDS: not there)
         // (default.ini's shape, one box: 4592 -> 4546 us per step for fc1's and fc3's forward together, 741 -> 696 us)
-        if (splits == 1 && !a.amax_part && !a.a_hop && (Mp / 256) * (Np / 256) >= 512) return launch_persist<AK, BK, EPI>(a, Mp, Np, st);
+        if (g_tile_lists && splits == 1 && !a.amax_part && !a.a_hop && (Mp / 256) * (Np / 256) >= 512) return launch_persist<AK, BK, EPI>(a, Mp, Np, st);
       }
       return launch<256, 256, 2, 4, 8, AK, BK, EPI>(a, Mp, Np, splits, st);
     default: return launch<256, 128, 2, 2, 3, AK, BK, EPI>(a, Mp, Np, splits, st);
@@ -362,6 +363,7 @@ extern "C" int rv_gemm_pick(long Mp, long Np, long Kp, int max_splits, int* bm, 
 // (-1: the picker's choice), or -- 102 / 108 -- the main loop of the paired 256x256 launch (two-slot ring / ping-pong).
 extern "C" int rv_gemm_force_tile(int tile) {
   if (tile == 102 || tile == 108) { g_pair_loop = tile - 100; return RV_OK; }
+  if (tile == 110 || tile == 111) { g_tile_lists = tile - 110; return RV_OK; }
   g_force_tile = tile;
   return RV_OK;
 }
