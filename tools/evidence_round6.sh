@@ -17,6 +17,7 @@ bash tools/pmc_round.sh r06 > /dev/null 2>&1; tail -12 $O/r06_traffic.txt
 bash tools/pmc_sq_step.sh r06 > $O/r06_pmc_sq.log 2>&1; head -14 $O/r06_pmc_sq_summary.txt
 bash tools/pmc_sq_shape.sh r06_refini 1024 2048 256 4096 > /dev/null 2>&1; head -16 $O/r06_refini_pmc_sq.txt
 bash tools/pmc_sq_shape.sh r06_default_ini 1024 2048 256 131072 > /dev/null 2>&1; head -16 $O/r06_default_ini_pmc_sq.txt
+bash tools/pmc_traffic_shape.sh r06_default_ini 1024 2048 256 131072 > /dev/null 2>&1; cat $O/r06_default_ini_traffic.txt
 bash tools/r06_sweep.sh > $O/r06_batch_sweep_table.txt 2>&1; cp $O/r06/batch_sweep.jsonl $O/r06_batch_sweep.jsonl; cat $O/r06_batch_sweep_table.txt
 python tools/big_batch_gemms.py 131072 2>&1 | grep -v amdgpu > $O/r06_big_batch_gemms.txt; cat $O/r06_big_batch_gemms.txt
 python tools/latent_k_sweep.py 2>&1 | grep -v amdgpu > $O/r06_latent_k_sweep.txt; cat $O/r06_latent_k_sweep.txt
