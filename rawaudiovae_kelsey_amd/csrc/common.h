@@ -1,10 +1,24 @@
 // Shared device/host helpers for librawvae_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
 namespace rv {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: a kernel is opted in once per device of this process
+// (`done`: one bit per device ordinal, a static at the call site; a lost race only repeats an idempotent call).
+inline void lds_opt_in(const void* kern, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_relaxed) & bit)) {
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
+  }
+}
+
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -38,11 +38,8 @@ int launch(const GemmArgs& a, long Mp, long Np, int splits, hipStream_t st) {
   const int used = (NSTAGE >= 8 ? RING : (a.k_tiles < RING ? a.k_tiles : RING)) * stage_bytes + mask_extra;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, AK, BK, EPI, NSTAGE, FP8>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)kern, smem_max, attr_done);
   GemmArgs g = a;
   g.wt = rv_store_wt;
   g.tiles_m = (int)(Mp / BM);
@@ -59,11 +56,8 @@ template <bool AK, bool BK, int EPI>
 int launch_persist(const GemmArgs& a, long Mp, long Np, hipStream_t st) {
   constexpr int smem = 2 * (256 + 256) * 128;
   auto kern = gemm_pp_persist_kernel<AK, BK, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)kern, smem, attr_done);
   GemmArgs g = a;
   g.wt = rv_store_wt;
   g.tiles_m = (int)(Mp / 256);
@@ -224,11 +218,8 @@ int launch_pair(const GemmArgs& d_in, const GemmArgs& g_in, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128 + 8 * 4096;  // the ring (the epilogue's reductions reuse its first bytes) + the
                                                          // first ReLU-mask chunk of the dgrad blocks (gemm_bf16.h MASK_LDS)
   auto kern = gemm_dgrad_wgrad_kernel<BM, BN, WGM, WGN, NSTAGE, FP8>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)kern, smem, attr_done);
   if (g_pair_stop_event) {
     // the launch's own completion signal as a HIP event: 3.7 us of bubble behind this kernel on its stream instead of the
     // 5.7 a hipEventRecord behind it costs, and 7 us instead of 11 to the dependent kernel on the other stream
@@ -253,11 +244,8 @@ int launch_dual(const GemmArgs& a, long Mp1, long Np1, int splits1, const GemmAr
   const int used = (kt < NSTAGE ? kt : NSTAGE) * stage_bytes;
   const int smem = used > epi_bytes ? used : epi_bytes;
   auto kern = gemm_dual_kernel<BM, BN, WGM, WGN, NSTAGE, A1, B1, E1, A2, B2, E2>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)kern, smem_max, attr_done);
   GemmArgs g1 = a, g2 = b;
   g1.wt = g2.wt = rv_store_wt;
   g1.tiles_m = (int)(Mp1 / BM); g1.tiles_n = (int)(Np1 / BN); g1.splits = splits1;
@@ -598,11 +586,8 @@ static int wgrad_riders(const char* who, const void* dy, long lddy, const void* 
   const bool pp = g.k_tiles % 2 == 0;
   const int which = fp8 ? 2 : (pp ? 1 : 0);
   auto kern = fp8 ? gemm_wgrad_adam_kernel<8, true> : (pp ? gemm_wgrad_adam_kernel<8, false> : gemm_wgrad_adam_kernel<2, false>);
-  static bool attr_done[3] = {false, false, false};
-  if (!attr_done[which]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done[which] = true;
-  }
+  static std::atomic<unsigned long long> attr_done[3];
+  lds_opt_in((const void*)kern, smem, attr_done[which]);
   hipLaunchKernelGGL(kern, dim3((unsigned)(n_gemm + n_rider_blocks)), dim3(512), smem, (hipStream_t)stream, g, n_gemm, tab,
                      param, exp_avg, exp_avg_sq, lr, grad_scale, step_counter, stream_mode, fin_f32, fin_bf16, tail_vb);
   RV_CHECK_LAUNCH();

@@ -854,13 +854,12 @@ int heads_reparam_gemm(const void* h, long ldh, const void* wh, long ldwh, const
   a.bias = bias_heads; a.lat_lp = Lp; a.lat_l = L; a.eps_in = eps_in; a.eps_out = eps_out; a.seed = seed;
   a.step_counter = step_counter; a.mulv = mulv; a.z = (bf16_t*)z; a.kl_partial = kl_partial;
   a.wt = rv_store_wt;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, HG_LDS);
-    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
-    (void)hipFuncSetAttribute((const void*)k_heads_reparam_gemm_pp, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done0{0};
+  lds_opt_in((const void*)k_heads_reparam_gemm, HG_LDS, attr_done0);
+  static std::atomic<unsigned long long> attr_done1{0};
+  lds_opt_in((const void*)k_heads_reparam_gemm_big, HGB_LDS, attr_done1);
+  static std::atomic<unsigned long long> attr_done2{0};
+  lds_opt_in((const void*)k_heads_reparam_gemm_pp, PP_LDS, attr_done2);
   if (pp) hipLaunchKernelGGL(k_heads_reparam_gemm_pp, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), PP_LDS, st, a);
   else if (big) hipLaunchKernelGGL(k_heads_reparam_gemm_big, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HGB_LDS, st, a);
   else hipLaunchKernelGGL(k_heads_reparam_gemm, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), HG_LDS, st, a);
@@ -936,11 +935,8 @@ int rv_latent_fwd_ex(const void* h_bf16, long ldh, const void* wh_bf16, long ldw
   RV_REQUIRE((((uintptr_t)h_bf16 | (uintptr_t)wh_bf16 | (uintptr_t)w3_bf16 | (uintptr_t)bias_heads | (uintptr_t)bias3 |
                (uintptr_t)mulv | (uintptr_t)z_bf16 | (uintptr_t)h3_bf16) & 15) == 0,
              RV_ERR_SHAPE, "rv_latent_fwd: operands must be 16-byte aligned");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_latent_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)k_latent_fwd, L_LDS, attr_done);
   hipLaunchKernelGGL(k_latent_fwd, dim3((unsigned)(Bp / LAT_ROWS)), dim3(512), L_LDS, (hipStream_t)stream,
                      (const bf16_t*)h_bf16, ldh, (const bf16_t*)wh_bf16, ldwh, bias_heads, (const bf16_t*)w3_bf16, ldw3, bias3,
                      Hp, B, L, eps_in, eps_out, (uint64_t)seed, step_counter, mulv, (bf16_t*)z_bf16, kl_partial,
@@ -993,13 +989,12 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     d.dmulv = (bf16_t*)dmulv_bf16; d.dbh_partial = dbh_partial;
     d.wt = rv_store_wt;
     const int n_dz = d.tiles_m * d.tiles_n;
-    static bool attr_gemm = false;
-    if (!attr_gemm) {
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, DZ_LDS);
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, HGB_LDS);
-      (void)hipFuncSetAttribute((const void*)k_dz_reparam_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-      attr_gemm = true;
-    }
+    static std::atomic<unsigned long long> attr_gemm0{0};
+    lds_opt_in((const void*)k_dz_reparam_gemm<0>, DZ_LDS, attr_gemm0);
+    static std::atomic<unsigned long long> attr_gemm1{0};
+    lds_opt_in((const void*)k_dz_reparam_gemm<1>, HGB_LDS, attr_gemm1);
+    static std::atomic<unsigned long long> attr_gemm2{0};
+    lds_opt_in((const void*)k_dz_reparam_gemm<2>, PP_LDS, attr_gemm2);
     if (pp)
       hipLaunchKernelGGL(k_dz_reparam_gemm<2>, dim3((unsigned)(n_dz + n_w3 + 1)), dim3(512), PP_LDS, (hipStream_t)stream, d, g,
                          n_dz, n_w3, B, L, S, kl_beta, mse_partial, n_mse, kl_partial, n_kl, loss_out, step_counter, ring);
@@ -1012,11 +1007,8 @@ int rv_latent_bwd(const void* dp3_bf16, long lddp, const void* w3_bf16, long ldw
     RV_CHECK_LAUNCH();
     return RV_OK;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_latent_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  lds_opt_in((const void*)k_latent_bwd, LB_LDS, attr_done);
   const int n_rows = (int)(Bp / LAT_ROWS);
   hipLaunchKernelGGL(k_latent_bwd, dim3((unsigned)(n_rows + n_w3 + 1)), dim3(256), LB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dp3_bf16, lddp, (const bf16_t*)w3_bf16, ldw3, Hp, B, L, S, mulv, eps, kl_beta, dmu_ext,
@@ -1055,12 +1047,9 @@ int rv_heads_bwd_ex(const void* dmulv_bf16, const void* wh_bf16, long ldw, const
   const bool q8 = dp1_fp8 || amax_part, h16 = dwh_unscale != nullptr;
   RV_REQUIRE(!h16 || Hp % 32 == 0, RV_ERR_SHAPE, "rv_heads_bwd: fp16 slabs need a padded hidden width that is a multiple of 32");
   auto kern = q8 ? (h16 ? k_heads_bwd<true, true> : k_heads_bwd<true, false>) : (h16 ? k_heads_bwd<false, true> : k_heads_bwd<false, false>);
-  static bool attr_done[4] = {false, false, false, false};
+  static std::atomic<unsigned long long> attr_done[4];
   const int which = 2 * q8 + h16;
-  if (!attr_done[which]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
-    attr_done[which] = true;
-  }
+  lds_opt_in((const void*)kern, HB_LDS, attr_done[which]);
   hipLaunchKernelGGL(kern, dim3((unsigned)((Bp / HB_RG) * (Hp / 64))), dim3(512), HB_LDS, (hipStream_t)stream,
                      (const bf16_t*)dmulv_bf16, (const bf16_t*)wh_bf16, ldw, (const bf16_t*)h1_bf16, ldh, (bf16_t*)dp1_bf16, ldp,
                      db1_partial, dwh_slabs, lddw, Hp, rv_store_wt, (unsigned char*)dp1_fp8, ldq, q_scale, amax_part, dwh_unscale);
