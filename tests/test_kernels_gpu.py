@@ -781,6 +781,33 @@ def test_paired_dgrad_wgrad(L, force, loop, M, N, K):
         L.rv_gemm_force_tile(108)    # the default
 
 
+@pytest.mark.parametrize("M,N,K,rounds", [(8192, 2048, 512, 2), (8192, 1024, 1024, 1), (12288, 2048, 512, 3), (8192, 2048, 1024, 2)])
+def test_paired_dgrad_wgrad_several_rounds(L, M, N, K, rounds):
+    """The picker pairs dgrad + wgrad into one 256 x 256 launch while their blocks come to one round of the 256 CUs or two to
+    four rounds filled to three quarters (rv_dgrad_wgrad_pick; B = 8192 / 16384 in the batch sweep): the paired launch against
+    float64 at those sizes, the block count checked from the picker's own numbers."""
+    from rawaudiovae_kelsey_amd._lib import dgrad_wgrad_pick
+    rng = np.random.default_rng(47)
+    dy, w = rand_bf16(rng, (M, K), 0.1), rand_bf16(rng, (K, N), 0.1)
+    x = O.bf16_round(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32))
+    paired, bm, splits = dgrad_wgrad_pick(M, N, K)
+    blocks = (M // 256) * (N // 256) + (K // 256) * (N // 256) * splits
+    assert paired == 1 and bm == 256 and -(-blocks // 256) == rounds, (paired, bm, splits, blocks)
+    DY, W, X = dev(dy, torch.bfloat16), dev(w, torch.bfloat16), dev(x, torch.bfloat16)
+    dx = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    cs = torch.zeros((M // bm, N), dtype=torch.float32, device="cuda")
+    dw = torch.full((splits, K, N), 7.0, dtype=torch.float32, device="cuda")
+    L.rv_linear_dgrad_wgrad(DY.data_ptr(), K, W.data_ptr(), N, X.data_ptr(), N, M, N, K, dx.data_ptr(), N,
+                            cs.data_ptr(), dw.data_ptr(), N, splits, 0, None, sp())
+    # float64 on the GPU (a 12288 x 2048 x 512 contraction takes numpy tens of seconds)
+    d64, w64, x64 = DY.double(), W.double(), X.double()
+    ref_dx = (d64 @ w64) * (x64 > 0)
+    ref_dw = d64.T @ x64
+    assert float((dx.double() - ref_dx).abs().max()) <= 2 ** -7 * float(ref_dx.abs().max())
+    assert torch.allclose(cs.double().sum(0), ref_dx.sum(0), rtol=1e-4, atol=1e-4 * float(ref_dx.sum(0).abs().max()))
+    assert torch.allclose(dw.double().sum(0), ref_dw, rtol=1e-5, atol=1e-5 * float(ref_dw.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,ds,ws", [(512, 64, 256, 2, 4), (4096, 64, 2048, 4, 8), (256, 256, 512, 1, 2), (384, 128, 192, 1, 1)])
 def test_linear_dgrad_wgrad_f32(L, M, N, K, ds, ws):
     """rv_linear_dgrad_wgrad_f32: dX = dY W as fp32 split slabs and dW = dY^T X slabs -- one dual launch when
