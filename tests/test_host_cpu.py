@@ -224,6 +224,46 @@ def test_plan_descriptors_follow_the_heads_backward_in_use():
         L.rv_plan_destroy(plan)
 
 
+def test_large_batch_plan_rules():
+    """Host-only: the rules a large batch switches on (default.ini:27 trains at batch_size 131072).  The head biases'
+    partial table keeps one row per 16 batch rows, but the optimizer's descriptors step over the rows the GEMM forms of
+    the latent backward leave zero (one non-zero row per dz tile: 64 rows, 256 at large batches); fc3's weight gradient
+    gets 16 K splits beside the 256 x 256 dz tiles; dgrad + wgrad are paired while their blocks come to one round of the
+    256 CUs or two to four rounds filled to three quarters."""
+    import ctypes as C
+    from rawaudiovae_kelsey_amd import _lib
+    L = _lib.lib()
+    rows_expected = {(4096, 64): 16, (4096, 256): 64, (16384, 256): 64, (32768, 256): 256, (131072, 256): 256, (131072, 64): 64,
+                     (131072, 128): 256}
+    for (B, Lt), rows in rows_expected.items():
+        plan = C.c_void_p()
+        L.rv_plan_create(C.byref(plan), B, 1024, 2048, Lt)
+        base = 0x10000000
+        bufs = _lib.PlanBuffers(param=base, exp_avg=base + 0x4000000, exp_avg_sq=base + 0x8000000, grad=base + 0xc000000,
+                                workspace=base + 0x10000000, step_counter=base + 0x100, loss_ring=base + 0x1000, ring=4)
+        L.rv_plan_bind(plan, C.byref(bufs))
+        arr = (_lib.ParamDesc * 10)()
+        L.rv_plan_descs(plan, arr, 0)
+        Lp = 64 if Lt <= 64 else 128 if Lt <= 128 else 256
+        for i in (3, 5):
+            assert arr[i].grad_splits == B // rows and arr[i].grad_split_stride == rows // 16 * 2 * Lp, (B, Lt, i)
+        if (B, Lt) == (131072, 256):
+            assert arr[6].grad_splits == 16          # dW3: 8 tiles of 256 x 256 x 16 K splits, first in the dz launch's grid
+        L.rv_plan_set_option(plan, _lib.OPT_LATENT_FUSED, 0)     # the generic route: rv_reparam_bwd fills every row
+        L.rv_plan_descs(plan, arr, 0)
+        assert arr[3].grad_splits == arr[5].grad_splits == B // 16 and arr[3].grad_split_stride == 2 * Lp
+        L.rv_plan_destroy(plan)
+    # (batch, in features, out features) -> paired?, rounds of 256 blocks
+    for (M, N, K), want in {(4096, 2048, 1024): (1, 1), (8192, 2048, 1024): (1, 2), (8192, 2048, 512): (1, 2),
+                            (16384, 2048, 512): (1, 3), (16384, 2048, 1024): (1, 4), (32768, 2048, 1024): (0, 0),
+                            (131072, 2048, 1024): (0, 0)}.items():
+        paired, bm, sp = _lib.dgrad_wgrad_pick(M, N, K)
+        assert paired == want[0], (M, N, K, paired, sp)
+        if paired:
+            blocks = (M // 256) * (N // 256) + (K // 256) * (N // 256) * sp
+            assert -(-blocks // 256) == want[1] and bm == 256
+
+
 def test_private_torch_entry_points_are_feature_tested_with_public_fallbacks(monkeypatch):
     """The drop-in loop's host path leans on three torch entry points outside the documented API
     (`torch.autograd.graph.increment_version`, `torch._foreach_add_`, `torch._C._cuda_getCurrentRawStream`).  Each is
